@@ -1,0 +1,62 @@
+"""ctypes loader for the C-ABI HIP library (include/psdf.h).  The product path has NO fallback:
+if the library is missing or a symbol is absent we raise, loudly."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpsdf_hip.so")
+_lib = None
+
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+c_p = ctypes.c_void_p
+c_u64 = ctypes.c_uint64
+
+
+class PsdfError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PsdfError(
+                "permuto_sdf_amd: HIP extension %s not found. Build it with "
+                "`python -m permuto_sdf_amd.build` (hipcc, gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def ptr(t):
+    """Raw device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(status, name):
+    if status != 0:
+        raise PsdfError("%s failed with status %d (%s)" % (
+            name, status, "argument error" if status == -1 else "unsupported configuration" if status == -2
+            else "HIP error code"))
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    fn.restype = ctypes.c_int
+    check(fn(*args), name)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PsdfError("permuto_sdf_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)

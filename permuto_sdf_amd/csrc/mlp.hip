@@ -1,0 +1,335 @@
+// Fused small-MLP evaluator for gfx950 (fp32 MFMA, LDS-staged weight tiles).
+// Replaces the torch.nn.Sequential(Linear, GELU, ...) evaluators of the reference
+// (permuto_sdf_py/models/models.py:153-161 SDF net, :451-470 background nets, :54-129,350 colour net,
+// and the BASELINE 64x3 SDF variant).  The reference has no native MLP code; the oracle is torch.nn fp32.
+//
+// Formulation: everything is computed TRANSPOSED, Z^T[out x samples] = W[out x in] * H^T[in x samples],
+// with v_mfma_f32_32x32x2_f32.  One wave owns a tile of 32 samples.
+//   A operand (1 VGPR): lane l holds W[32*to + (l&31)][k(l>>5)]         -> read from LDS, pre-packed
+//   B operand (1 VGPR): lane l holds H^T[k(l>>5)][sample (l&31)]
+//   D (16 VGPRs):       lane l, reg r holds Z^T[32*to + (r&3)+8*(r>>2)+4*(l>>5)][sample (l&31)]
+// Because a dot product may visit k in any order as long as A and B agree, the k-step "(tile ti, reg r)"
+// is defined as the neuron pair { 32*ti + (r&3)+8*(r>>2) + 4*h : h = 0,1 }: then register r of the previous
+// layer's D tile IS the B operand of that k-step.  Activations never leave registers and need no
+// cross-lane movement between layers; only the weights are permuted (once, by psdf_mlp_pack).
+// The first layer reads its B operand straight from the feature-major encoding output [K0, N]
+// (two 128-B segments per wave load); the result is stored feature-major [OUT, N].
+#include "psdf_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int MAXL = 5;  // max number of linear layers
+
+struct MlpPlan {
+  int n_layers;        // number of linear layers (hidden layers + 1)
+  int dims[MAXL + 1];  // true widths: dims[0] = input, dims[n_layers] = output
+  int in_steps0;       // ceil(dims[0]/2)
+  int tiles[MAXL + 1]; // tiles[i] = ceil(dims[i]/32) for i>=1
+  int w_off[MAXL];     // float offsets into the packed buffer
+  int b_off[MAXL];
+  int total;           // packed floats
+  int final_dot;       // 1 when the last layer is evaluated with VALU dot products (out <= 4)
+};
+
+__host__ __device__ inline int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+static int make_plan(int n_layers, const int* dims, MlpPlan& p) {
+  if (n_layers < 2 || n_layers > MAXL) return PSDF_ERR_ARG;
+  p.n_layers = n_layers;
+  for (int i = 0; i <= n_layers; i++) {
+    if (dims[i] <= 0) return PSDF_ERR_ARG;
+    p.dims[i] = dims[i];
+    p.tiles[i] = (dims[i] + 31) / 32;
+  }
+  p.in_steps0 = (dims[0] + 1) / 2;
+  p.final_dot = dims[n_layers] <= 4;
+  int off = 0;
+  for (int l = 0; l < n_layers; l++) {
+    p.w_off[l] = off;
+    const bool last = (l == n_layers - 1);
+    if (l == 0)
+      off += p.tiles[1] * p.in_steps0 * 64;
+    else if (last && p.final_dot)
+      off += dims[n_layers] * p.tiles[l] * 32;
+    else
+      off += p.tiles[l + 1] * p.tiles[l] * 16 * 64;
+    p.b_off[l] = off;
+    off += (last && p.final_dot) ? 4 : p.tiles[l + 1] * 32;
+  }
+  p.total = off;
+  return PSDF_OK;
+}
+
+// ---------------------------------------------------------------------------------------- packing
+// One thread per packed float.  W_l is torch layout [dims[l+1]][dims[l]] row major.
+struct PackArgs {
+  MlpPlan plan;
+  const float* W[MAXL];
+  const float* b[MAXL];
+};
+
+__global__ void mlp_pack_kernel(PackArgs a, float* __restrict__ packed) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const MlpPlan& p = a.plan;
+  if (e >= p.total) return;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < MAXL; i++)
+    if (i < p.n_layers && e >= p.w_off[i]) l = i;
+  const int out_d = p.dims[l + 1], in_d = p.dims[l];
+  const bool last = (l == p.n_layers - 1);
+  float v = 0.f;
+  if (e >= p.b_off[l]) {
+    const int row = e - p.b_off[l];
+    if (row < out_d) v = a.b[l][row];
+  } else {
+    const int q = e - p.w_off[l];
+    int row, col;
+    if (l == 0) {  // [to][s][lane]
+      const int lane = q & 63, s = (q >> 6) % p.in_steps0, to = (q >> 6) / p.in_steps0;
+      row = 32 * to + (lane & 31);
+      col = 2 * s + (lane >> 5);
+    } else if (last && p.final_dot) {  // [o][ti][r][h]
+      const int h = q & 1, r = (q >> 1) & 15, ti = (q >> 5) % p.tiles[l], o = (q >> 5) / p.tiles[l];
+      row = o;
+      col = 32 * ti + row_of(r, h);
+    } else {  // [to][ti][r][lane]
+      const int lane = q & 63, r = (q >> 6) & 15, ti = (q >> 10) % p.tiles[l], to = (q >> 10) / p.tiles[l];
+      row = 32 * to + (lane & 31);
+      col = 32 * ti + row_of(r, lane >> 5);
+    }
+    if (row < out_d && col < in_d) v = a.W[l][(int64_t)row * in_d + col];
+  }
+  packed[e] = v;
+}
+
+// -------------------------------------------------------------------------------------- device math
+// erf with < 1 ulp error, branch-free (both ranges evaluated, then selected): a ~20-instruction VALU
+// sequence instead of the two-branch library erff, which matters because 96 GELUs per lane sit between
+// the MFMA chains of every tile.  Polynomials: the widely used single-precision minimax pair
+// (|x| <= 0.927734375: odd polynomial in x; above: 1 - exp(p(|x|))).
+__device__ __forceinline__ float erf_fast(float a) {
+  const float t = fabsf(a);
+  const float s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float hi = copysignf(1.0f - __expf(r), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  const float lo = fmaf(q, a, a);
+  return t > 0.927734375f ? hi : lo;
+}
+
+__device__ __forceinline__ float gelu_exact(float x) {
+  // torch.nn.GELU() default (erf form): 0.5*x*(1+erf(x/sqrt(2)))
+  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+}
+
+// d/dx gelu(x) = Phi(x) + x*phi(x)
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return fmaf(x, pdf, cdf);
+}
+
+template <int T>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[T], const float* __restrict__ bias_lds, int h) {
+#pragma unroll
+  for (int to = 0; to < T; to++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[to][r] = bias_lds[32 * to + row_of(r, h)];
+}
+
+template <int T>
+__device__ __forceinline__ void apply_gelu(f32x16 (&acc)[T]) {
+#pragma unroll
+  for (int to = 0; to < T; to++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[to][r] = gelu_exact(acc[to][r]);
+}
+
+// out^T = W * in^T for register-resident activations (chained layout, see header).
+template <int TI, int TO>
+__device__ __forceinline__ void dense_chain(const f32x16 (&in)[TI], f32x16 (&out)[TO], const float* __restrict__ w_lds,
+                                            int lane) {
+#pragma unroll
+  for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float b = in[ti][r];
+#pragma unroll
+      for (int to = 0; to < TO; to++) {
+        const float a = w_lds[((to * TI + ti) * 16 + r) * 64 + lane];
+        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[to], 0, 0, 0);
+      }
+    }
+}
+
+// Forward of the whole net for one 32-sample tile; fills the hidden pre-activation free result in `hid`.
+// T1,T2,T3: hidden widths in tiles of 32 (T3 == 0: only two hidden layers).
+template <int T1, int T2, int T3>
+struct Net {
+  static constexpr int NH = (T3 > 0) ? 3 : 2;
+  static constexpr int TL = (T3 > 0) ? T3 : T2;  // tiles of the last hidden layer
+};
+
+template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+__global__ void __launch_bounds__(PSDF_BLOCK, 2)
+    mlp_fwd_kernel(MlpPlan p, int64_t N, const float* __restrict__ X, const float* __restrict__ packed,
+                   float* __restrict__ Y) {
+  extern __shared__ __align__(16) float lds[];
+  for (int i = threadIdx.x; i < p.total; i += PSDF_BLOCK) lds[i] = packed[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int K0 = p.dims[0];
+  const int OUT = p.dims[p.n_layers];
+  const int64_t ntiles = (N + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    // compiler-only barrier: keeps the (loop-invariant) LDS weight reads inside the tile loop; without it
+    // LICM hoists hundreds of them into VGPRs and the kernel spills
+    asm volatile("" ::: "memory");
+    const int64_t n = tile * 32 + sl;
+    const int64_t nc = n < N ? n : N - 1;
+    // ---- layer 0: B operand from global (feature-major input)
+    f32x16 h1[T1];
+    init_bias<T1>(h1, lds + p.b_off[0], h);
+    {
+      const float* __restrict__ w0 = lds + p.w_off[0];
+      const int steps = p.in_steps0;
+      for (int s = 0; s < steps; s++) {
+        const int k = 2 * s + h;
+        const float b = (k < K0) ? X[(int64_t)k * N + nc] : 0.f;
+#pragma unroll
+        for (int to = 0; to < T1; to++)
+          h1[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(to * steps + s) * 64 + lane], b, h1[to], 0, 0, 0);
+      }
+    }
+    apply_gelu<T1>(h1);
+    f32x16 h2[T2];
+    init_bias<T2>(h2, lds + p.b_off[1], h);
+    dense_chain<T1, T2>(h1, h2, lds + p.w_off[1], lane);
+    apply_gelu<T2>(h2);
+    constexpr int TL = (T3 > 0) ? T3 : T2;
+    f32x16 hl[TL];
+    if constexpr (T3 > 0) {
+      init_bias<T3>(hl, lds + p.b_off[2], h);
+      dense_chain<T2, T3>(h2, hl, lds + p.w_off[2], lane);
+      apply_gelu<T3>(hl);
+    } else {
+#pragma unroll
+      for (int t = 0; t < T2; t++) hl[t] = h2[t];
+    }
+    const int lf = p.n_layers - 1;
+    if constexpr (FINAL_DOT) {
+      const float* __restrict__ wf = lds + p.w_off[lf];
+      for (int o = 0; o < OUT; o++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < TL; ti++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc = fmaf(wf[((o * TL + ti) * 16 + r) * 2 + h], hl[ti][r], acc);
+        acc += __shfl_xor(acc, 32, 64);
+        acc += lds[p.b_off[lf] + o];
+        if (h == 0 && n < N) Y[(int64_t)o * N + n] = acc;
+      }
+    } else {
+      f32x16 y[OUT_T];
+      init_bias<OUT_T>(y, lds + p.b_off[lf], h);
+      dense_chain<TL, OUT_T>(hl, y, lds + p.w_off[lf], lane);
+      if (n < N) {
+#pragma unroll
+        for (int to = 0; to < OUT_T; to++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = 32 * to + row_of(r, h);
+            if (row < OUT) Y[(int64_t)row * N + n] = y[to][r];
+          }
+      }
+    }
+  }
+}
+
+template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+int launch_fwd(const MlpPlan& p, int64_t N, const float* X, const float* packed, float* Y, hipStream_t st) {
+  const size_t shmem = (size_t)p.total * sizeof(float);
+  auto kern = mlp_fwd_kernel<T1, T2, T3, OUT_T, FINAL_DOT>;
+  if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t ntiles = (N + 31) / 32;
+  int64_t blocks = (ntiles + 3) / 4;
+  const int64_t cap = 256 * 4;  // persistent-ish: the weight staging is amortised over many tiles
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PSDF_BLOCK), shmem, st, p, N, X, packed, Y);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Number of floats of the packed (MFMA-operand ordered) parameter buffer for a net with the given
+// layer widths: dims[0]=input .. dims[n_layers]=output.  Returns <0 on argument error.
+int64_t psdf_mlp_packed_size(int n_layers, const int* dims) {
+  MlpPlan p;
+  if (make_plan(n_layers, dims, p) != PSDF_OK) return PSDF_ERR_ARG;
+  return p.total;
+}
+
+// weights[l]: device pointer to torch-layout W_l [dims[l+1], dims[l]]; biases[l]: [dims[l+1]].
+int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, const float* const* biases,
+                  float* packed, void* stream) {
+  PackArgs a;
+  int rc = make_plan(n_layers, dims, a.plan);
+  if (rc != PSDF_OK) return rc;
+  for (int l = 0; l < MAXL; l++) {
+    a.W[l] = l < n_layers ? weights[l] : nullptr;
+    a.b[l] = l < n_layers ? biases[l] : nullptr;
+  }
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(psdf_blocks(a.plan.total, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                     packed);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// X: [dims[0], N] feature-major; Y: [dims[n_layers], N] feature-major.  GELU (erf) after every layer but the last.
+int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y,
+                     void* stream) {
+  MlpPlan p;
+  int rc = make_plan(n_layers, dims, p);
+  if (rc != PSDF_OK) return rc;
+  if (N < 0 || !X || !packed || !Y) return PSDF_ERR_ARG;
+  if (N == 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0, to = p.tiles[n_layers];
+  if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
+#define CASE(A, B, C, O, D)                                          \
+  if (t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
+    return launch_fwd<A, B, C, O, D>(p, N, X, packed, Y, st);
+  CASE(2, 2, 2, 1, true)   // 64x3 -> 1..4      (BASELINE SDF net)
+  CASE(1, 1, 1, 1, true)   // 32x3 -> 1..4
+  CASE(1, 1, 1, 2, false)  // 32x3 -> 33        (reference SDF net, models.py:153-161)
+  CASE(2, 2, 2, 3, false)  // 64x3 -> 65        (background density+feature net, models.py:451-459)
+  CASE(2, 2, 2, 2, false)  // 64x3 -> 33
+  CASE(2, 2, 0, 1, true)   // 64x2 -> 3         (background colour head, models.py:463-469)
+  CASE(4, 4, 2, 1, true)   // 128,128,64 -> 3   (colour net, models.py:350)
+#undef CASE
+  return PSDF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

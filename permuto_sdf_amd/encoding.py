@@ -1,0 +1,192 @@
+"""Host-side mirror of the `permutohedral_encoding` operator API (boundary #2 of the hot path).
+
+Mirrors what the reference imports at permuto_sdf_py/models/models.py:20 and uses at
+models.py:149,154,172,183,186,333,370,408-420,442 and train_sdf_from_mesh.py:155:
+``PermutoEncoding(pos_dim, capacity, nr_levels, nr_feat_per_level, scale_list,
+appply_random_shift_per_level=..., concat_points=..., concat_points_scaling=...)``, ``output_dims()``,
+``__call__(points, window)``, a parameter named ``lattice_values``, and ``Coarse2Fine(nr_levels)``.
+Compute goes through the C-ABI HIP library only (csrc/encode.hip); autograd structure (a forward
+Function whose backward is itself a Function, so that ``create_graph=True`` works — models.py:245-251)
+follows SURVEY.md App. A.4.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def scale_factor_tensor(scale_list, pos_dim):
+    scale_list = np.asarray(scale_list, dtype=np.float64)
+    sf = np.empty((len(scale_list), pos_dim), dtype=np.float64)
+    for i in range(pos_dim):
+        sf[:, i] = 1.0 / (math.sqrt((i + 1) * (i + 2)) * scale_list)
+    return torch.from_numpy(sf.astype(np.float32))
+
+
+class _Cfg:
+    """Fixed (non-tensor) parameters of one encoding instance."""
+
+    def __init__(self, pos_dim, capacity, nr_levels, nr_feat, concat_points, points_scaling):
+        self.pos_dim, self.capacity, self.nr_levels, self.nr_feat = pos_dim, capacity, nr_levels, nr_feat
+        self.concat_points, self.points_scaling = bool(concat_points), float(points_scaling)
+        self.extra = int(math.ceil(pos_dim / nr_feat)) if concat_points else 0
+        self.channels = nr_feat * (nr_levels + self.extra)
+
+
+def _head(cfg, N):
+    return (L.c_i(cfg.pos_dim), L.c_i(cfg.nr_feat), L.c_l(N), L.c_i(cfg.nr_levels), L.c_i(cfg.capacity))
+
+
+def _tail(cfg):
+    return (L.c_i(int(cfg.concat_points)), L.c_f(cfg.points_scaling))
+
+
+def encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window):
+    """-> sliced [channels, N] (feature-major)."""
+    L.require_cuda(positions, lattice)
+    N = positions.shape[0]
+    sliced = torch.empty((cfg.channels, N), dtype=torch.float32, device=positions.device)
+    L.call("psdf_encode_forward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
+           L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(sliced), L.stream())
+    return sliced
+
+
+def _feature_major(g):
+    """[N, C] gradient (any strides) -> contiguous [C, N]."""
+    gt = g.t()
+    return gt if gt.is_contiguous() else gt.contiguous()
+
+
+class PermutoEncodingFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window):
+        positions = positions.contiguous()
+        window = window.contiguous()
+        sliced = encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window)
+        ctx.cfg = cfg
+        ctx.save_for_backward(scale_factor, shifts, lattice, positions, window)
+        # [N, C] view of the feature-major buffer: zero copy; BLAS consumes the transposed operand natively
+        return sliced.t()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        scale_factor, shifts, lattice, positions, window = ctx.saved_tensors
+        need_lat, need_pos = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        g_lat, g_pos = PermutoEncodingBackFunc.apply(ctx.cfg, scale_factor, shifts, lattice, positions, window,
+                                                     grad_out, need_lat, need_pos)
+        return None, None, None, (g_lat if need_lat else None), (g_pos if need_pos else None), None
+
+
+class PermutoEncodingBackFunc(torch.autograd.Function):
+    """Backward as a Function so it can itself be differentiated (double backward from positions)."""
+
+    @staticmethod
+    def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window, grad_out, need_lat, need_pos):
+        g = _feature_major(grad_out)
+        N = positions.shape[0]
+        g_lat = torch.zeros_like(lattice) if need_lat else None
+        g_pos = torch.zeros_like(positions) if need_pos else None
+        L.call("psdf_encode_backward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
+               L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(g), L.ptr(g_lat), L.ptr(g_pos), L.stream())
+        ctx.cfg = cfg
+        ctx.save_for_backward(scale_factor, shifts, lattice, positions, window, g)
+        if g_lat is None:
+            g_lat = torch.zeros((), device=positions.device)
+            ctx.mark_non_differentiable(g_lat)
+        if g_pos is None:
+            g_pos = torch.zeros((), device=positions.device)
+            ctx.mark_non_differentiable(g_pos)
+        return g_lat, g_pos
+
+    @staticmethod
+    def backward(ctx, dd_lattice, dd_positions):
+        # d(grad_lattice)/d(.) is not propagated (the reference never differentiates through the
+        # lattice gradient); only the path from grad_positions is (eikonal / curvature losses).
+        scale_factor, shifts, lattice, positions, window, g = ctx.saved_tensors
+        cfg = ctx.cfg
+        need_lat, need_g = ctx.needs_input_grad[3], ctx.needs_input_grad[6]
+        if dd_positions is None or not (need_lat or need_g):
+            return (None,) * 9
+        N = positions.shape[0]
+        dd = dd_positions.contiguous()
+        g_lat = torch.zeros_like(lattice) if need_lat else None
+        gg = torch.empty_like(g)
+        L.call("psdf_encode_double_backward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
+               L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(dd), L.ptr(g), L.ptr(g_lat), L.ptr(gg), L.stream())
+        return None, None, None, g_lat, None, None, (gg.t() if need_g else None), None, None
+
+
+class PermutoEncoding(torch.nn.Module):
+    def __init__(self, pos_dim, capacity, nr_levels, nr_feat_per_level, scale_per_level,
+                 appply_random_shift_per_level=True, concat_points=False, concat_points_scaling=1.0,
+                 init_scale=1e-5, apply_random_shift_per_level=None):
+        super().__init__()
+        if apply_random_shift_per_level is not None:  # accept the correctly spelled keyword as well
+            appply_random_shift_per_level = apply_random_shift_per_level
+        scale_per_level = list(np.asarray(scale_per_level, dtype=np.float64).reshape(-1))
+        if len(scale_per_level) != nr_levels:
+            raise ValueError("scale_per_level must have nr_levels=%d entries, got %d" % (nr_levels, len(scale_per_level)))
+        if (pos_dim, nr_feat_per_level) not in ((2, 2), (3, 2), (4, 2), (3, 4)):
+            raise ValueError("unsupported (pos_dim, nr_feat_per_level)=(%d,%d); built variants: (2,2),(3,2),(4,2),(3,4)"
+                             % (pos_dim, nr_feat_per_level))
+        self.pos_dim, self.capacity, self.nr_levels, self.nr_feat_per_level = pos_dim, int(capacity), nr_levels, nr_feat_per_level
+        self.scale_per_level = scale_per_level
+        self.concat_points, self.concat_points_scaling = concat_points, concat_points_scaling
+        self.cfg = _Cfg(pos_dim, int(capacity), nr_levels, nr_feat_per_level, concat_points, concat_points_scaling)
+
+        lattice_values = torch.randn(int(capacity), nr_levels, nr_feat_per_level) * init_scale
+        self.lattice_values = torch.nn.Parameter(lattice_values.permute(1, 0, 2).contiguous())
+        if appply_random_shift_per_level:
+            shift = torch.randn(nr_levels, pos_dim) * 10
+        else:
+            shift = torch.zeros(nr_levels, pos_dim)
+        # fixed (saved with the checkpoint, never trained)
+        self.random_shift_per_level = torch.nn.Parameter(shift, requires_grad=False)
+        self.register_buffer("scale_factor", scale_factor_tensor(scale_per_level, pos_dim), persistent=False)
+        self.register_buffer("anneal_window_ones", torch.ones(nr_levels), persistent=False)
+
+    def output_dims(self):
+        return self.cfg.channels
+
+    def forward(self, positions, anneal_window=None):
+        if positions.dim() != 2 or positions.shape[1] != self.pos_dim:
+            raise ValueError("positions must be [N, %d], got %s" % (self.pos_dim, tuple(positions.shape)))
+        L.require_cuda(positions, self.lattice_values)
+        if anneal_window is None:
+            anneal_window = self.anneal_window_ones
+        else:
+            anneal_window = anneal_window.to(device=positions.device, dtype=torch.float32).reshape(-1)
+            if anneal_window.numel() != self.nr_levels:
+                raise ValueError("anneal_window must have nr_levels entries")
+        positions = positions.to(torch.float32)
+        return PermutoEncodingFunc.apply(self.cfg, self.scale_factor, self.random_shift_per_level.detach(),
+                                         self.lattice_values, positions, anneal_window)
+
+    def forward_feature_major(self, positions, anneal_window=None):
+        """No-grad fast path used by the fused evaluators: returns the [channels, N] buffer itself."""
+        if anneal_window is None:
+            anneal_window = self.anneal_window_ones
+        with torch.no_grad():
+            return encode_forward_raw(self.cfg, positions.contiguous(), self.lattice_values.detach(), self.scale_factor,
+                                      self.random_shift_per_level.detach(), anneal_window.contiguous())
+
+
+class Coarse2Fine(torch.nn.Module):
+    """Cosine-eased per-level window (same formula as reference common_utils.py:51-62)."""
+
+    def __init__(self, nr_levels):
+        super().__init__()
+        self.nr_levels = nr_levels
+        self.last_t = 0.0
+        self.register_buffer("level_idx", torch.arange(nr_levels, dtype=torch.float32), persistent=False)
+
+    def forward(self, t):
+        self.last_t = float(t)
+        alpha = float(t) * self.nr_levels
+        x = torch.clamp(alpha - self.level_idx, 0.0, 1.0)
+        return 0.5 * (1.0 + torch.cos(math.pi * x + math.pi))
+
+    def get_last_t(self):
+        return self.last_t

@@ -1,0 +1,128 @@
+"""Fused small-MLP evaluator (csrc/mlp.hip) behind a torch.nn.Module.
+
+Replaces the reference's ``torch.nn.Sequential(Linear, GELU, ..., Linear)`` evaluators
+(permuto_sdf_py/models/models.py:153-161, :451-470) with one MFMA kernel per pass.  Parameters keep
+torch.nn.Linear layout/names (``layers.{i}.weight|bias``) so a state_dict maps 1:1 onto the reference's
+``mlp_sdf.{2i}.weight|bias``.  Activations are exchanged feature-major ([C, N]) with the encoding kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def _dims_array(dims):
+    return (ctypes.c_int * len(dims))(*dims)
+
+
+def packed_size(dims):
+    n = L.lib().psdf_mlp_packed_size
+    n.restype = ctypes.c_int64
+    r = n(L.c_i(len(dims) - 1), _dims_array(dims))
+    if r < 0:
+        raise L.PsdfError("psdf_mlp_packed_size: bad layer widths %s" % (dims,))
+    return int(r)
+
+
+def pack_params(dims, weights, biases):
+    """torch-layout weights/biases -> MFMA-operand ordered buffer (one small kernel)."""
+    n_layers = len(dims) - 1
+    L.require_cuda(*weights)
+    packed = torch.empty(packed_size(dims), dtype=torch.float32, device=weights[0].device)
+    ws = [w.detach().contiguous() for w in weights]
+    bs = [b.detach().contiguous() for b in biases]
+    W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
+    B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
+    L.call("psdf_mlp_pack", L.c_i(n_layers), _dims_array(dims), W, B, L.ptr(packed), L.stream())
+    return packed
+
+
+def mlp_forward_raw(dims, x_fm, packed):
+    """x_fm [dims[0], N] feature-major -> y [dims[-1], N] feature-major."""
+    N = x_fm.shape[1]
+    y = torch.empty((dims[-1], N), dtype=torch.float32, device=x_fm.device)
+    L.call("psdf_mlp_forward", L.c_i(len(dims) - 1), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(y),
+           L.stream())
+    return y
+
+
+def mlp_backward_raw(dims, x_fm, packed, packed_t, gy_fm, need_dx=True):
+    """-> (dx_fm [dims[0], N] or None, [dW_l], [db_l])"""
+    N = x_fm.shape[1]
+    n_layers = len(dims) - 1
+    dev = x_fm.device
+    dx = torch.empty((dims[0], N), dtype=torch.float32, device=dev) if need_dx else None
+    dWs = [torch.zeros((dims[l + 1], dims[l]), dtype=torch.float32, device=dev) for l in range(n_layers)]
+    dbs = [torch.zeros((dims[l + 1],), dtype=torch.float32, device=dev) for l in range(n_layers)]
+    W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
+    B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
+    L.call("psdf_mlp_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(packed_t),
+           L.ptr(gy_fm), L.ptr(dx), W, B, L.stream())
+    return dx, dWs, dbs
+
+
+class _FusedMLPFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        n_layers = module.n_layers
+        weights, biases = params[:n_layers], params[n_layers:]
+        x_fm = x.t()
+        if not x_fm.is_contiguous():
+            x_fm = x_fm.contiguous()
+        packed = pack_params(module.dims, weights, biases)
+        y = mlp_forward_raw(module.dims, x_fm, packed)
+        ctx.module = module
+        ctx.save_for_backward(x_fm, packed, *weights)
+        return y.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        module = ctx.module
+        x_fm, packed = ctx.saved_tensors[:2]
+        weights = ctx.saved_tensors[2:]
+        gy_fm = gy.t()
+        if not gy_fm.is_contiguous():
+            gy_fm = gy_fm.contiguous()
+        packed_t = module.pack_transposed(weights)
+        dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, packed, packed_t, gy_fm, need_dx=ctx.needs_input_grad[1])
+        return (None, dx.t() if dx is not None else None, *dWs, *dbs)
+
+
+class FusedMLP(torch.nn.Module):
+    """Linear(d0,d1)-GELU-...-Linear(d_{n-1},d_n), GELU(erf) after every layer but the last."""
+
+    def __init__(self, dims):
+        super().__init__()
+        self.dims = [int(d) for d in dims]
+        self.n_layers = len(self.dims) - 1
+        self.layers = torch.nn.ModuleList(
+            [torch.nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(self.n_layers)])
+
+    @classmethod
+    def from_sequential(cls, seq):
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        m = cls([lin[0].in_features] + [l.out_features for l in lin])
+        for dst, src in zip(m.layers, lin):
+            dst.weight.data.copy_(src.weight.data)
+            dst.bias.data.copy_(src.bias.data)
+        return m
+
+    def pack_transposed(self, weights):
+        """Packed W^T chain used by the backward kernel to propagate dL/dH (biases unused -> zeros)."""
+        dims_t = list(reversed(self.dims))
+        wt = [w.t().contiguous() for w in reversed(weights)]
+        zb = [torch.zeros(d, device=wt[0].device) for d in dims_t[1:]]
+        return pack_params(dims_t, wt, zb)
+
+    def forward(self, x):
+        """x [N, d0] (any strides; the transposed view of a feature-major buffer is consumed zero-copy)."""
+        ws = [l.weight for l in self.layers]
+        bs = [l.bias for l in self.layers]
+        return _FusedMLPFunc.apply(self, x, *ws, *bs)
+
+    def forward_feature_major(self, x_fm):
+        """No-grad fast path: [d0, N] -> [d_n, N]."""
+        with torch.no_grad():
+            packed = pack_params(self.dims, [l.weight for l in self.layers], [l.bias for l in self.layers])
+            return mlp_forward_raw(self.dims, x_fm, packed)

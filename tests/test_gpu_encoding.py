@@ -1,0 +1,111 @@
+"""GPU parity: HIP permutohedral encoding (through the C ABI) vs the CPU oracle on identical seeded inputs.
+Tolerances: forward 1e-6 abs on O(1) lattice values (same op order, fp32); gradients 1e-5 relative
+(atomic accumulation order differs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import permuto_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(P, L, T, F, N, seed, concat=True, scaling=1e-3, init_scale=1.0, coarsest=1.0, finest=1e-4):
+    from permuto_sdf_amd import PermutoEncoding
+    torch.manual_seed(seed)
+    sl = np.geomspace(coarsest, finest, L)
+    enc = PermutoEncoding(P, T, L, F, sl, appply_random_shift_per_level=True, concat_points=concat,
+                          concat_points_scaling=scaling, init_scale=init_scale)
+    pts = (torch.rand(N, P) - 0.5)
+    win = po.coarse2fine_window(0.8, L)
+    return enc, sl, pts, win
+
+
+@pytest.mark.parametrize("P,L,T,N", [(3, 1, 2 ** 18, 65536), (3, 24, 2 ** 18, 20000), (4, 24, 2 ** 18, 8192),
+                                      (3, 16, 2 ** 12, 5000), (2, 4, 2 ** 10, 1000)])
+def test_forward_matches_oracle(dev, P, L, T, N):
+    enc, sl, pts, win = _make(P, L, T, 2, N, seed=P * 100 + L)
+    ref = po.encode(pts, enc.lattice_values.detach(), sl, enc.random_shift_per_level.detach(), win, True, 1e-3)
+    enc = enc.to(dev)
+    out = enc(pts.to(dev), win.to(dev))
+    assert out.shape == (N, enc.output_dims()) == ref.shape
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 1e-6 * max(1.0, ref.abs().max().item()), err
+
+
+def test_forward_edge_cases(dev):
+    enc, sl, pts, win = _make(3, 8, 2 ** 14, 2, 1, seed=5, concat=False)
+    enc_d = enc.to(dev)
+    # empty input
+    out = enc_d(torch.zeros(0, 3, device=dev), win.to(dev))
+    assert out.shape == (0, 16)
+    # single point, ragged block (N not a multiple of the block), far-away and lattice-aligned coordinates
+    pts = torch.tensor([[0.0, 0.0, 0.0], [1e3, -1e3, 5e2], [0.5, 0.5, 0.5], [-0.25, 0.125, 1.0]])
+    pts = torch.cat([pts, torch.rand(300, 3) * 4 - 2])
+    ref = po.encode(pts, enc.lattice_values.detach().cpu(), sl, enc.random_shift_per_level.detach().cpu(), win)
+    out = enc_d(pts.to(dev), win.to(dev))
+    assert torch.allclose(out.cpu(), ref, rtol=0, atol=1e-5)  # |coords| up to 1e3 at scale 1e-4: elevated ~1e7
+
+
+@pytest.mark.parametrize("P", [3, 4])
+def test_backward_matches_oracle_autograd(dev, P):
+    L_, T, N = 12, 2 ** 14, 6000
+    enc, sl, pts, win = _make(P, L_, T, 2, N, seed=7 + P)
+    g = torch.randn(N, enc.output_dims())
+    lat = enc.lattice_values.detach().clone().requires_grad_(True)
+    p_ref = pts.clone().requires_grad_(True)
+    ref = po.encode(p_ref, lat, sl, enc.random_shift_per_level.detach(), win, True, 1e-3)
+    ref.backward(g)
+    enc = enc.to(dev)
+    p = pts.to(dev).requires_grad_(True)
+    out = enc(p, win.to(dev))
+    out.backward(g.to(dev))
+    gl, gl_ref = enc.lattice_values.grad.cpu(), lat.grad
+    assert (gl - gl_ref).abs().max() <= 1e-5 * gl_ref.abs().max() + 1e-7
+    gp, gp_ref = p.grad.cpu(), p_ref.grad
+    assert (gp - gp_ref).abs().max() <= 2e-5 * gp_ref.abs().max()
+
+
+def test_double_backward_matches_oracle_autograd(dev):
+    P, L_, T, N = 3, 10, 2 ** 13, 4000
+    enc, sl, pts, win = _make(P, L_, T, 2, N, seed=21)
+    C = enc.output_dims()
+    torch.manual_seed(3)
+    w1 = torch.randn(C, 5)            # stand-in for the MLP: sdf = tanh(feat @ w1).sum
+    u = torch.randn(N, P)
+
+    def run(encode_fn, lat, pts_, w1_, u_):
+        pts_ = pts_.clone().requires_grad_(True)
+        feat = encode_fn(pts_)
+        sdf = torch.tanh(feat @ w1_).sum(1, keepdim=True)
+        grad = torch.autograd.grad(sdf, pts_, torch.ones_like(sdf), create_graph=True)[0]
+        loss = ((grad * u_).sum(1) ** 2).mean() + sdf.mean()
+        return torch.autograd.grad(loss, [lat], retain_graph=False)[0], grad.detach()
+
+    lat_ref = enc.lattice_values.detach().clone().requires_grad_(True)
+    shifts = enc.random_shift_per_level.detach().clone()
+    g_ref, grad_ref = run(lambda x: po.encode(x, lat_ref, sl, shifts, win, True, 1e-3), lat_ref, pts, w1, u)
+    enc = enc.to(dev)
+    wd = win.to(dev)
+    g_hip, grad_hip = run(lambda x: enc(x, wd), enc.lattice_values, pts.to(dev), w1.to(dev), u.to(dev))
+    assert (grad_hip.cpu() - grad_ref).abs().max() <= 2e-5 * grad_ref.abs().max()
+    assert (g_hip.cpu() - g_ref).abs().max() <= 2e-5 * g_ref.abs().max()
+
+
+def test_lattice_grad_linearity_full_size(dev):
+    """Size-independent property at the BASELINE size (2M points, 16 levels): the lattice gradient is
+    linear in the upstream gradient and its total mass equals sum(window_l * sum_n g) per level and feature
+    (barycentric weights sum to one)."""
+    P, L_, T, N = 3, 16, 2 ** 18, 2 * 1024 * 1024
+    enc, sl, _, win = _make(P, L_, T, 2, 8, seed=33, concat=False)
+    enc = enc.to(dev)
+    torch.manual_seed(0)
+    pts = torch.rand(N, P, device=dev) - 0.5
+    g = torch.randn(N, enc.output_dims(), device=dev)
+    out = enc(pts, win.to(dev))
+    (gl,) = torch.autograd.grad(out, enc.lattice_values, g)
+    mass = gl.double().sum(1)                                       # [L, F]
+    expect = (g.double().sum(0).view(L_, 2)) * win.to(dev).double()[:, None]
+    assert torch.allclose(mass, expect, rtol=1e-3, atol=1e-2)
+    (gl2,) = torch.autograd.grad(enc(pts, win.to(dev)), enc.lattice_values, 2 * g)
+    assert torch.allclose(gl2, 2 * gl, rtol=1e-4, atol=1e-4)
