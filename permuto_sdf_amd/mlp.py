@@ -47,7 +47,7 @@ def mlp_forward_raw(dims, x_fm, packed):
     return y
 
 
-def mlp_backward_raw(dims, x_fm, packed, packed_t, gy_fm, need_dx=True):
+def mlp_backward_raw(dims, x_fm, packed, gy_fm, need_dx=True):
     """-> (dx_fm [dims[0], N] or None, [dW_l], [db_l])"""
     N = x_fm.shape[1]
     n_layers = len(dims) - 1
@@ -57,8 +57,8 @@ def mlp_backward_raw(dims, x_fm, packed, packed_t, gy_fm, need_dx=True):
     dbs = [torch.zeros((dims[l + 1],), dtype=torch.float32, device=dev) for l in range(n_layers)]
     W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
     B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
-    L.call("psdf_mlp_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(packed_t),
-           L.ptr(gy_fm), L.ptr(dx), W, B, L.stream())
+    L.call("psdf_mlp_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(gy_fm),
+           L.ptr(dx), W, B, L.stream())
     return dx, dWs, dbs
 
 
@@ -73,19 +73,17 @@ class _FusedMLPFunc(torch.autograd.Function):
         packed = pack_params(module.dims, weights, biases)
         y = mlp_forward_raw(module.dims, x_fm, packed)
         ctx.module = module
-        ctx.save_for_backward(x_fm, packed, *weights)
+        ctx.save_for_backward(x_fm, packed)
         return y.t()
 
     @staticmethod
     def backward(ctx, gy):
         module = ctx.module
-        x_fm, packed = ctx.saved_tensors[:2]
-        weights = ctx.saved_tensors[2:]
+        x_fm, packed = ctx.saved_tensors
         gy_fm = gy.t()
         if not gy_fm.is_contiguous():
             gy_fm = gy_fm.contiguous()
-        packed_t = module.pack_transposed(weights)
-        dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, packed, packed_t, gy_fm, need_dx=ctx.needs_input_grad[1])
+        dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, packed, gy_fm, need_dx=ctx.needs_input_grad[1])
         return (None, dx.t() if dx is not None else None, *dWs, *dbs)
 
 
@@ -107,13 +105,6 @@ class FusedMLP(torch.nn.Module):
             dst.weight.data.copy_(src.weight.data)
             dst.bias.data.copy_(src.bias.data)
         return m
-
-    def pack_transposed(self, weights):
-        """Packed W^T chain used by the backward kernel to propagate dL/dH (biases unused -> zeros)."""
-        dims_t = list(reversed(self.dims))
-        wt = [w.t().contiguous() for w in reversed(weights)]
-        zb = [torch.zeros(d, device=wt[0].device) for d in dims_t[1:]]
-        return pack_params(dims_t, wt, zb)
 
     def forward(self, x):
         """x [N, d0] (any strides; the transposed view of a feature-major buffer is consumed zero-copy)."""

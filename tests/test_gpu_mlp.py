@@ -56,3 +56,32 @@ def test_forward_asymmetric_weights(dev):
         y = m(x.to(dev)).cpu()
     y_ref = ref(x).detach()
     assert (y - y_ref).abs().max() <= 2e-5 * max(1.0, y_ref.abs().max().item())
+
+
+BWD_NETS = [[52, 64, 64, 64, 1], [36, 64, 64, 64, 1], [52, 32, 32, 32, 33], [52, 64, 64, 64, 65], [80, 64, 64, 3],
+            [51, 32, 32, 32, 1]]
+
+
+@pytest.mark.parametrize("dims", BWD_NETS)
+@pytest.mark.parametrize("N", [33, 5000])
+def test_backward_matches_torch(dev, dims, N):
+    """dX, dW, db of the fused kernel vs torch autograd through the unmodified torch.nn evaluator (fp64 for the
+    reference gradient so that the comparison is not limited by torch's own fp32 rounding)."""
+    from permuto_sdf_amd import FusedMLP
+    torch.manual_seed(dims[0] + N)
+    ref = _ref_net(dims)
+    x = torch.randn(N, dims[0])
+    gy = torch.randn(N, dims[-1])
+    ref64 = _ref_net(dims).double()
+    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    ref64(x64).backward(gy.double())
+    m = FusedMLP.from_sequential(ref).to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    m(xd).backward(gy.to(dev))
+    scale = lambda t: max(1e-6, t.abs().max().item())
+    assert (xd.grad.cpu().double() - x64.grad).abs().max() <= 5e-5 * scale(x64.grad)
+    lin64 = [l for l in ref64 if isinstance(l, torch.nn.Linear)]
+    for l_hip, l_ref in zip(m.layers, lin64):
+        assert (l_hip.weight.grad.cpu().double() - l_ref.weight.grad).abs().max() <= 1e-4 * scale(l_ref.weight.grad)
+        assert (l_hip.bias.grad.cpu().double() - l_ref.bias.grad).abs().max() <= 1e-4 * scale(l_ref.bias.grad)

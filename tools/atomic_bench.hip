@@ -1,0 +1,72 @@
+// Microbenchmark: fp32 atomic scatter-add throughput on gfx950 under different placements.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1;}}while(0)
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x){ x ^= x>>16; x*=0x7feb352dU; x^=x>>15; x*=0x846ca68bU; x^=x>>16; return x; }
+
+// mode 0: shared table; 1: table copy selected by blockIdx%8; 2: table copy selected by HW XCC id
+template<int MODE, int PER_THREAD>
+__global__ void scatter(float* table, uint32_t rows_mask, uint32_t rows, int nfeat){
+  uint32_t gid = blockIdx.x*blockDim.x + threadIdx.x;
+  uint32_t copy = 0;
+  if (MODE==1) copy = blockIdx.x & 7;
+  if (MODE==2) { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); copy = x & 7; }
+  float* t = table + (size_t)copy*rows*nfeat;
+  #pragma unroll
+  for(int i=0;i<PER_THREAD;i++){
+    uint32_t r = hash32(gid*PER_THREAD+i) & rows_mask;
+    for(int f=0; f<nfeat; f++) atomicAdd(t + (size_t)r*nfeat + f, 1.0f);
+  }
+}
+template<int PER_THREAD>
+__global__ void scatter_lds(float* out, uint32_t rows_mask){
+  extern __shared__ float lds[];
+  for(int i=threadIdx.x;i<=rows_mask;i+=blockDim.x) lds[i]=0;
+  __syncthreads();
+  uint32_t gid = blockIdx.x*blockDim.x + threadIdx.x;
+  #pragma unroll 4
+  for(int i=0;i<PER_THREAD;i++){
+    uint32_t r = hash32(gid*PER_THREAD+i) & rows_mask;
+    atomicAdd(&lds[r], 1.0f);
+  }
+  __syncthreads();
+  if(threadIdx.x==0) out[blockIdx.x]=lds[0];
+}
+__global__ void gather(const float2* table, uint32_t rows_mask, float* out){
+  uint32_t gid = blockIdx.x*blockDim.x + threadIdx.x;
+  float acc=0;
+  #pragma unroll
+  for(int i=0;i<8;i++){ float2 v = table[hash32(gid*8+i)&rows_mask]; acc+=v.x+v.y; }
+  out[gid]=acc;
+}
+template<typename F> float timeit(F f,int n=5){ hipEvent_t a,b; hipEventCreate(&a); hipEventCreate(&b); f(); hipDeviceSynchronize(); hipEventRecord(a); for(int i=0;i<n;i++) f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms,a,b); return ms/n; }
+
+int main(){
+  const uint32_t rows = 1u<<18; const int nfeat=2;
+  float* table; CK(hipMalloc(&table, (size_t)8*rows*nfeat*4*4)); CK(hipMemset(table,0,(size_t)8*rows*nfeat*4*4));
+  float* out; CK(hipMalloc(&out, 64u<<20));
+  const int threads=256; const int per=4; const int64_t total = 8ll*1024*1024; // contributions
+  int blocks = total/per/threads;
+  for(int nf=1; nf<=2; nf++){
+    float t0 = timeit([&]{ hipLaunchKernelGGL((scatter<0,per>), dim3(blocks), dim3(threads),0,0, table, rows-1, rows, nf); });
+    float t1 = timeit([&]{ hipLaunchKernelGGL((scatter<1,per>), dim3(blocks), dim3(threads),0,0, table, rows-1, rows, nf); });
+    float t2 = timeit([&]{ hipLaunchKernelGGL((scatter<2,per>), dim3(blocks), dim3(threads),0,0, table, rows-1, rows, nf); });
+    printf("nfeat=%d  shared %.3f ms (%.1f Gatom/s) | copy=blk%%8 %.3f ms (%.1f) | copy=xcc %.3f ms (%.1f)\n", nf, t0, total*nf/t0/1e6, t1, total*nf/t1/1e6, t2, total*nf/t2/1e6);
+  }
+  // table size sweep (shared), nfeat=1
+  for(uint32_t lg=10; lg<=24; lg+=2){
+    uint32_t r = 1u<<lg; if((size_t)r*4 > (size_t)8*rows*nfeat*4*4) break;
+    float t0 = timeit([&]{ hipLaunchKernelGGL((scatter<0,per>), dim3(blocks), dim3(threads),0,0, table, r-1, r, 1); });
+    printf("rows=2^%u shared nfeat=1: %.3f ms (%.1f Gatom/s)\n", lg, t0, total/t0/1e6);
+  }
+  // LDS atomics: 16K-entry table per block
+  { const int perl=64; int b = total/perl/threads; 
+    float t = timeit([&]{ hipLaunchKernelGGL((scatter_lds<perl>), dim3(b), dim3(threads), 16384*4, 0, out, 16383u); });
+    printf("LDS atomics (16K floats/block, random): %.3f ms (%.1f Gatom/s)\n", t, total/t/1e6); }
+  { float t = timeit([&]{ hipLaunchKernelGGL(gather, dim3(total/8/threads), dim3(threads),0,0,(const float2*)table, rows-1, out); });
+    printf("gather float2 from 2MiB table: %.3f ms (%.1f Ggather/s)\n", t, total/t/1e6); }
+  return 0;
+}

@@ -54,3 +54,16 @@ for L_ in (16, 24):
     with torch.no_grad():
         tr = timeit(lambda: ref(xt))
     print(f"L={L_} torch.nn mlp fwd {tr:.3f} ms")
+
+print("---- per-level fwd+bwd(lattice), single-level encodings, 2M points")
+p = torch.randn(N, 3, device=dev); p = p / p.norm(dim=1, keepdim=True) * 0.5 * torch.rand(N, 1, device=dev) ** (1 / 3)
+for sc in np.geomspace(1.0, 1e-4, 16):
+    enc1 = PermutoEncoding(3, 2 ** 18, 1, 2, [sc], concat_points=False).to(dev)
+    w1 = torch.ones(1, device=dev)
+    g1 = torch.randn(2, N, device=dev).t()
+    tf = timeit(lambda: enc1.forward_feature_major(p, w1), n=5, warm=2)
+    def b1():
+        torch.autograd.grad(enc1(p, w1), enc1.lattice_values, g1)
+    tb = timeit(b1, n=5, warm=2)
+    nz = 0
+    print(f"scale {sc:.5f}: fwd {tf:.3f} ms  fwd+bwd {tb:.3f} ms")
