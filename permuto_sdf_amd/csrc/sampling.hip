@@ -1,0 +1,850 @@
+// Sample generation for gfx950: Morton occupancy grid (update, DDA ray marching, queries), ray samplers
+// (foreground uniform, NeRF++ style background), bounding sphere, packed-sample container utilities,
+// spherical harmonics and random ray generation from an image stack.
+// Replaces, with the same per-item arithmetic (fp32, one rounding per operation, see psdf_common.h):
+//   src/OccupancyGrid.cu + kernels/permuto_sdf/OccupancyGridGPU.cuh      (all kernels)
+//   src/RaySampler.cu    + kernels/permuto_sdf/RaySamplerGPU.cuh         (:37 bg, :162 fg)
+//   src/Sphere.cu        + kernels/permuto_sdf/SphereGPU.cuh             (:21, :96)
+//   src/RaySamplesPacked.cu + kernels/permuto_sdf/RaySamplesPackedGPU.cuh (:15 compact, :84 per-sample ray idx)
+//   src/PermutoSDF.cu    + kernels/permuto_sdf/PermutoSDFGPU.cuh         (:24 random_rays_from_reel, :275 SH)
+//
+// Differences in STRUCTURE (not arithmetic): every kernel that reserved output slots with atomicAdd on a
+// global counter (nondeterministic ray order, OccupancyGridGPU.cuh:599, RaySamplerGPU.cuh:228,
+// RaySamplesPackedGPU.cuh:51) is split into count -> exclusive scan over rays -> fill, so packed samples are
+// ray-ordered, reproducible and exactly sized (no holes, no compaction copy).
+#include "psdf_common.h"
+
+using namespace psdf;
+
+namespace {
+
+// ---------------------------------------------------------------------------------- Morton helpers
+__host__ __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+__host__ __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
+  return expand_bits10(x) | (expand_bits10(y) << 1) | (expand_bits10(z) << 2);
+}
+__host__ __device__ __forceinline__ uint32_t compact_bits10(uint32_t x) {
+  x &= 0x49249249u;
+  x = (x | (x >> 2)) & 0xc30c30c3u;
+  x = (x | (x >> 4)) & 0x0f00f00fu;
+  x = (x | (x >> 8)) & 0xff0000ffu;
+  x = (x | (x >> 16)) & 0x0000ffffu;
+  return x;
+}
+// float -> uint32 with the device semantics the reference relies on (negative / NaN -> 0, huge -> 2^32-1)
+__device__ __forceinline__ uint32_t sat_u32(float f) {
+  if (!(f > 0.f)) return 0u;
+  if (f >= 4294967296.f) return 0xFFFFFFFFu;
+  return (uint32_t)f;
+}
+
+struct Grid {
+  int n;         // voxels per dimension (power of two)
+  float extent;  // edge length of the cube
+  float tx, ty, tz;
+  __device__ __forceinline__ int nr_voxels() const { return n * n * n; }
+  // voxel centre (or corner) of a Morton index (OccupancyGridGPU.cuh:112-155)
+  __device__ __forceinline__ v3 idx_to_pos(uint32_t idx, bool centre) const {
+    float x = (float)compact_bits10(idx), y = (float)compact_bits10(idx >> 1), z = (float)compact_bits10(idx >> 2);
+    x = x / n;
+    y = y / n;
+    z = z / n;
+    x = x - 0.5f;
+    y = y - 0.5f;
+    z = z - 0.5f;
+    if (centre) {
+      const float half = (float)((double)(float)(1.0 / n) / 2);
+      x += half;
+      y += half;
+      z += half;
+    }
+    return mk3(x * extent + tx, y * extent + ty, z * extent + tz);
+  }
+  // world position -> Morton index (OccupancyGridGPU.cuh:158-193, get_center_of_voxel=false)
+  __device__ __forceinline__ int pos_to_idx(v3 p) const {
+    float x = (p.x - tx) / extent, y = (p.y - ty) / extent, z = (p.z - tz) / extent;
+    x = (x + 0.5f) * n;
+    y = (y + 0.5f) * n;
+    z = (z + 0.5f) * n;
+    return (int)morton3(sat_u32(x), sat_u32(y), sat_u32(z));
+  }
+  __device__ __forceinline__ bool in_range(int idx) const { return !(idx >= nr_voxels() || idx < 0); }
+};
+
+__device__ __forceinline__ int sgn(float x) { return x > 0 ? 1 : (x < 0 ? -1 : 0); }
+
+// DDA step to the next voxel face, in world units (OccupancyGridGPU.cuh:95-109)
+__device__ __forceinline__ float dist_to_next_voxel(v3 pos, v3 dir, v3 idir, int n) {
+  pos = (float)n * pos;
+  const float tx = (floorf(pos.x + 0.5f + 0.5f * sgn(dir.x)) - pos.x) * idir.x;
+  const float ty = (floorf(pos.y + 0.5f + 0.5f * sgn(dir.y)) - pos.y) * idir.y;
+  const float tz = (floorf(pos.z + 0.5f + 0.5f * sgn(dir.z)) - pos.z) * idir.z;
+  const float t = fminf(fminf(fabsf(tx), fabsf(ty)), fabsf(tz));
+  return fmaxf(t / n, 0.0f);
+}
+__device__ __forceinline__ v3 safe_inverse(v3 d) {
+  v3 r;
+  r.x = fabsf(d.x) < 1e-16f ? 0.f : (float)(1.0 / (double)d.x);
+  r.y = fabsf(d.y) < 1e-16f ? 0.f : (float)(1.0 / (double)d.y);
+  r.z = fabsf(d.z) < 1e-16f ? 0.f : (float)(1.0 / (double)d.z);
+  return r;
+}
+constexpr int MAX_DDA_STEPS = 4096;
+constexpr float DDA_EPS = 1e-6f;
+
+// ---------------------------------------------------------------------------------- grid points
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    grid_points_kernel(int count, Grid g, const int* __restrict__ indices, Pcg rng, int randomize,
+                       float* __restrict__ out) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t vox = indices ? (uint32_t)indices[i] : (uint32_t)i;
+  v3 p = g.idx_to_pos(vox, true);
+  if (randomize) {
+    const float voxel = g.extent / g.n;
+    const float half = (float)((double)voxel / 2.0);
+    rng.advance((uint64_t)(int64_t)(i * 3));
+    p.x += voxel * rng.next_float() - half;
+    p.y += voxel * rng.next_float() - half;
+    p.z += voxel * rng.next_float() - half;
+  }
+  st3(out + 3 * (int64_t)i, p);
+}
+
+// ---------------------------------------------------------------------------------- grid updates
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    update_density_kernel(int count, const int* __restrict__ indices, const float* __restrict__ density, float decay,
+                          float thresh, float* __restrict__ values, uint8_t* __restrict__ occ) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const int vox = indices ? indices[i] : i;
+  const float v = fmaxf(density[i], values[vox] * decay);
+  values[vox] = v;
+  occ[vox] = v > thresh;
+}
+// NeuS logistic density: s e^{-sx} / (1 + e^{-sx})^2 (OccupancyGridGPU.cuh:381-384)
+__device__ __forceinline__ float logistic_density(float x, float s) {
+  const float e = expf(-s * x);
+  return s * e / powf(1 + e, 2);
+}
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    update_sdf_kernel(int count, const int* __restrict__ indices, const float* __restrict__ sdf, Grid g, float inv_s,
+                      const float* __restrict__ inv_s_tensor, int full_update, float thresh,
+                      float* __restrict__ values, uint8_t* __restrict__ occ) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const int vox = indices ? indices[i] : i;
+  const float voxel = g.extent / g.n;
+  const float half = (float)((double)voxel / 2.0);
+  const float half_diag = sqrtf(3.0f) * half;
+  const float v = sdf[i];
+  values[vox] = v;
+  const float err = (float)((full_update ? 1.3 : 1.0) * (double)half_diag);
+  const float x = fmaxf(0.f, fminf(fabsf(v) - err, 1e10f));
+  const float s = inv_s_tensor ? inv_s_tensor[0] : inv_s;
+  occ[vox] = logistic_density(x, s) > thresh;
+}
+
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    check_occupancy_kernel(int count, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ pts,
+                           uint8_t* __restrict__ out) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const int vox = g.pos_to_idx(ld3(pts + 3 * (int64_t)i));
+  out[i] = g.in_range(vox) ? occ[vox] : 0;
+}
+
+// ---------------------------------------------------------------------------------- DDA samplers
+// One thread per ray (the march is inherently serial and its float sequence is an index-exact contract).
+// WRITE=false: count the samples this ray will emit.  WRITE=true: emit them at offsets[ray].
+// USE_GRID=false gives the reference's compute_samples_fg (RaySamplerGPU.cuh:162) = same march without occupancy.
+template <bool WRITE, bool USE_GRID>
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    march_kernel(int nr_rays, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ origins,
+                 const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
+                 float min_dist, int max_per_ray, int max_nr_samples, Pcg rng, int jitter, const int* __restrict__ offsets,
+                 int* __restrict__ counts, float* __restrict__ s_pos, float* __restrict__ s_dirs, float* __restrict__ s_z,
+                 float* __restrict__ s_dt, float* __restrict__ ray_fixed_dt, int* __restrict__ start_end) {
+  const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (ray >= nr_rays) return;
+  const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
+  const v3 idir = safe_inverse(dir);
+  const float t_start = t_entry[ray], t_exit = t_exit_p[ray];
+  float occupied = 0.f;
+  if (USE_GRID) {
+    float t = t_start;
+    int steps = 0;
+    while (t < t_exit && steps < MAX_DDA_STEPS) {
+      const v3 pos = along(org, t, dir);
+      const int vox = g.pos_to_idx(pos);
+      if (!g.in_range(vox)) break;
+      const float d = dist_to_next_voxel(pos, dir, idir, g.n);
+      t += d;
+      t += DDA_EPS;
+      if (occ[vox]) {
+        occupied += d;
+        if ((t - DDA_EPS) > t_exit) occupied -= (t - DDA_EPS) - t_exit;
+      }
+      steps++;
+    }
+  } else {
+    occupied = t_exit - t_start;
+  }
+  int to_create = (int)(occupied / min_dist);
+  to_create = clampi(to_create, 0, max_per_ray);
+  const float spacing = occupied / to_create;
+  int created = 0;
+  int base = 0;
+  float last_z = 0.f;
+  bool go = USE_GRID ? (to_create > 1) : (to_create > 1 && occupied > DDA_EPS);
+  if (WRITE) {
+    // the count pass already ran the identical march: skip rays that emit nothing, and never write past the pool
+    const int cnt = counts[ray];
+    base = offsets[ray];
+    if (cnt == 0) {
+      start_end[2 * ray] = 0;
+      start_end[2 * ray + 1] = 0;
+      ray_fixed_dt[ray] = 0.f;
+      return;
+    }
+    if (base + cnt > max_nr_samples) {  // reservation overflows the pool: keep the range so consumers skip the ray
+      start_end[2 * ray] = base;
+      start_end[2 * ray + 1] = base + cnt;
+      ray_fixed_dt[ray] = spacing;
+      return;
+    }
+  }
+  if (go) {
+    float t = t_start;
+    int steps = 0;
+    if (jitter) {
+      rng.advance((uint64_t)(int64_t)ray);
+      t = t + spacing * rng.next_float();
+    }
+    while (t < t_exit && steps < MAX_DDA_STEPS) {
+      t = fmaxf(t_start, fminf(t, t_exit));
+      const v3 pos = along(org, t, dir);
+      bool occupied_here = true;
+      if (USE_GRID) {
+        const int vox = g.pos_to_idx(pos);
+        if (!g.in_range(vox)) break;
+        occupied_here = occ[vox];
+      }
+      if (occupied_here && created < to_create) {
+        if (WRITE) {
+          const int64_t o = base + created;
+          st3(s_pos + 3 * o, pos);
+          st3(s_dirs + 3 * o, dir);
+          s_z[o] = t;
+          s_dt[o] = spacing;
+        }
+        last_z = t;
+        t += spacing;
+        created++;
+      } else if (USE_GRID) {
+        float delta = dist_to_next_voxel(pos, dir, idir, g.n);
+        if (jitter) delta = delta + spacing * rng.next_float();
+        t += delta;
+        t += DDA_EPS;
+      } else {
+        break;  // all samples of a grid-less ray are out; the reference idles here until its step bound
+      }
+      steps++;
+    }
+    if (created <= 2) created = 0;  // rays with <= 2 samples are dropped (OccupancyGridGPU.cuh:685-689)
+  }
+  if (!WRITE) {
+    counts[ray] = created;
+    return;
+  }
+  if (created > 0) {
+    start_end[2 * ray] = base;
+    start_end[2 * ray + 1] = base + created;
+    ray_fixed_dt[ray] = spacing;
+    // the last sample may sit closer than `spacing` to the exit
+    s_dt[base + created - 1] = fmaxf(0.0f, fminf(t_exit - last_z, spacing));
+  } else {
+    start_end[2 * ray] = 0;
+    start_end[2 * ray + 1] = 0;
+    ray_fixed_dt[ray] = 0.f;
+  }
+}
+
+// first sample at the entry of the first occupied voxel (sphere-tracing start), OccupancyGridGPU.cuh:707-814
+template <bool WRITE>
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    first_hit_kernel(int nr_rays, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ origins,
+                     const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
+                     int max_nr_samples, const int* __restrict__ offsets, int* __restrict__ counts,
+                     float* __restrict__ s_pos, float* __restrict__ s_dirs, float* __restrict__ s_z,
+                     float* __restrict__ s_dt, float* __restrict__ ray_fixed_dt, int* __restrict__ start_end) {
+  const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (ray >= nr_rays) return;
+  const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
+  const v3 idir = safe_inverse(dir);
+  float t = t_entry[ray];
+  const float t_exit = t_exit_p[ray];
+  int steps = 0;
+  bool hit = false;
+  v3 hit_pos = mk3(0, 0, 0);
+  float hit_t = 0.f;
+  while (t < t_exit && steps < MAX_DDA_STEPS) {
+    const v3 pos = along(org, t, dir);
+    const int vox = g.pos_to_idx(pos);
+    if (!g.in_range(vox)) break;
+    const float d = dist_to_next_voxel(pos, dir, idir, g.n);
+    t += d;
+    t += DDA_EPS;
+    if (occ[vox]) {  // the stored z is the t AFTER the step, the position the one before it (as in the reference)
+      hit = true;
+      hit_pos = pos;
+      hit_t = t;
+      break;
+    }
+    // note: the reference does not count steps in this loop; the bound only guards degenerate directions
+    steps++;
+  }
+  if (!WRITE) {
+    counts[ray] = hit ? 1 : 0;
+    return;
+  }
+  ray_fixed_dt[ray] = 0.f;
+  if (hit) {
+    const int o = offsets[ray];
+    start_end[2 * ray] = o;
+    start_end[2 * ray + 1] = o + 1;
+    if (o + 1 <= max_nr_samples) {
+      st3(s_pos + 3 * (int64_t)o, hit_pos);
+      st3(s_dirs + 3 * (int64_t)o, dir);
+      s_z[o] = hit_t;
+      s_dt[o] = 0.f;
+    }
+  } else {
+    start_end[2 * ray] = 0;
+    start_end[2 * ray + 1] = 0;
+  }
+}
+
+// march a point along its direction to the next occupied voxel (OccupancyGridGPU.cuh:817-895); in place
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    advance_kernel(int count, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ dirs,
+                   float* __restrict__ pts, uint8_t* __restrict__ within) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const v3 org = ld3(pts + 3 * (int64_t)i), dir = ld3(dirs + 3 * (int64_t)i);
+  const v3 idir = safe_inverse(dir);
+  float t = 0.f;
+  int steps = 0;
+  bool inside = true;
+  const double limit = (double)g.n * sqrt(3.0);
+  while (inside && (double)steps < limit) {
+    const v3 pos = along(org, t, dir);
+    const int vox = g.pos_to_idx(pos);
+    if (!g.in_range(vox)) {
+      inside = false;
+      st3(pts + 3 * (int64_t)i, pos);
+      break;
+    }
+    const float d = dist_to_next_voxel(pos, dir, idir, g.n);
+    t += d;
+    t += DDA_EPS;
+    if (occ[vox]) {
+      st3(pts + 3 * (int64_t)i, pos);
+      break;
+    }
+    steps++;
+  }
+  within[i] = inside;
+}
+
+// ---------------------------------------------------------------------------------- background sampler
+// inverse-depth samples outside the bounding sphere, 3-D point (optionally contracted) + 4-D NeRF++ point
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    samples_bg_kernel(int nr_rays, int per_ray, const float* __restrict__ origins, const float* __restrict__ dirs,
+                      const float* __restrict__ t_exit_p, float radius, float cx, float cy, float cz, Pcg rng,
+                      int randomize, int contract, float* __restrict__ p3, float* __restrict__ p4,
+                      float* __restrict__ s_dirs, float* __restrict__ s_z, float* __restrict__ s_dt,
+                      float* __restrict__ ray_fixed_dt, int* __restrict__ start_end) {
+  const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (ray >= nr_rays) return;
+  const float t_exit = t_exit_p[ray];
+  const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
+  const v3 centre = mk3(cx, cy, cz);
+  const float min_t = 1e-3f;
+  const float step = (float)((1.0 - (double)min_t) / (per_ray - 1));
+  const int64_t base = (int64_t)ray * per_ray;
+  float prev_z = 0.f;
+  for (int i = 0; i < per_ray; i++) {
+    float ts = (float)(1.0 - (double)(i * step));
+    if (randomize) {
+      rng.advance((uint64_t)(int64_t)(ray * per_ray));
+      const float rnd = rng.next_float();
+      ts += (float)((double)(step * rnd) - (double)step / 2.0);
+    }
+    ts = fmaxf(min_t, fminf(ts, 1.0f));
+    const float z = t_exit / ts;
+    s_z[base + i] = z;
+    v3 p = along(org, z, dir);
+    if (contract) {
+      const float tr = ts * radius;
+      const float len = sqrtf(dot3(p, p));
+      const v3 u = mk3(p.x / len, p.y / len, p.z / len);
+      p = (2 * radius - tr) * u;
+    }
+    st3(p3 + 3 * (base + i), p);
+    const v3 q = p - centre;
+    const float inv = rsqrtf(dot3(q, q));
+    const float dist = sqrtf(dot3(q, q));
+    const v3 u = q * inv;
+    float* o4 = p4 + 4 * (base + i);
+    o4[0] = u.x;
+    o4[1] = u.y;
+    o4[2] = u.z;
+    o4[3] = radius / fmaxf(1e-6f, dist);
+    st3(s_dirs + 3 * (base + i), dir);
+    if (i > 0) s_dt[base + i - 1] = z - prev_z;
+    prev_z = z;
+  }
+  s_dt[base + per_ray - 1] = 1e10f;
+  ray_fixed_dt[ray] = 0.f;
+  start_end[2 * ray] = ray * per_ray;
+  start_end[2 * ray + 1] = ray * per_ray + per_ray;
+}
+
+// ---------------------------------------------------------------------------------- sphere
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    sphere_intersect_kernel(int nr_rays, float radius, float cx, float cy, float cz, const float* __restrict__ origins,
+                            const float* __restrict__ dirs, float* __restrict__ p_entry, float* __restrict__ t_entry,
+                            float* __restrict__ p_exit, float* __restrict__ t_exit, uint8_t* __restrict__ hit) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= nr_rays) return;
+  const v3 o = ld3(origins + 3 * (int64_t)i), d = ld3(dirs + 3 * (int64_t)i);
+  const v3 oc = o - mk3(cx, cy, cz);
+  const float a = dot3(d, d);
+  const float b = (float)(2.0 * (double)dot3(oc, d));
+  const float c = dot3(oc, oc) - radius * radius;
+  const float disc = b * b - 4 * a * c;
+  const float sq = sqrtf(fabsf(disc));
+  float t0 = (float)((double)(-b - sq) / (2.0 * (double)a));
+  float t1 = (float)((double)(-b + sq) / (2.0 * (double)a));
+  const bool miss = disc < 0;
+  if (miss) {
+    t0 = 0.f;
+    t1 = 0.f;
+  }
+  t0 = fmaxf(0.0f, t0);
+  st3(p_entry + 3 * (int64_t)i, along(o, t0, d));
+  st3(p_exit + 3 * (int64_t)i, along(o, t1, d));
+  t_entry[i] = t0;
+  t_exit[i] = t1;
+  hit[i] = !miss;
+}
+
+// spherical coordinates from three uniform tensors; like the reference (SphereGPU.cuh:121-127) the centre is ignored
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    sphere_rand_points_kernel(int count, float radius, const float* __restrict__ phi, const float* __restrict__ costheta,
+                              const float* __restrict__ u, float* __restrict__ out) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const float theta = acosf(costheta[i]);
+  const float r = (float)((double)radius * pow((double)u[i], 1.0 / 3));
+  const float st = sinf(theta);
+  out[3 * (int64_t)i] = r * st * cosf(phi[i]);
+  out[3 * (int64_t)i + 1] = r * st * sinf(phi[i]);
+  out[3 * (int64_t)i + 2] = r * cosf(theta);
+}
+
+// ---------------------------------------------------------------------------------- packed samples
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    ray_counts_kernel(int nr_rays, const int* __restrict__ start_end, int* __restrict__ counts) {
+  const int r = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (r < nr_rays) counts[r] = start_end[2 * r + 1] - start_end[2 * r];
+}
+// wave per ray: copy the ray's sample range to its compacted position (13 floats per sample)
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    compact_copy_kernel(int nr_rays, const int* __restrict__ start_end, const int* __restrict__ offsets,
+                        const float* __restrict__ pos, const float* __restrict__ pos4, const float* __restrict__ dirs,
+                        const float* __restrict__ z, const float* __restrict__ dt, const float* __restrict__ sdf,
+                        const float* __restrict__ fixed_dt, float* __restrict__ o_pos, float* __restrict__ o_pos4,
+                        float* __restrict__ o_dirs, float* __restrict__ o_z, float* __restrict__ o_dt,
+                        float* __restrict__ o_sdf, float* __restrict__ o_fixed_dt, int* __restrict__ o_start_end) {
+  const int lane = lane_id();
+  for (int ray = blockIdx.x * (PSDF_BLOCK / 64) + (threadIdx.x >> 6); ray < nr_rays; ray += gridDim.x * (PSDF_BLOCK / 64)) {
+    const int s = start_end[2 * ray], n = start_end[2 * ray + 1] - s;
+    const int64_t o = offsets[ray];
+    for (int j = lane; j < 3 * n; j += 64) {
+      o_pos[3 * o + j] = pos[3 * (int64_t)s + j];
+      o_dirs[3 * o + j] = dirs[3 * (int64_t)s + j];
+    }
+    for (int j = lane; j < 4 * n; j += 64) o_pos4[4 * o + j] = pos4[4 * (int64_t)s + j];
+    for (int j = lane; j < n; j += 64) {
+      o_z[o + j] = z[s + j];
+      o_dt[o + j] = dt[s + j];
+      o_sdf[o + j] = sdf[s + j];
+    }
+    if (lane == 0) {
+      o_fixed_dt[ray] = fixed_dt[ray];
+      o_start_end[2 * ray] = (int)o;
+      o_start_end[2 * ray + 1] = (int)o + n;
+    }
+  }
+}
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    per_sample_ray_idx_kernel(int nr_rays, int nr_samples, const int* __restrict__ start_end, int* __restrict__ out) {
+  const int lane = lane_id();
+  for (int ray = blockIdx.x * (PSDF_BLOCK / 64) + (threadIdx.x >> 6); ray < nr_rays; ray += gridDim.x * (PSDF_BLOCK / 64)) {
+    const int s = start_end[2 * ray], e = start_end[2 * ray + 1];
+    for (int i = s + lane; i < e; i += 64)
+      if (i < nr_samples) out[i] = ray;
+  }
+}
+
+// ---------------------------------------------------------------------------------- spherical harmonics
+// real SH basis, degree <= 7 (49 channels), polynomial form (PermutoSDFGPU.cuh:275-365)
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    sh_kernel(int count, int degree, int channels, const float* __restrict__ dirs, float* __restrict__ out) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  const float x = dirs[3 * (int64_t)i], y = dirs[3 * (int64_t)i + 1], z = dirs[3 * (int64_t)i + 2];
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  const float x4 = x2 * x2, y4 = y2 * y2, z4 = z2 * z2;
+  const float x6 = x4 * x2, y6 = y4 * y2, z6 = z4 * z2;
+  float* o = out + (int64_t)i * channels;
+  o[0] = 0.28209479177387814f;
+  if (degree <= 1) return;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  if (degree <= 2) return;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  if (degree <= 3) return;
+  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+  o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+  o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+  if (degree <= 4) return;
+  o[16] = 2.5033429417967046f * xy * (x2 - y2);
+  o[17] = 1.7701307697799304f * yz * (-3.0f * x2 + y2);
+  o[18] = 0.94617469575756008f * xy * (7.0f * z2 - 1.0f);
+  o[19] = 0.66904654355728921f * yz * (3.0f - 7.0f * z2);
+  o[20] = -3.1735664074561294f * z2 + 3.7024941420321507f * z4 + 0.31735664074561293f;
+  o[21] = 0.66904654355728921f * xz * (3.0f - 7.0f * z2);
+  o[22] = 0.47308734787878004f * (x2 - y2) * (7.0f * z2 - 1.0f);
+  o[23] = 1.7701307697799304f * xz * (-x2 + 3.0f * y2);
+  o[24] = -3.7550144126950569f * x2 * y2 + 0.62583573544917614f * x4 + 0.62583573544917614f * y4;
+  if (degree <= 5) return;
+  o[25] = 0.65638205684017015f * y * (10.0f * x2 * y2 - 5.0f * x4 - y4);
+  o[26] = 8.3026492595241645f * xy * z * (x2 - y2);
+  o[27] = -0.48923829943525038f * y * (3.0f * x2 - y2) * (9.0f * z2 - 1.0f);
+  o[28] = 4.7935367849733241f * xy * z * (3.0f * z2 - 1.0f);
+  o[29] = 0.45294665119569694f * y * (14.0f * z2 - 21.0f * z4 - 1.0f);
+  o[30] = 0.1169503224534236f * z * (-70.0f * z2 + 63.0f * z4 + 15.0f);
+  o[31] = 0.45294665119569694f * x * (14.0f * z2 - 21.0f * z4 - 1.0f);
+  o[32] = 2.3967683924866621f * z * (x2 - y2) * (3.0f * z2 - 1.0f);
+  o[33] = -0.48923829943525038f * x * (x2 - 3.0f * y2) * (9.0f * z2 - 1.0f);
+  o[34] = 2.0756623148810411f * z * (-6.0f * x2 * y2 + x4 + y4);
+  o[35] = 0.65638205684017015f * x * (10.0f * x2 * y2 - x4 - 5.0f * y4);
+  if (degree <= 6) return;
+  o[36] = 1.3663682103838286f * xy * (-10.0f * x2 * y2 + 3.0f * x4 + 3.0f * y4);
+  o[37] = 2.3666191622317521f * yz * (10.0f * x2 * y2 - 5.0f * x4 - y4);
+  o[38] = 2.0182596029148963f * xy * (x2 - y2) * (11.0f * z2 - 1.0f);
+  o[39] = -0.92120525951492349f * yz * (3.0f * x2 - y2) * (11.0f * z2 - 3.0f);
+  o[40] = 0.92120525951492349f * xy * (-18.0f * z2 + 33.0f * z4 + 1.0f);
+  o[41] = 0.58262136251873131f * yz * (30.0f * z2 - 33.0f * z4 - 5.0f);
+  o[42] = 6.6747662381009842f * z2 - 20.024298714302954f * z4 + 14.684485723822165f * z6 - 0.31784601133814211f;
+  o[43] = 0.58262136251873131f * xz * (30.0f * z2 - 33.0f * z4 - 5.0f);
+  o[44] = 0.46060262975746175f * (x2 - y2) * (11.0f * z2 * (3.0f * z2 - 1.0f) - 7.0f * z2 + 1.0f);
+  o[45] = -0.92120525951492349f * xz * (x2 - 3.0f * y2) * (11.0f * z2 - 3.0f);
+  o[46] = 0.50456490072872406f * (11.0f * z2 - 1.0f) * (-6.0f * x2 * y2 + x4 + y4);
+  o[47] = 2.3666191622317521f * xz * (10.0f * x2 * y2 - x4 - 5.0f * y4);
+  o[48] = 10.247761577878714f * x2 * y4 - 10.247761577878714f * x4 * y2 + 0.6831841051919143f * x6 - 0.6831841051919143f * y6;
+}
+
+// ---------------------------------------------------------------------------------- rays from the image reel
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    rays_from_reel_kernel(int nr_rays, int H, int W, const float* __restrict__ rgb, const float* __restrict__ mask,
+                          const float* __restrict__ K, const float* __restrict__ tf_world_cam,
+                          const int* __restrict__ pixel_idx, const int* __restrict__ img_idx, int has_mask,
+                          float* __restrict__ origins, float* __restrict__ dirs, float* __restrict__ gt_rgb,
+                          float* __restrict__ gt_mask) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= nr_rays) return;
+  const int im = img_idx[i], pix = pixel_idx[i];
+  const float px = (float)((double)(float)(pix % W) + 0.5), py = (float)((double)(float)(pix / W) + 0.5);
+  const float* Ki = K + 9 * (int64_t)im;
+  const float fx = Ki[0], fy = Ki[4], cx = Ki[2], cy = Ki[5];
+  const v3 pc = mk3((px - cx) / fx, (py - cy) / fy, 1.0f);
+  const float* T = tf_world_cam + 16 * (int64_t)im;  // row major [R|t]
+  const v3 t = mk3(T[3], T[7], T[11]);
+  // R * pc as the sum of scaled columns, in column order (mat3 * float3 of the reference)
+  v3 pw = mk3(T[0] * pc.x + T[1] * pc.y + T[2] * pc.z, T[4] * pc.x + T[5] * pc.y + T[6] * pc.z,
+              T[8] * pc.x + T[9] * pc.y + T[10] * pc.z);
+  pw = pw + t;
+  const v3 d0 = pw - t;
+  const v3 d = d0 * rsqrtf(dot3(d0, d0));
+  const int x = (int)floorf(px), y = (int)floorf(py);
+  const int64_t plane = (int64_t)H * W;
+  const float* img = rgb + (int64_t)im * 3 * plane + (int64_t)y * W + x;
+  const float m = has_mask ? mask[(int64_t)im * plane + (int64_t)y * W + x] : 1.0f;
+  st3(origins + 3 * (int64_t)i, t);
+  st3(dirs + 3 * (int64_t)i, d);
+  gt_rgb[3 * (int64_t)i] = img[0] * m;
+  gt_rgb[3 * (int64_t)i + 1] = img[plane] * m;
+  gt_rgb[3 * (int64_t)i + 2] = img[2 * plane] * m;
+  gt_mask[i] = m;
+}
+
+__global__ void __launch_bounds__(1024)
+    scan_i32_kernel(int n, const int* __restrict__ in, int* __restrict__ out, int* __restrict__ total_out) {
+  __shared__ int wave_tot[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = (i < n) ? in[i] : 0;
+    const int incl = wave_incl_scan_add_i(v);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += wave_tot[w];
+    const int carry = carry_s;
+    if (i < n) out[i] = carry + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
+inline Grid mk_grid(int n, float extent, const float* tr) { return Grid{n, extent, tr[0], tr[1], tr[2]}; }
+#define GRID1(n) dim3(psdf_blocks((n), PSDF_BLOCK)), dim3(PSDF_BLOCK), 0, st
+inline unsigned wave_ray_grid(int nr_rays) {
+  unsigned b = psdf_blocks(nr_rays, PSDF_BLOCK / 64);
+  return b < 16384u ? (b ? b : 1u) : 16384u;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+// grid_translation: HOST pointer to 3 floats.  Bool tensors are 1 byte per element (torch.bool).
+extern "C" {
+
+int psdf_grid_points(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
+                     const int* voxel_indices /*NULL = all voxels in Morton order*/, uint64_t rng_state, uint64_t rng_inc,
+                     int randomize, float* out_points, void* stream) {
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(grid_points_kernel, GRID1(count), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     voxel_indices, Pcg{rng_state, rng_inc}, randomize, out_points);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_grid_update_with_density(int count, const int* voxel_indices, const float* density, float decay, float thresh,
+                                  float* grid_values, uint8_t* grid_occupancy, void* stream) {
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(update_density_kernel, GRID1(count), count, voxel_indices, density, decay, thresh, grid_values,
+                     grid_occupancy);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// inv_s_tensor (device, 1 float) overrides inv_s when non-NULL.  full_update selects the sdf error range:
+// 1.3 half-diagonals for the full update, 1.0 for the random-subset update (OccupancyGridGPU.cuh:437 / :497).
+int psdf_grid_update_with_sdf(int count, const int* voxel_indices, const float* sdf, int nr_voxels_per_dim, float extent,
+                              const float* grid_translation, float inv_s, const float* inv_s_tensor, int full_update,
+                              float thresh, float* grid_values, uint8_t* grid_occupancy, void* stream) {
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(update_sdf_kernel, GRID1(count), count, voxel_indices, sdf,
+                     mk_grid(nr_voxels_per_dim, extent, grid_translation), inv_s, inv_s_tensor, full_update, thresh,
+                     grid_values, grid_occupancy);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_grid_check_occupancy(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
+                              const uint8_t* grid_occupancy, const float* points, uint8_t* out, void* stream) {
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(check_occupancy_kernel, GRID1(count), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     grid_occupancy, points, out);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// use_grid=1: OccupancyGrid::compute_samples_in_occupied_regions; use_grid=0: RaySampler::compute_samples_fg.
+// scratch: 2*nr_rays ints.  cur_nr_samples (device int) receives the exact total.
+int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
+                       const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs,
+                       const float* ray_t_entry, const float* ray_t_exit, float min_dist_between_samples,
+                       int max_nr_samples_per_ray, int max_nr_samples, uint64_t rng_state, uint64_t rng_inc, int jitter,
+                       float* samples_pos, float* samples_dirs, float* samples_z, float* samples_dt, float* ray_fixed_dt,
+                       int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Grid g = use_grid ? mk_grid(nr_voxels_per_dim, extent, grid_translation) : Grid{1, 1.f, 0.f, 0.f, 0.f};
+  Pcg rng{rng_state, rng_inc};
+  int* counts = scratch;
+  int* offsets = scratch + nr_rays;
+#define MARCH(W_, G_)                                                                                                  \
+  hipLaunchKernelGGL((march_kernel<W_, G_>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs,          \
+                     ray_t_entry, ray_t_exit, min_dist_between_samples, max_nr_samples_per_ray, max_nr_samples, rng,     \
+                     jitter, offsets, counts, samples_pos, samples_dirs, samples_z, samples_dt, ray_fixed_dt,            \
+                     ray_start_end_idx)
+  if (use_grid)
+    MARCH(false, true);
+  else
+    MARCH(false, false);
+  hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, counts, offsets, cur_nr_samples);
+  if (use_grid)
+    MARCH(true, true);
+  else
+    MARCH(true, false);
+#undef MARCH
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_first_hit_samples(int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
+                           const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs,
+                           const float* ray_t_entry, const float* ray_t_exit, int max_nr_samples, float* samples_pos,
+                           float* samples_dirs, float* samples_z, float* samples_dt, float* ray_fixed_dt,
+                           int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  Grid g = mk_grid(nr_voxels_per_dim, extent, grid_translation);
+  int* counts = scratch;
+  int* offsets = scratch + nr_rays;
+  hipLaunchKernelGGL((first_hit_kernel<false>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs,
+                     ray_t_entry, ray_t_exit, max_nr_samples, offsets, counts, samples_pos, samples_dirs, samples_z,
+                     samples_dt, ray_fixed_dt, ray_start_end_idx);
+  hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, counts, offsets, cur_nr_samples);
+  hipLaunchKernelGGL((first_hit_kernel<true>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs,
+                     ray_t_entry, ray_t_exit, max_nr_samples, offsets, counts, samples_pos, samples_dirs, samples_z,
+                     samples_dt, ray_fixed_dt, ray_start_end_idx);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// samples_pos is updated IN PLACE (the reference aliases input and output, src/OccupancyGrid.cu:311)
+int psdf_advance_to_next_occupied_voxel(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
+                                        const uint8_t* grid_occupancy, const float* samples_dirs, float* samples_pos,
+                                        uint8_t* is_within_bounds, void* stream) {
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(advance_kernel, GRID1(count), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     grid_occupancy, samples_dirs, samples_pos, is_within_bounds);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_samples_bg(int nr_rays, int nr_samples_per_ray, const float* ray_origins, const float* ray_dirs,
+                    const float* ray_t_exit, float sphere_radius, const float* sphere_center /*host, 3 floats*/,
+                    uint64_t rng_state, uint64_t rng_inc, int randomize, int contract_3d_samples, float* samples_3d,
+                    float* samples_4d, float* samples_dirs, float* samples_z, float* samples_dt, float* ray_fixed_dt,
+                    int* ray_start_end_idx, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  if (nr_samples_per_ray < 2) return PSDF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(samples_bg_kernel, GRID1(nr_rays), nr_rays, nr_samples_per_ray, ray_origins, ray_dirs, ray_t_exit,
+                     sphere_radius, sphere_center[0], sphere_center[1], sphere_center[2], Pcg{rng_state, rng_inc},
+                     randomize, contract_3d_samples, samples_3d, samples_4d, samples_dirs, samples_z, samples_dt,
+                     ray_fixed_dt, ray_start_end_idx);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_sphere_ray_intersection(int nr_rays, float radius, const float* center /*host*/, const float* ray_origins,
+                                 const float* ray_dirs, float* points_entry, float* t_entry, float* points_exit,
+                                 float* t_exit, uint8_t* does_intersect, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sphere_intersect_kernel, GRID1(nr_rays), nr_rays, radius, center[0], center[1], center[2],
+                     ray_origins, ray_dirs, points_entry, t_entry, points_exit, t_exit, does_intersect);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_sphere_rand_points_inside(int count, float radius, const float* phi, const float* costheta, const float* u,
+                                   float* points, void* stream) {
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sphere_rand_points_kernel, GRID1(count), count, radius, phi, costheta, u, points);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// generic compaction of a packed container with holes: counts -> scan -> wave-per-ray copy.
+// step 1 (this call) computes offsets + total; the caller reads the total (the one host sync the API
+// semantics require: the result tensors are exactly sized) and calls psdf_compact_copy.
+int psdf_compact_offsets(int nr_rays, const int* ray_start_end_idx, int* scratch /*2*nr_rays*/, int* total,
+                         void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ray_counts_kernel, GRID1(nr_rays), nr_rays, ray_start_end_idx, scratch);
+  hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, scratch, scratch + nr_rays, total);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+int psdf_compact_copy(int nr_rays, const int* ray_start_end_idx, const int* offsets, const float* pos, const float* pos4,
+                      const float* dirs, const float* z, const float* dt, const float* sdf, const float* fixed_dt,
+                      float* o_pos, float* o_pos4, float* o_dirs, float* o_z, float* o_dt, float* o_sdf,
+                      float* o_fixed_dt, int* o_start_end, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(compact_copy_kernel, dim3(wave_ray_grid(nr_rays)), dim3(PSDF_BLOCK), 0, st, nr_rays,
+                     ray_start_end_idx, offsets, pos, pos4, dirs, z, dt, sdf, fixed_dt, o_pos, o_pos4, o_dirs, o_z, o_dt,
+                     o_sdf, o_fixed_dt, o_start_end);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_per_sample_ray_idx(int nr_rays, int nr_samples, const int* ray_start_end_idx, int* out, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(per_sample_ray_idx_kernel, dim3(wave_ray_grid(nr_rays)), dim3(PSDF_BLOCK), 0, st, nr_rays,
+                     nr_samples, ray_start_end_idx, out);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_spherical_harmonics(int count, int degree, const float* dirs, float* out, void* stream) {
+  if (degree < 1 || degree > 7) return PSDF_ERR_ARG;
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sh_kernel, GRID1(count), count, degree, degree * degree, dirs, out);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_random_rays_from_reel(int nr_rays, int nr_images, int height, int width, const float* rgb_reel,
+                               const float* mask_reel, const float* K_reel, const float* tf_world_cam_reel,
+                               const int* pixel_indices, const int* img_indices, int has_mask, float* ray_origins,
+                               float* ray_dirs, float* gt_rgb, float* gt_mask, void* stream) {
+  (void)nr_images;
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(rays_from_reel_kernel, GRID1(nr_rays), nr_rays, height, width, rgb_reel, mask_reel, K_reel,
+                     tf_world_cam_reel, pixel_indices, img_indices, has_mask, ray_origins, ray_dirs, gt_rgb, gt_mask);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+}  // extern "C"

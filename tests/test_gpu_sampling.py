@@ -1,0 +1,279 @@
+"""GPU parity (through the drop-in `permuto_sdf` API -> C ABI -> HIP) vs the CPU oracle for the sample-generation
+rows: OccupancyGrid, RaySampler, Sphere, RaySamplesPacked, spherical harmonics, rays from reel.
+Bar: bit-exact for everything built from + - * / sqrt floor (voxel indices, per-ray counts, sample positions);
+1e-6 where device libm / rsqrt differ from the host's (stated per assertion)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def bits_equal(t, a):
+    t = t.detach().cpu().numpy()
+    assert t.shape == a.shape, (t.shape, a.shape)
+    if a.dtype == np.float32:
+        assert np.array_equal(t.view(np.uint32), a.view(np.uint32)), float(np.abs(t - a).max())
+    else:
+        assert np.array_equal(t, a)
+
+
+@pytest.fixture(scope="module")
+def port():
+    return O.Oracle("port")
+
+
+@pytest.fixture(scope="module", params=[64, 256])
+def world(request, port, dev):
+    from permuto_sdf import OccupancyGrid, Sphere
+    n = request.param
+    occ = scene.shell_occupancy(port, n)
+    o, d = scene.make_rays(2000, seed=3)
+    sph = Sphere(0.5, [0, 0, 0])
+    grid = OccupancyGrid(n, 1.0, [0, 0, 0])
+    grid.set_grid_occupancy(T(occ, dev))
+    _, te, _, tx, _ = port.sphere_intersect(0.5, [0, 0, 0], o, d)
+    return dict(n=n, occ=occ, gridnp=(n, 1.0, [0, 0, 0], occ), grid=grid, sphere=sph, o=o, d=d, te=te, tx=tx)
+
+
+def test_sphere_intersection(port, dev):
+    from permuto_sdf import Sphere
+    o, d = scene.make_rays(5000, seed=9, jitter_target=0.8)
+    c = [0.05, -0.02, 0.01]
+    ref = port.sphere_intersect(0.5, c, o, d)
+    out = Sphere(0.5, c).ray_intersection(T(o, dev), T(d, dev))
+    for a, b in zip(out, ref):
+        bits_equal(a, b)
+    assert out[4].dtype == torch.bool
+    # ray through the centre: t0 = |o| - r, t1 = |o| + r  (known answer)
+    o1 = torch.tensor([[0.0, 0.0, -2.0]], device=dev)
+    d1 = torch.tensor([[0.0, 0.0, 1.0]], device=dev)
+    _, t0, _, t1, hit = Sphere(0.5, [0, 0, 0]).ray_intersection(o1, d1)
+    assert float(t0) == 1.5 and float(t1) == 2.5 and bool(hit)
+    # empty input
+    e = Sphere(0.5, [0, 0, 0]).ray_intersection(torch.zeros(0, 3, device=dev), torch.zeros(0, 3, device=dev))
+    assert e[0].shape == (0, 3) and e[4].shape == (0, 1)
+
+
+def test_sphere_points_and_inside(port, dev):
+    from permuto_sdf import Sphere
+    s = Sphere(0.5, [0, 0, 0])
+    torch.manual_seed(0)
+    pts = s.rand_points_inside(30000)
+    assert pts.shape == (30000, 3)
+    assert float(pts.norm(dim=1).max()) <= 0.5 * (1 + 1e-5)
+    assert bool(s.check_point_inside_primitive(pts).all())
+    # kernel arithmetic vs oracle on explicit uniforms (device sin/cos/acos/pow differ from glibc by a few ulp)
+    rng = np.random.default_rng(2)
+    phi, ct, u = rng.uniform(0, 6.28, 4000), rng.uniform(-1, 1, 4000), rng.uniform(0, 1, 4000)
+    ref = port.rand_points_inside(0.5, phi, ct, u)
+    from permuto_sdf_amd import _lib as L
+    out = torch.empty(4000, 3, device=dev)
+    L.call("psdf_sphere_rand_points_inside", L.c_i(4000), L.c_f(0.5), L.ptr(T(phi.astype(np.float32), dev)),
+           L.ptr(T(ct.astype(np.float32), dev)), L.ptr(T(u.astype(np.float32), dev)), L.ptr(out), L.stream())
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-6
+
+
+def test_grid_points_and_morton(port, dev):
+    from permuto_sdf import OccupancyGrid
+    g = OccupancyGrid(32, 1.0, [0.1, -0.2, 0.05])
+    assert g.get_nr_voxels() == 32 ** 3 and g.get_nr_voxels_per_dim() == 32
+    bits_equal(g.compute_grid_points(False), port.grid_points(32, 1.0, [0.1, -0.2, 0.05]))
+    # jittered points use the process-global generator: replay its state in the oracle
+    st = (OccupancyGrid._rng.state, OccupancyGrid._rng.inc)
+    bits_equal(g.compute_grid_points(True), port.grid_points(32, 1.0, [0.1, -0.2, 0.05], randomize=True, rng=st))
+    assert OccupancyGrid._rng.state != st[0]          # advanced by 2^32 on the host, like the reference
+    st = (OccupancyGrid._rng.state, OccupancyGrid._rng.inc)
+    pts, idx = g.compute_random_sample_of_grid_points(5000, True)
+    assert idx.dtype == torch.int32 and int(idx.min()) >= 0 and int(idx.max()) < 32 ** 3
+    bits_equal(pts, port.grid_points(32, 1.0, [0.1, -0.2, 0.05], idx.cpu().numpy(), True, rng=st))
+    # Morton round trip: centre of voxel i maps back to voxel i (occupancy one-hot probe)
+    g2 = OccupancyGrid(16, 1.0, [0, 0, 0])
+    centres = g2.compute_grid_points(False)
+    for probe in (0, 1, 2, 4, 77, 16 ** 3 - 1):
+        occ = torch.zeros(16 ** 3, dtype=torch.bool, device=dev)
+        occ[probe] = True
+        g2.set_grid_occupancy(occ)
+        hit = g2.check_occupancy(centres).view(-1)
+        assert int(hit.sum()) == 1 and bool(hit[probe])
+    with pytest.raises(ValueError):
+        OccupancyGrid(48, 1.0, [0, 0, 0])
+
+
+def test_grid_updates(port, dev):
+    from permuto_sdf import OccupancyGrid
+    n = 32
+    rng = np.random.default_rng(1)
+    vals = rng.uniform(0, 2, n ** 3).astype(np.float32)
+    occ = rng.uniform(size=n ** 3) > 0.5
+    dens = rng.uniform(0, 3, (n ** 3, 1)).astype(np.float32)
+
+    def fresh():
+        g = OccupancyGrid(n, 1.0, [0, 0, 0])
+        g.set_grid_values(T(vals, dev).clone())
+        g.set_grid_occupancy(T(occ, dev).clone())
+        return g
+
+    g = fresh()
+    g.update_with_density(T(dens, dev), 0.95, 0.5)
+    rv, ro = port.update_with_density(vals, occ, dens, 0.95, 0.5)
+    bits_equal(g.get_grid_values(), rv)
+    bits_equal(g.get_grid_occupancy(), ro)
+    idx = np.unique(rng.integers(0, n ** 3, 6000)).astype(np.int32)       # unique: duplicates race in the reference
+    g = fresh()
+    g.update_with_density_random_sample(T(idx, dev), T(dens[:len(idx)], dev), 0.9, 0.7)
+    rv, ro = port.update_with_density(vals, occ, dens[:len(idx)], 0.9, 0.7, idx)
+    bits_equal(g.get_grid_values(), rv)
+    bits_equal(g.get_grid_occupancy(), ro)
+    sdf = rng.normal(0, 0.05, (n ** 3, 1)).astype(np.float32)
+    for inv_s in (64.0, 512.0):
+        g = fresh()
+        g.update_with_sdf(T(sdf, dev), inv_s, 0.0, 1e-4)
+        rv, ro = port.update_with_sdf(vals, occ, sdf, n, 1.0, inv_s, 1e-4)
+        bits_equal(g.get_grid_values(), rv)
+        # occupancy threshold goes through exp/pow: allow the device libm to flip voxels within 1e-5 of the threshold
+        mism = (g.get_grid_occupancy().cpu().numpy() != ro).mean()
+        assert mism < 1e-4, mism
+        g = fresh()
+        g.update_with_sdf_random_sample(T(idx, dev), T(sdf[:len(idx)], dev), torch.tensor([inv_s], device=dev), 1e-4)
+        rv, ro = port.update_with_sdf(vals, occ, sdf[:len(idx)], n, 1.0, inv_s, 1e-4, idx)
+        bits_equal(g.get_grid_values(), rv)
+        assert (g.get_grid_occupancy().cpu().numpy() != ro).mean() < 1e-4
+
+
+def test_check_occupancy_and_advance(port, world, dev):
+    w = world
+    pts = np.random.default_rng(5).uniform(-0.6, 0.6, (20000, 3)).astype(np.float32)   # includes out-of-grid points
+    bits_equal(w["grid"].check_occupancy(T(pts, dev)), port.check_occupancy(*w["gridnp"][:3], w["occ"], pts))
+    dirs = w["d"][:1000]
+    start = np.clip(w["o"][:1000] + w["te"][:1000] * dirs, -0.49, 0.49).astype(np.float32)
+    ref_pos, ref_in = port.advance_samples(dirs, start, w["gridnp"])
+    p = T(start, dev)
+    new_pos, within = w["grid"].advance_sample_to_next_occupied_voxel(T(dirs, dev), p)
+    bits_equal(new_pos, ref_pos)
+    bits_equal(within, ref_in)
+    assert new_pos.data_ptr() == p.data_ptr()      # in place, like the reference
+
+
+def compare_packed(rs, ref, exact=True):
+    """rs: RaySamplesPacked (already compact / ray ordered); ref: compacted oracle Samples."""
+    n = ref.total()
+    assert rs.compute_exact_nr_samples() == n
+    c = rs.compact_to_valid_samples()
+    assert c.samples_pos.shape[0] == n
+    bits_equal(c.ray_start_end_idx, ref.start_end)
+    bits_equal(c.ray_fixed_dt, ref.fixed_dt)
+    for name, arr in (("samples_pos", ref.pos), ("samples_dirs", ref.dirs), ("samples_z", ref.z), ("samples_dt", ref.dt)):
+        bits_equal(getattr(c, name), arr[:n])
+    return c
+
+
+@pytest.mark.parametrize("jitter", [False, True])
+def test_compute_samples_in_occupied_regions(port, world, dev, jitter):
+    from permuto_sdf import OccupancyGrid
+    w = world
+    st = (OccupancyGrid._rng.state, OccupancyGrid._rng.inc)
+    rs = w["grid"].compute_samples_in_occupied_regions(T(w["o"], dev), T(w["d"], dev), T(w["te"], dev), T(w["tx"], dev),
+                                                       1e-3, 64, jitter)
+    ref = port.march_samples(w["o"], w["d"], w["te"], w["tx"], 1e-3, 64, 1 << 21, grid=w["gridnp"], jitter=jitter, rng=st)
+    ref_c = port.compact(ref)
+    assert ref_c.total() > 10000
+    counts = ref_c.counts()
+    assert ((counts == 0) | (counts >= 3)).all()             # invariant: a ray has 0 or >= 3 samples
+    c = compare_packed(rs, ref_c)
+    ridx = c.compute_per_sample_ray_idx(c.ray_start_end_idx, c.samples_pos.shape[0])
+    bits_equal(ridx, port.per_sample_ray_idx(ref_c.start_end, ref_c.total()))
+
+
+def test_generic_compaction_with_holes(port, world, dev):
+    """compact_to_valid_samples on a container with holes (the reference's pool layout, produced by the oracle)."""
+    from permuto_sdf import RaySamplesPacked
+    w = world
+    ref = port.march_samples(w["o"], w["d"], w["te"], w["tx"], 1e-3, 64, 1 << 17, grid=w["gridnp"])
+    rs = RaySamplesPacked(len(w["o"]), 1 << 17)
+    rs.samples_pos.copy_(T(ref.pos, dev)); rs.samples_dirs.copy_(T(ref.dirs, dev))
+    rs.samples_z.copy_(T(ref.z, dev)); rs.samples_dt.copy_(T(ref.dt, dev)); rs.samples_sdf.copy_(T(ref.sdf, dev))
+    rs.samples_pos_4d.zero_()
+    rs.ray_fixed_dt.copy_(T(ref.fixed_dt, dev)); rs.ray_start_end_idx.copy_(T(ref.start_end, dev))
+    compare_packed(rs, port.compact(ref))
+
+
+@pytest.mark.parametrize("jitter", [False, True])
+def test_ray_sampler_fg_bg(port, world, dev, jitter):
+    from permuto_sdf import RaySampler
+    w = world
+    o, d, te, tx = (T(w[k], dev) for k in ("o", "d", "te", "tx"))
+    st = (RaySampler._rng.state, RaySampler._rng.inc)
+    rs = RaySampler.compute_samples_fg(o, d, te, tx, 1e-2, 48, 0.5, torch.zeros(3, device=dev), jitter)
+    ref = port.compact(port.march_samples(w["o"], w["d"], w["te"], w["tx"], 1e-2, 48, len(w["o"]) * 48, jitter=jitter, rng=st))
+    compare_packed(rs, ref)
+    for contract in (False, True):
+        st = (RaySampler._rng.state, RaySampler._rng.inc)
+        bg = RaySampler.compute_samples_bg(o, d, tx, 32, 0.5, [0, 0, 0], jitter, contract)
+        rb = port.samples_bg(w["o"], w["d"], w["tx"], 32, 0.5, [0, 0, 0], jitter, contract, rng=st)
+        assert bg.rays_have_equal_nr_of_samples and bg.fixed_nr_of_samples_per_ray == 32
+        bits_equal(bg.samples_z, rb.z)
+        bits_equal(bg.samples_dt, rb.dt)
+        bits_equal(bg.samples_pos, rb.pos)
+        bits_equal(bg.samples_dirs, rb.dirs)
+        bits_equal(bg.ray_start_end_idx, rb.start_end)
+        # 4-D point: direction uses the device reciprocal square root (1 ulp) -> 1e-6
+        assert np.abs(bg.samples_pos_4d.cpu().numpy() - rb.pos4).max() < 1e-6
+
+
+def test_first_hit(port, world, dev):
+    w = world
+    rs = w["grid"].compute_first_sample_start_of_occupied_regions(T(w["o"], dev), T(w["d"], dev), T(w["te"], dev), T(w["tx"], dev))
+    ref = port.compact(port.first_hit_samples(w["o"], w["d"], w["te"], w["tx"], 1 << 21, w["gridnp"]))
+    assert ref.total() > 100
+    compare_packed(rs, ref)
+
+
+def test_spherical_harmonics(port, dev):
+    from permuto_sdf import PermutoSDF
+    _, d = scene.make_rays(5000, seed=11)
+    for deg in range(1, 8):
+        out = PermutoSDF.spherical_harmonics(T(d, dev), deg)
+        assert out.shape == (5000, deg * deg)
+        bits_equal(out, port.spherical_harmonics(d, deg))
+    assert abs(float(out[0, 0]) - 0.28209479) < 1e-7         # band-0 constant (known answer)
+    with pytest.raises(ValueError):
+        PermutoSDF.spherical_harmonics(T(d, dev), 8)
+
+
+def test_random_rays_from_reel(port, dev):
+    from permuto_sdf import PermutoSDF
+    rng = np.random.default_rng(2)
+    I, H, W = 4, 30, 40
+
+    class Reel:
+        pass
+    reel = Reel()
+    rgb = rng.uniform(size=(I, 3, H, W)).astype(np.float32)
+    mask = (rng.uniform(size=(I, 1, H, W)) > 0.3).astype(np.float32)
+    K = np.tile(np.array([[30, 0, 20], [0, 31, 15], [0, 0, 1]], np.float32), (I, 1, 1))
+    tf = np.tile(np.eye(4, dtype=np.float32), (I, 1, 1))
+    tf[:, :3, :3] = np.linalg.qr(rng.normal(size=(I, 3, 3)))[0]
+    tf[:, :3, 3] = rng.normal(size=(I, 3))
+    reel.rgb_reel, reel.mask_reel, reel.K_reel, reel.tf_world_cam_reel = (T(a, dev) for a in (rgb, mask, K, tf))
+    for has_mask in (True, False):
+        reel.has_mask = has_mask
+        torch.manual_seed(5)
+        o, d, gt, gm, img = PermutoSDF.random_rays_from_reel(reel, 3000)
+        torch.manual_seed(5)   # the launcher draws pixel indices first, then image indices
+        pix = torch.randint(0, H * W, (3000,), dtype=torch.int32, device=dev)
+        img2 = torch.randint(0, I, (3000,), dtype=torch.int32, device=dev)
+        assert torch.equal(img, img2)
+        ro, rd, rgt, rgm = port.random_rays_from_reel(rgb, mask, K, tf, pix.cpu().numpy(), img.cpu().numpy(), has_mask)
+        bits_equal(o, ro)
+        bits_equal(gt, rgt)
+        bits_equal(gm, rgm)
+        assert np.abs(d.cpu().numpy() - rd).max() < 1e-6       # normalisation through the device rsqrt
+        assert np.abs(d.norm(dim=1).cpu().numpy() - 1).max() < 1e-6
