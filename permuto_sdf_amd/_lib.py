@@ -31,12 +31,20 @@ def lib():
     return _lib
 
 
+class _Ptr(ctypes.c_void_p):
+    """c_void_p that keeps its tensor alive for as long as the argument tuple of the call exists (a temporary
+    made by `.contiguous()` must not be recycled by the caching allocator before the launch is enqueued)."""
+    pass
+
+
 def ptr(t):
     """Raw device pointer of a contiguous tensor (None -> NULL)."""
     if t is None:
         return None
     assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
-    return ctypes.c_void_p(t.data_ptr())
+    p = _Ptr(t.data_ptr())
+    p.keepalive = t
+    return p
 
 
 def stream():

@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     // the count pass already ran the identical march: skip rays that emit nothing, and never write past the pool
     const int cnt = counts[ray];
     base = offsets[ray];
-    if (cnt == 0) {
-      start_end[2 * ray] = 0;
-      start_end[2 * ray + 1] = 0;
+    if (cnt == 0) {  // empty range at the running offset: the layout the reference has after its compaction pass
+      start_end[2 * ray] = base;
+      start_end[2 * ray + 1] = base;
       ray_fixed_dt[ray] = 0.f;
       return;
     }
@@ -326,8 +326,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       s_dt[o] = 0.f;
     }
   } else {
-    start_end[2 * ray] = 0;
-    start_end[2 * ray + 1] = 0;
+    const int o = offsets[ray];
+    start_end[2 * ray] = o;
+    start_end[2 * ray + 1] = o;
   }
 }
 

@@ -460,14 +460,14 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   int us, ue;
   uni.get(ray, us, ue);
   const int un = ue - us;
-  if (un <= 1) {
+  const int base = offsets[ray];
+  if (un <= 1) {  // empty range at the running offset (the reference's layout after compaction)
     out_fixed_dt[ray] = 0.f;
-    out_start_end[2 * ray] = 0;
-    out_start_end[2 * ray + 1] = 0;
+    out_start_end[2 * ray] = base;
+    out_start_end[2 * ray + 1] = base;
     return;
   }
   const int total = un + nr_imp;
-  const int base = offsets[ray];
   out_start_end[2 * ray] = base;
   out_start_end[2 * ray + 1] = base + total;
   if (base + total > out_max) return;

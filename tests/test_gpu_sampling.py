@@ -76,8 +76,8 @@ def test_sphere_points_and_inside(port, dev):
     ref = port.rand_points_inside(0.5, phi, ct, u)
     from permuto_sdf_amd import _lib as L
     out = torch.empty(4000, 3, device=dev)
-    L.call("psdf_sphere_rand_points_inside", L.c_i(4000), L.c_f(0.5), L.ptr(T(phi.astype(np.float32), dev)),
-           L.ptr(T(ct.astype(np.float32), dev)), L.ptr(T(u.astype(np.float32), dev)), L.ptr(out), L.stream())
+    tp, tc, tu = (T(a.astype(np.float32), dev) for a in (phi, ct, u))    # keep the device buffers alive over the call
+    L.call("psdf_sphere_rand_points_inside", L.c_i(4000), L.c_f(0.5), L.ptr(tp), L.ptr(tc), L.ptr(tu), L.ptr(out), L.stream())
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-6
 
 
