@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Benchmark of the PermutoSDF data-parallel hot path on MI355X (contract: see the round instructions).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1] + the compositing of configs[2]'s chunk size): per GPU 16 384 rays x 128 samples
+= 2 097 152 synthetic ray samples inside the radius-0.5 bounding sphere, already resident in HBM.  One step =
+  forward : 16-level permutohedral encode (T=2^18, F=2, +points) -> fused 64x3 SDF MLP (fp32 MFMA) -> sdf2alpha ->
+            transmittance cumprod -> weights -> per-ray weight sum -> radiance integration
+  backward: integrate_backward -> cumprod backward (incl. per-ray inverse cumsum) -> fused MLP backward (dX, dW, db)
+            -> encode backward (lattice gradient)   [dL/dsdf = ones: the reference has no native sdf->alpha backward]
+  N > 1   : RCCL sum all-reduce of MLP + lattice gradients (bucketed, overlapped with the encode backward)
+  update  : fused AdamW on lattice + MLP parameters
+value = ray samples through that whole step per second, summed over ranks (weak scaling: per-GPU work is fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+NR_RAYS = 16384
+SAMPLES_PER_RAY = 128
+NR_LEVELS = 16
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3
+
+
+def make_batch(dev, seed, nr_rays=NR_RAYS, per_ray=SAMPLES_PER_RAY):
+    """Equal-count packed ray samples inside the bounding sphere + synthetic per-sample radiance."""
+    from permuto_sdf import RaySamplesPacked, Sphere
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    o = torch.randn(nr_rays, 3, generator=g)
+    o = o / o.norm(dim=1, keepdim=True) * 1.5
+    target = (torch.rand(nr_rays, 3, generator=g) - 0.5) * 0.7
+    d = target - o
+    d = d / d.norm(dim=1, keepdim=True)
+    o, d = o.to(dev), d.to(dev)
+    _, te, _, tx, hit = Sphere(0.5, [0, 0, 0]).ray_intersection(o, d)
+    n = per_ray
+    frac = (torch.arange(n, device=dev, dtype=torch.float32) + 0.5) / n
+    z = te + (tx - te) * frac[None, :]                                   # [R, n]
+    rs = RaySamplesPacked(nr_rays, nr_rays * n, device=dev)
+    rs.rays_have_equal_nr_of_samples, rs.fixed_nr_of_samples_per_ray = True, n
+    rs.samples_z = z.reshape(-1, 1).contiguous()
+    rs.samples_dt = ((tx - te) / n).expand(-1, n).reshape(-1, 1).contiguous()
+    rs.samples_pos = (o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3).contiguous()
+    rs.samples_dirs = d[:, None, :].expand(-1, n, -1).reshape(-1, 3).contiguous()
+    rs.ray_fixed_dt = ((tx - te) / n).contiguous()
+    idx = torch.arange(nr_rays, device=dev, dtype=torch.int32) * n
+    rs.ray_start_end_idx = torch.stack([idx, idx + n], 1).contiguous()
+    rs.cur_nr_samples.fill_(nr_rays * n)
+    rs._exact = True
+    rgb = torch.rand(nr_rays * n, 3, generator=g).to(dev)
+    return rs, rgb, (o, d, te, tx)
+
+
+def cpu_baseline(cores):
+    """The CPU oracle timed on a bounded sample of the same workload: torch-vectorised encode restatement + the
+    unmodified torch.nn MLP (fwd + autograd bwd) + the C compositing oracle (fwd + bwd), fp32, `cores` threads."""
+    from oracle import oracle as O
+    from oracle import permuto_oracle as po
+    torch.set_num_threads(cores)
+    rays, per_ray = 1024, SAMPLES_PER_RAY
+    N = rays * per_ray
+    g = torch.Generator().manual_seed(1)
+    pos = torch.randn(N, 3, generator=g)
+    pos = pos / pos.norm(dim=1, keepdim=True) * 0.5 * torch.rand(N, 1, generator=g) ** (1 / 3)
+    lat, shifts = po.make_params(3, 2 ** 18, NR_LEVELS, 2, seed=2, init_scale=1e-2)
+    lat.requires_grad_(True)
+    sl = np.geomspace(1.0, 1e-4, NR_LEVELS)
+    C = po.output_dims(3, NR_LEVELS, 2, True)
+    mlp = torch.nn.Sequential(torch.nn.Linear(C, 64), torch.nn.GELU(), torch.nn.Linear(64, 64), torch.nn.GELU(),
+                              torch.nn.Linear(64, 64), torch.nn.GELU(), torch.nn.Linear(64, 1))
+    port = O.Oracle("port")
+    s = O.Samples(rays, N)
+    s.equal, s.fixed = True, per_ray
+    s.dt[:] = 1.0 / per_ray / 2
+    s.fixed_dt[:] = 1.0 / per_ray / 2
+    rgb = np.random.default_rng(0).uniform(size=(N, 3)).astype(np.float32)
+    win = torch.ones(NR_LEVELS)
+
+    def one():
+        feat = po.encode(pos, lat, sl, shifts, win, True, 1e-3)
+        sdf = mlp(feat)
+        sdf_np = sdf.detach().numpy()
+        alpha = port.sdf2alpha(s, sdf_np, 512.0, True, 1.0)
+        om = (1 - alpha + 1e-7).astype(np.float32)
+        T, bg = port.cumprod(s, om)
+        w = alpha * T
+        port.sum_over_each_ray(s, w)
+        pred = port.integrate(s, rgb, w)
+        g_rgb, g_w = port.integrate_backward(s, np.ones_like(pred), rgb, w)
+        gT = (g_w * alpha).astype(np.float32)
+        cs = port.cumsum(s, (gT * T).astype(np.float32), True)
+        port.cumprod_backward(s, gT, np.zeros_like(bg), om, T, bg, cs)
+        sdf.backward(torch.ones_like(sdf))
+        lat.grad = None
+        mlp.zero_grad()
+
+    one()  # warm-up (page-in, thread pools)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0) < 10.0:
+        one()
+        reps += 1
+        if time.perf_counter() - t0 > 30.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": N / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d rays x %d samples (%d samples) of the same step: torch-CPU encode restatement fwd+bwd, torch.nn "
+                      "64x3 MLP fwd+bwd, C compositing oracle fwd+bwd; %d repetitions, %.2f s each" % (rays, per_ray, N, reps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from permuto_sdf_amd import parallel
+    from permuto_sdf_amd.hotpath import SdfHotPath
+    rank, world, local = parallel.init()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    hp = SdfHotPath(nr_levels=NR_LEVELS, hidden=64, out_channels=1, device=dev, seed=0)   # replicated parameters
+    rs, rgb, _ = make_batch(dev, parallel.rank_seed(7, rank))                               # per-rank rays
+    N = rs.samples_pos.shape[0]
+    grad_pred = torch.ones(NR_RAYS, 3, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hp.step(rs, rgb, grad_pred)
+    # per-kernel HIP events on the launch stream (torch's current stream == the stream the kernels are launched on)
+    K = args.steps
+    ev = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+          for k in ("enc_bwd", "mlp_bwd", "fwd")}
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        hp.events = {"enc_bwd": ev["enc_bwd"][i], "mlp_bwd": ev["mlp_bwd"][i]}
+        ev["fwd"][i][0].record()
+        pred, saved = hp.forward(rs, rgb)
+        ev["fwd"][i][1].record()
+        hp.backward(rs, rgb, saved, grad_pred)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hp.events = None
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+        # dominant kernel: the encode backward (lattice scatter).  Algorithmic bytes per sample:
+        # 4*(P + L*F + 2*L*F*(P+1)) = read position + read the L*F upstream gradients + read-modify-write of the
+        # (P+1)*L*F table entries; plus one zero-fill + final read of the 4*L*T*F gradient table per launch.
+        P, F, L_, Tcap = 3, 2, NR_LEVELS, 2 ** 18
+        alg_bytes = N * 4 * (P + L_ * F + 2 * L_ * F * (P + 1)) + 2 * 4 * L_ * Tcap * F
+        achieved = alg_bytes / (ms["enc_bwd"] * 1e-3) / 1e9
+        flops_mlp_bwd = 2 * 2 * (36 * 64 + 64 * 64 * 2 + 64) * N + 2 * (36 * 64 + 64 * 64 * 2 + 64) * N  # dX,dW chains + recompute
+        out = {
+            "metric": "ray-samples/sec (encode+MLP+composite)",
+            "value": world * N * K / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cfg2+composite: 16-level permutohedral encode fwd/bwd + 64x3 SDF MLP fwd/bwd + NeuS "
+                                   "compositing fwd/bwd + AdamW, %d rays x %d samples = %d samples per GPU" % (NR_RAYS, SAMPLES_PER_RAY, N),
+                       "pos_dim": 3, "nr_levels": NR_LEVELS, "capacity": Tcap, "feat_per_level": F, "mlp": "36-64-64-64-1 GELU",
+                       "parallelism": "ray-sharded dp%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "encode_bwd_kernel<3,2,true,false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": ms["enc_bwd"], "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "bounded in practice by the ~21 G/s fp32 global-atomic rate (tools/atomic_bench.hip), not by HBM"},
+            "kernel_ms": {"forward_total": ms["fwd"], "mlp_backward": ms["mlp_bwd"], "encode_backward": ms["enc_bwd"]},
+            "fwd_only_samples_per_s": N / (ms["fwd"] * 1e-3),
+            "mlp_bwd_tflops": flops_mlp_bwd / (ms["mlp_bwd"] * 1e-3) / 1e12,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

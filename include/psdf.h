@@ -1,0 +1,204 @@
+/* psdf.h -- C ABI of libpsdf_hip.so, the MI355X (gfx950) implementation of the PermutoSDF rendering/training hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Each entry point replaces one
+ * operator of the reference's Python-facing API -- the pybind11 module `permuto_sdf` (src/PyBridge.cxx:36-166) and
+ * the external `permutohedral_encoding` package -- and cites the reference interface it stands in for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 / int32 / 1-byte-bool data unless marked "host";
+ *   - the callee never allocates and never synchronises: outputs are caller-allocated (zero-filled where a comment
+ *     says "accumulated into" or where the reference allocates with torch::zeros), launches are asynchronous on `stream`
+ *     (a hipStream_t; pass the framework's current stream, NULL = default stream);
+ *   - return value: 0 = ok, -1 = argument error, -2 = unsupported configuration, > 0 = hipError_t of the launch;
+ *   - ray-index arguments (nr_rays, ray_start_end_idx [R,2] int32, rays_have_equal_nr_of_samples,
+ *     fixed_nr_of_samples_per_ray, max_nr_samples) mirror RaySamplesPacked (include/permuto_sdf/RaySamplesPacked.cuh:6-46);
+ *   - PCG32 generators are passed by value as (state, inc) exactly as the reference passes `pcg32 rng` to its kernels;
+ *     the owner advances its host copy by 2^32 after every jittered call (src/OccupancyGrid.cu:252-254).
+ */
+#ifndef PSDF_H
+#define PSDF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- encode.hip ---- */
+/* replaces: permutohedral_encoding CUDA op `forward_gpu` (un-vendored; call sites permuto_sdf_py/models/models.py:186,370,500,542) */
+int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+    const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
+    float points_scaling, float* sliced, void* stream);
+
+/* replaces: permutohedral_encoding `backward_gpu` / `backward_gpu_only_pos` (autograd of models.py:186; positions grad needed by models.py:240-251) */
+int psdf_encode_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+    const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
+    float points_scaling, const float* grad_sliced, float* grad_lattice, float* grad_positions, void* stream);
+
+/* replaces: permutohedral_encoding `double_backward_from_positions_gpu` (create_graph=True at models.py:245-251) */
+int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float*
+    positions, const float* lattice, const float* scale_factor, const float* shifts, const float* window, int
+    concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced, float* grad_lattice,
+    float* grad_grad_sliced, void* stream);
+
+/* ---- mlp.hip ---- */
+/* replaces: torch.nn.Sequential(Linear,GELU,...) evaluators, permuto_sdf_py/models/models.py:153-161,451-470 */
+int64_t psdf_mlp_packed_size(int n_layers, const int* dims);
+
+/* replaces: same evaluators (parameter re-ordering for the MFMA kernels) */
+int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, const float* const* biases, float*
+    packed, void* stream);
+
+/* replaces: models.py:187 `self.mlp_sdf(point_features)` and :508-517 (cuBLAS + elementwise GELU in the reference) */
+int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y, void*
+    stream);
+
+/* replaces: autograd backward of the same evaluators */
+int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, const float* dY,
+    float* dX, float* const* dW, float* const* db, void* stream);
+
+/* ---- optim.hip ---- */
+/* replaces: torch.optim.AdamW at permuto_sdf_py/train_permuto_sdf.py:293-304,418 */
+int psdf_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float
+    beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- sampling.hip ---- */
+/* replaces: OccupancyGrid::compute_grid_points / compute_random_sample_of_grid_points, src/OccupancyGrid.cu:88-117,179-208 */
+int psdf_grid_points(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const int*
+    voxel_indices, uint64_t rng_state, uint64_t rng_inc, int randomize, float* out_points, void* stream);
+
+/* replaces: OccupancyGrid::update_with_density[_random_sample], src/OccupancyGrid.cu:368-420 */
+int psdf_grid_update_with_density(int count, const int* voxel_indices, const float* density, float decay, float
+    thresh, float* grid_values, uint8_t* grid_occupancy, void* stream);
+
+/* replaces: OccupancyGrid::update_with_sdf[_random_sample], src/OccupancyGrid.cu:422-475 */
+int psdf_grid_update_with_sdf(int count, const int* voxel_indices, const float* sdf, int nr_voxels_per_dim, float
+    extent, const float* grid_translation, float inv_s, const float* inv_s_tensor, int full_update, float thresh,
+    float* grid_values, uint8_t* grid_occupancy, void* stream);
+
+/* replaces: OccupancyGrid::check_occupancy, src/OccupancyGrid.cu:339-365 */
+int psdf_grid_check_occupancy(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const
+    uint8_t* grid_occupancy, const float* points, uint8_t* out, void* stream);
+
+/* replaces: OccupancyGrid::compute_samples_in_occupied_regions (src/OccupancyGrid.cu:212-257) and RaySampler::compute_samples_fg (src/RaySampler.cu:104-152) */
+int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
+    const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs, const float* ray_t_entry, const
+    float* ray_t_exit, float min_dist_between_samples, int max_nr_samples_per_ray, int max_nr_samples, uint64_t
+    rng_state, uint64_t rng_inc, int jitter, float* samples_pos, float* samples_dirs, float* samples_z, float*
+    samples_dt, float* ray_fixed_dt, int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream);
+
+/* replaces: OccupancyGrid::compute_first_sample_start_of_occupied_regions, src/OccupancyGrid.cu:259-300 */
+int psdf_first_hit_samples(int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation, const
+    uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs, const float* ray_t_entry, const float*
+    ray_t_exit, int max_nr_samples, float* samples_pos, float* samples_dirs, float* samples_z, float* samples_dt,
+    float* ray_fixed_dt, int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream);
+
+/* replaces: OccupancyGrid::advance_sample_to_next_occupied_voxel, src/OccupancyGrid.cu:302-337 */
+int psdf_advance_to_next_occupied_voxel(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
+    const uint8_t* grid_occupancy, const float* samples_dirs, float* samples_pos, uint8_t* is_within_bounds, void*
+    stream);
+
+/* replaces: RaySampler::compute_samples_bg, src/RaySampler.cu:37-101 */
+int psdf_samples_bg(int nr_rays, int nr_samples_per_ray, const float* ray_origins, const float* ray_dirs, const float*
+    ray_t_exit, float sphere_radius, const float* sphere_center, uint64_t rng_state, uint64_t rng_inc, int randomize,
+    int contract_3d_samples, float* samples_3d, float* samples_4d, float* samples_dirs, float* samples_z, float*
+    samples_dt, float* ray_fixed_dt, int* ray_start_end_idx, void* stream);
+
+/* replaces: Sphere::ray_intersection, src/Sphere.cu:42-79 */
+int psdf_sphere_ray_intersection(int nr_rays, float radius, const float* center, const float* ray_origins, const
+    float* ray_dirs, float* points_entry, float* t_entry, float* points_exit, float* t_exit, uint8_t* does_intersect,
+    void* stream);
+
+/* replaces: Sphere::rand_points_inside, src/Sphere.cu:82-108 */
+int psdf_sphere_rand_points_inside(int count, float radius, const float* phi, const float* costheta, const float* u,
+    float* points, void* stream);
+
+/* replaces: RaySamplesPacked::compute_exact_nr_samples + compact_to_valid_samples, src/RaySamplesPacked.cu:44-95 */
+int psdf_compact_offsets(int nr_rays, const int* ray_start_end_idx, int* scratch, int* total, void* stream);
+
+/* replaces: RaySamplesPacked::compact_to_valid_samples, src/RaySamplesPacked.cu:57-95 */
+int psdf_compact_copy(int nr_rays, const int* ray_start_end_idx, const int* offsets, const float* pos, const float*
+    pos4, const float* dirs, const float* z, const float* dt, const float* sdf, const float* fixed_dt, float* o_pos,
+    float* o_pos4, float* o_dirs, float* o_z, float* o_dt, float* o_sdf, float* o_fixed_dt, int* o_start_end, void*
+    stream);
+
+/* replaces: RaySamplesPacked::compute_per_sample_ray_idx, src/RaySamplesPacked.cu:124-146 */
+int psdf_per_sample_ray_idx(int nr_rays, int nr_samples, const int* ray_start_end_idx, int* out, void* stream);
+
+/* replaces: PermutoSDF::spherical_harmonics, src/PermutoSDF.cu:167-204 */
+int psdf_spherical_harmonics(int count, int degree, const float* dirs, float* out, void* stream);
+
+/* replaces: PermutoSDF::random_rays_from_reel, src/PermutoSDF.cu:67-112 */
+int psdf_random_rays_from_reel(int nr_rays, int nr_images, int height, int width, const float* rgb_reel, const float*
+    mask_reel, const float* K_reel, const float* tf_world_cam_reel, const int* pixel_indices, const int* img_indices,
+    int has_mask, float* ray_origins, float* ray_dirs, float* gt_rgb, float* gt_mask, void* stream);
+
+/* ---- volume_rendering.hip ---- */
+/* replaces: (helper) replaces the atomicAdd slot counters, e.g. kernels/permuto_sdf/OccupancyGridGPU.cuh:599 */
+int psdf_exclusive_scan_i32(int n, const int* in, int* out, int* total, void* stream);
+
+/* replaces: VolumeRendering::cumprod_alpha2transmittance, src/VolumeRendering.cu:169-201 */
+int psdf_cumprod_alpha2transmittance(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples,
+    const float* alpha, float* transmittance, float* bg_transmittance, void* stream);
+
+/* replaces: VolumeRendering::cumprod_alpha2transmittance_backward, src/VolumeRendering.cu:530-564 */
+int psdf_cumprod_alpha2transmittance_backward(int nr_rays, const int* start_end, int equal, int fixed, int
+    max_nr_samples, const float* grad_bg, const float* alpha, const float* bg, const float* cumsumLV, float*
+    grad_alpha, void* stream);
+
+/* replaces: VolumeRendering::integrate_with_weights, src/VolumeRendering.cu:204-232 */
+int psdf_integrate_with_weights(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const
+    float* rgb, const float* weights, float* pred, void* stream);
+
+/* replaces: VolumeRendering::integrate_with_weights_backward, src/VolumeRendering.cu:567-601 */
+int psdf_integrate_with_weights_backward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples,
+    const float* grad_pred, const float* rgb, const float* weights, float* grad_rgb, float* grad_weights, int
+    reference_compat, void* stream);
+
+/* replaces: VolumeRendering::sum_over_each_ray, src/VolumeRendering.cu:272-344 */
+int psdf_sum_over_each_ray(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, int channels,
+    const float* values, float* sum_per_ray, float* sum_per_sample, void* stream);
+
+/* replaces: VolumeRendering::sum_over_each_ray_backward, src/VolumeRendering.cu:604-668 */
+int psdf_sum_over_each_ray_backward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, int
+    channels, const float* grad_per_ray, const float* grad_per_sample, float* grad_values, void* stream);
+
+/* replaces: VolumeRendering::cumsum_over_each_ray (:346-376) and compute_cdf (:379-408) */
+int psdf_cumsum_over_each_ray(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const
+    float* values, int inverse, int exclusive, float* out, void* stream);
+
+/* replaces: VolumeRendering::sdf2alpha, src/VolumeRendering.cu:234-269 */
+int psdf_sdf2alpha(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float*
+    ray_fixed_dt, const float* samples_dt, const float* sdf, float inv_s, int dynamic_inv_s, float inv_s_multiplier,
+    float* alpha, void* stream);
+
+/* replaces: VolumeRendering::compute_dt, src/VolumeRendering.cu:135-167 */
+int psdf_compute_dt(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float*
+    samples_z, const float* ray_t_exit, int use_ray_t_exit, float* dt, void* stream);
+
+/* replaces: VolumeRendering::volume_render_nerf, src/VolumeRendering.cu:40-83 */
+int psdf_volume_render_nerf(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float*
+    rgb, const float* density, const float* samples_z, const float* samples_dt, float* pred_rgb, float* pred_depth,
+    float* bg_transmittance, float* weight_per_sample, void* stream);
+
+/* replaces: VolumeRendering::volume_render_nerf_backward, src/VolumeRendering.cu:86-132 */
+int psdf_volume_render_nerf_backward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples,
+    const float* grad_pred_rgb, const float* grad_bg_transmittance, const float* pred_rgb, const float*
+    bg_transmittance, const float* rgb, const float* density, const float* samples_dt, float* grad_rgb, float*
+    grad_density, void* stream);
+
+/* replaces: VolumeRendering::importance_sample, src/VolumeRendering.cu:410-461 */
+int psdf_importance_sample(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float*
+    ray_origins, const float* ray_dirs, const float* ray_fixed_dt, const float* samples_z, const float* cdf, int
+    nr_importance_samples, uint64_t rng_state, uint64_t rng_inc, int jitter, float* out_pos, float* out_dirs, float*
+    out_z, void* stream);
+
+/* replaces: VolumeRendering::combine_uniform_samples_with_imp, src/VolumeRendering.cu:464-525 */
+int psdf_combine_uniform_samples_with_imp(int nr_rays, const int* uni_start_end, int uni_equal, int uni_fixed, int
+    uni_max_nr_samples, const float* ray_origins, const float* ray_dirs, const float* ray_t_exit, const float*
+    uni_fixed_dt, const float* uni_z, const float* uni_sdf, int has_sdf, int nr_imp, const float* imp_z, const float*
+    imp_sdf, int out_max_nr_samples, float* out_pos, float* out_dirs, float* out_z, float* out_dt, float* out_sdf,
+    float* out_fixed_dt, int* out_start_end, int* out_cur_nr_samples, int* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSDF_H */

@@ -1,0 +1,68 @@
+// Fused AdamW step over a flat fp32 parameter buffer (one launch per tensor, 16-B vector accesses).
+// The reference optimises 3 x 12.6 M lattice parameters with torch.optim.AdamW(betas=(0.9,0.99), eps=1e-15)
+// (permuto_sdf_py/train_permuto_sdf.py:293-304); this is the same update rule as torch's, streaming
+// 4 arrays once: 28 B/parameter of HBM traffic, pure bandwidth.
+#include "psdf_common.h"
+
+namespace {
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    adamw_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                 float* __restrict__ v, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 float bias_corr1, float bias_corr2_sqrt, float grad_scale) {
+  const int64_t stride = (int64_t)gridDim.x * PSDF_BLOCK * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      float4 P = *reinterpret_cast<float4*>(p + i);
+      const float4 G = *reinterpret_cast<const float4*>(g + i);
+      float4 M = *reinterpret_cast<float4*>(m + i);
+      float4 V = *reinterpret_cast<float4*>(v + i);
+      float* pp = &P.x;
+      const float* gp = &G.x;
+      float* mp = &M.x;
+      float* vp = &V.x;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float gk = gp[k] * grad_scale;
+        pp[k] = pp[k] * (1.f - lr * weight_decay);
+        mp[k] = beta1 * mp[k] + (1.f - beta1) * gk;
+        vp[k] = beta2 * vp[k] + (1.f - beta2) * gk * gk;
+        const float denom = sqrtf(vp[k]) / bias_corr2_sqrt + eps;
+        pp[k] = pp[k] - (lr / bias_corr1) * (mp[k] / denom);
+      }
+      *reinterpret_cast<float4*>(p + i) = P;
+      *reinterpret_cast<float4*>(m + i) = M;
+      *reinterpret_cast<float4*>(v + i) = V;
+    } else {
+      for (int64_t j = i; j < n; j++) {
+        const float gk = g[j] * grad_scale;
+        float pj = p[j] * (1.f - lr * weight_decay);
+        const float mj = beta1 * m[j] + (1.f - beta1) * gk;
+        const float vj = beta2 * v[j] + (1.f - beta2) * gk * gk;
+        const float denom = sqrtf(vj) / bias_corr2_sqrt + eps;
+        pj = pj - (lr / bias_corr1) * (mj / denom);
+        p[j] = pj;
+        m[j] = mj;
+        v[j] = vj;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" {
+// step >= 1.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+int psdf_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  if (n <= 0) return PSDF_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return PSDF_ERR_ARG;
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return PSDF_ERR_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  unsigned blocks = psdf_blocks((n + 3) / 4, PSDF_BLOCK);
+  if (blocks > 4096u) blocks = 4096u;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, n, param, grad, exp_avg,
+                     exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+}

@@ -1,0 +1,100 @@
+"""The data-parallel hot path as ONE object: encode -> fused SDF MLP -> NeuS compositing, forward and backward, over a
+packed batch of ray samples, entirely on the feature-major ([C, N]) fast path of the kernels (no autograd graph,
+no transposes).  It strings together exactly the operators the reference's Python strings together in
+permuto_sdf_py/utils/sdf_utils.py:383-423 (importance sampling: SDF eval -> sdf2alpha -> cumprod -> weights -> sum)
+and permuto_sdf_py/train_permuto_sdf.py:111-169 (run_net: SDF eval -> weights -> integrate), with their backward
+kernels.  bench.py times this object; the drop-in API (permuto_sdf / permutohedral_encoding) exposes the same kernels
+one by one for the reference's unmodified Python.
+"""
+import torch
+
+from . import _lib as L
+from . import parallel
+from .bridge import VolumeRendering as VR
+from .encoding import PermutoEncoding, _head, _tail
+from .mlp import FusedMLP, mlp_backward_raw, mlp_forward_raw, pack_params
+
+
+class SdfHotPath:
+    def __init__(self, nr_levels=16, hidden=64, out_channels=1, capacity=2 ** 18, device="cuda", seed=0, lr=1e-3):
+        import numpy as np
+        torch.manual_seed(seed)
+        self.dev = torch.device(device)
+        self.enc = PermutoEncoding(3, capacity, nr_levels, 2, np.geomspace(1.0, 1e-4, nr_levels),
+                                   appply_random_shift_per_level=True, concat_points=True, concat_points_scaling=1e-3,
+                                   init_scale=1e-2).to(self.dev)
+        C = self.enc.output_dims()
+        self.mlp = FusedMLP([C, hidden, hidden, hidden, out_channels]).to(self.dev)
+        with torch.no_grad():  # sphere-ish start so that alphas are neither all 0 nor all 1
+            self.mlp.layers[-1].bias.fill_(0.05)
+        self.window = torch.ones(nr_levels, device=self.dev)
+        self.params = [self.enc.lattice_values] + [p for l in self.mlp.layers for p in (l.weight, l.bias)]
+        from .optim import FusedAdamW
+        self.opt = FusedAdamW(self.params, lr=lr)
+        self.events = None
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, rs, rgb_samples):
+        """rs: RaySamplesPacked (positions, dt, ray ranges); rgb_samples [M,3].  Returns per-ray radiance [R,3] and the
+        tensors the backward needs."""
+        cfg = self.enc.cfg
+        pos = rs.samples_pos
+        N = pos.shape[0]
+        feat = torch.empty((cfg.channels, N), dtype=torch.float32, device=self.dev)
+        L.call("psdf_encode_forward", *_head(cfg, N), L.ptr(pos), L.ptr(self.enc.lattice_values), L.ptr(self.enc.scale_factor),
+               L.ptr(self.enc.random_shift_per_level), L.ptr(self.window), *_tail(cfg), L.ptr(feat), L.stream())
+        packed = pack_params(self.mlp.dims, [l.weight for l in self.mlp.layers], [l.bias for l in self.mlp.layers])
+        sdf = mlp_forward_raw(self.mlp.dims, feat, packed)                    # [1, N] feature-major == [N,1] memory
+        sdf_col = sdf.view(-1, 1)
+        alpha = VR.sdf2alpha(rs, sdf_col, 512.0, True, 1.0)
+        one_minus = 1.0 - alpha + 1e-7
+        T, bg = VR.cumprod_alpha2transmittance(rs, one_minus)
+        w = alpha * T
+        w_sum, _ = VR.sum_over_each_ray(rs, w)
+        pred = VR.integrate_with_weights(rs, rgb_samples, w)
+        return pred, dict(feat=feat, packed=packed, sdf=sdf, alpha=alpha, one_minus=one_minus, T=T, bg=bg, w=w, w_sum=w_sum)
+
+    # ------------------------------------------------------------------ backward (+ optional all-reduce and optimiser)
+    def backward(self, rs, rgb_samples, saved, grad_pred, grad_sdf=None, reduce=True, optimizer_step=True):
+        """Backward through integrate -> weights -> transmittance (the reference's native backward kernels), then the
+        fused MLP and the encoding.  The reference has no native sdf->alpha backward (its training path computes alpha
+        with torch elementwise ops); `grad_sdf` is therefore an input (default: ones), as in SURVEY.md section 8d cfg 2."""
+        cfg = self.enc.cfg
+        N = rs.samples_pos.shape[0]
+        g_rgb, g_w = VR.integrate_with_weights_backward(grad_pred, rs, rgb_samples, saved["w"], None)
+        g_T = g_w * saved["alpha"]
+        cs = VR.cumsum_over_each_ray(rs, g_T * saved["T"], True)
+        g_om = VR.cumprod_alpha2transmittance_backward(g_T, torch.zeros_like(saved["bg"]), rs, saved["one_minus"], saved["T"],
+                                                       saved["bg"], cs)
+        if grad_sdf is None:
+            grad_sdf = torch.ones((1, N), dtype=torch.float32, device=self.dev)
+        if self.events is not None:
+            self.events["mlp_bwd"][0].record()
+        d_feat, dWs, dbs = mlp_backward_raw(self.mlp.dims, saved["feat"], saved["packed"], grad_sdf, need_dx=True)
+        if self.events is not None:
+            self.events["mlp_bwd"][1].record()
+        buckets = parallel.GradientBuckets()
+        if reduce:
+            buckets.reduce(dWs + dbs)          # small bucket first: overlaps the encoding backward
+        g_lat = torch.zeros_like(self.enc.lattice_values)
+        if self.events is not None:
+            self.events["enc_bwd"][0].record()
+        L.call("psdf_encode_backward", *_head(cfg, N), L.ptr(rs.samples_pos), L.ptr(self.enc.lattice_values),
+               L.ptr(self.enc.scale_factor), L.ptr(self.enc.random_shift_per_level), L.ptr(self.window), *_tail(cfg),
+               L.ptr(d_feat), L.ptr(g_lat), None, L.stream())
+        if self.events is not None:
+            self.events["enc_bwd"][1].record()
+        if reduce:
+            buckets.reduce([g_lat])
+            buckets.finish()
+        grads = [g_lat] + [t for pair in zip(dWs, dbs) for t in pair]
+        if optimizer_step:
+            for p, g in zip(self.params, grads):
+                p.grad = g
+            self.opt.step(grad_scale=1.0 / parallel.world_size())
+        return dict(g_rgb=g_rgb, g_one_minus=g_om, grads=grads)
+
+    def step(self, rs, rgb_samples, grad_pred, **kw):
+        pred, saved = self.forward(rs, rgb_samples)
+        out = self.backward(rs, rgb_samples, saved, grad_pred, **kw)
+        return pred, saved, out

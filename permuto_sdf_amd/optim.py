@@ -1,0 +1,30 @@
+"""Fused AdamW over flat fp32 tensors (csrc/optim.hip).  Same update rule as torch.optim.AdamW, which the reference
+uses with betas=(0.9, 0.99), eps=1e-15 (permuto_sdf_py/train_permuto_sdf.py:293-304)."""
+import torch
+
+from . import _lib as L
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise L.PsdfError("FusedAdamW handles contiguous fp32 parameters only")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                L.call("psdf_adamw_step", L.c_l(p.numel()), L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                       L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]), L.c_f(group["weight_decay"]),
+                       L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())

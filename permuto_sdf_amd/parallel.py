@@ -1,0 +1,98 @@
+"""Ray-sharded data parallelism for the hot path: one process per GPU, torch.distributed (backend "nccl" == RCCL on
+ROCm, over xGMI).  The reference has no multi-GPU code at all; rays are independent units of
+work, so each rank renders / trains on its own ray batch against REPLICATED parameters and a replicated occupancy
+grid, and the only exchange is one sum all-reduce of the gradients per step.
+
+Gradients are reduced in buckets that are launched as soon as they are final, so the reduction of bucket k overlaps
+the backward kernels that produce bucket k+1: the small MLP gradients go first (they are ready before the encoding
+backward starts), then one bucket per lattice (50 MB each at L=24).  MI355X nodes are fully connected by 7 xGMI links
+per GPU; RCCL picks the algorithm, large fp32 buckets keep every link busy.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the launcher's environment; returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_rays(nr_rays_global, rank, world):
+    """Contiguous [start, end) slice of a global ray batch owned by `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(nr_rays_global, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def rank_seed(base_seed, rank):
+    """Distinct ray-selection stream per rank; the occupancy-grid update uses `base_seed` on every rank so that the
+    replicated grids stay bit-identical without communication (hard part 7)."""
+    return int(base_seed) * 1000003 + int(rank) + 1
+
+
+class GradientBuckets:
+    """Async sum all-reduce of gradient tensors, bucket by bucket; `finish()` waits for all of them."""
+
+    def __init__(self):
+        self.pending = []
+
+    def reduce(self, tensors):
+        """Launch the reduction of one bucket (a list of gradient tensors that are final).  No-op on one rank."""
+        if world_size() == 1:
+            return
+        tensors = [t for t in tensors if t is not None]
+        if not tensors:
+            return
+        if len(tensors) == 1:
+            self.pending.append((dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, async_op=True), None, None))
+            return
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        self.pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, tensors))
+
+    def finish(self):
+        for work, flat, tensors in self.pending:
+            work.wait()
+            if flat is not None:
+                off = 0
+                for t in tensors:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t))
+                    off += n
+        self.pending = []
+
+
+def allreduce_module_grads(modules, buckets=None):
+    """Convenience for autograd-driven training loops: reduce `.grad` of every parameter of `modules`, lattices as
+    their own buckets, everything else in one small bucket."""
+    own = buckets is None
+    buckets = buckets or GradientBuckets()
+    small = []
+    for m in modules:
+        for name, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            if "lattice_values" in name:
+                buckets.reduce([p.grad])
+            else:
+                small.append(p.grad)
+    buckets.reduce(small)
+    if own:
+        buckets.finish()
+    return buckets
