@@ -67,7 +67,7 @@ def cpu_baseline(cores):
     from oracle import oracle as O
     from oracle import permuto_oracle as po
     torch.set_num_threads(cores)
-    rays, per_ray = 1024, SAMPLES_PER_RAY
+    rays, per_ray = 256, SAMPLES_PER_RAY
     N = rays * per_ray
     g = torch.Generator().manual_seed(1)
     pos = torch.randn(N, 3, generator=g)
@@ -119,6 +119,9 @@ def cpu_baseline(cores):
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-child":
+        print(json.dumps(cpu_baseline(int(sys.argv[2]))), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -205,10 +208,17 @@ def main():
             "mlp_bwd_tflops": flops_mlp_bwd / (ms["mlp_bwd"] * 1e-3) / 1e12,
         }
         if not args.no_cpu_baseline and world == 1:
+            # The vectorised torch-CPU restatement gets SLOWER beyond ~8 threads on the 256-core host (measured:
+            # 8 thr 0.7 s, 32 thr 1.1 s, 64 thr 2.2 s per 32k samples), so the baseline uses 8 threads and says so.
+            # It runs in a child process under a hard timeout: the baseline must never take the GPU number down.
+            import subprocess
+            cores = min(8, os.cpu_count() or 1)
             try:
-                out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(cores)],
+                                   capture_output=True, text=True, timeout=150)
+                out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     if world > 1:
