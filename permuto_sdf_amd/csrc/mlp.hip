@@ -672,8 +672,8 @@ int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, c
   MlpPlan p;
   int rc = make_plan(n_layers, dims, p);
   if (rc != PSDF_OK) return rc;
-  if (N < 0 || !X || !packed || !Y) return PSDF_ERR_ARG;
   if (N == 0) return PSDF_OK;
+  if (N < 0 || !X || !packed || !Y) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0, to = p.tiles[n_layers];
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;

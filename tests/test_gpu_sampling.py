@@ -277,3 +277,63 @@ def test_random_rays_from_reel(port, dev):
         bits_equal(gm, rgm)
         assert np.abs(d.cpu().numpy() - rd).max() < 1e-6       # normalisation through the device rsqrt
         assert np.abs(d.norm(dim=1).cpu().numpy() - 1).max() < 1e-6
+
+
+def test_against_committed_golden_vectors(dev):
+    """HIP path vs tests/golden/ref_vectors.npz (outputs of the REFERENCE's own kernels, generated by
+    tests/golden/make_golden.py where /root/reference exists).  Inputs are regenerated from the same seeds."""
+    import os
+    from permuto_sdf import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRendering as VR
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz"))
+    port = O.Oracle("port")
+    n = 32
+    occ = scene.shell_occupancy(port, n, seed=11)
+    o, d = scene.make_rays(160, seed=21)
+    to, td = T(o, dev), T(d, dev)
+    p0, te, p1, tx, hit = Sphere(0.5, [0, 0, 0]).ray_intersection(to, td)
+    for t, k in ((p0, "sph_p0"), (te, "sph_t0"), (p1, "sph_p1"), (tx, "sph_t1"), (hit, "sph_hit")):
+        bits_equal(t, gold[k])
+    g = OccupancyGrid(n, 1.0, [0, 0, 0])
+    g.set_grid_occupancy(T(occ, dev))
+    from permuto_sdf_amd.bridge import Pcg32
+    for jit in (False, True):
+        OccupancyGrid._rng = Pcg32()
+        c = g.compute_samples_in_occupied_regions(to, td, te, tx, 2e-3, 48, jit).compact_to_valid_samples()
+        k = "march%d_" % jit
+        bits_equal(c.ray_start_end_idx, gold[k + "se"])
+        nn = gold[k + "se"][:, 1].max()
+        bits_equal(c.samples_z, gold[k + "z"][:nn])
+        bits_equal(c.samples_pos, gold[k + "pos"][:nn])
+        bits_equal(c.samples_dt, gold[k + "dt"][:nn])
+        bits_equal(c.ray_fixed_dt, gold[k + "fdt"])
+    RaySampler._rng = Pcg32()
+    bg = RaySampler.compute_samples_bg(to, td, tx, 16, 0.5, [0, 0, 0], True, True)
+    bits_equal(bg.samples_z, gold["bg_z"])
+    bits_equal(bg.samples_pos, gold["bg_p3"])
+    assert np.abs(bg.samples_pos_4d.cpu().numpy() - gold["bg_p4"]).max() < 1e-6
+    bits_equal(PermutoSDF.spherical_harmonics(td, 5), gold["sh5"])
+    bits_equal(PermutoSDF.spherical_harmonics(td, 7), gold["sh7"])
+    pts = np.random.default_rng(31)
+    fh = g.compute_first_sample_start_of_occupied_regions(to, td, te, tx).compact_to_valid_samples()
+    bits_equal(fh.ray_start_end_idx, gold["fh_se"])
+    bits_equal(fh.samples_z, gold["fh_z"][:gold["fh_se"][:, 1].max()])
+    # compositing: rebuild the packed samples and the random tensors exactly as tests/golden/cases.py does
+    OccupancyGrid._rng = Pcg32()
+    c = g.compute_samples_in_occupied_regions(to, td, te, tx, 2e-3, 48, False).compact_to_valid_samples()
+    M = c.samples_pos.shape[0]
+    rng = np.random.default_rng(31)
+    for _ in range(1):   # replay the generator draws of cases.run_all up to the compositing block
+        rng.uniform(0, 2, n ** 3); rng.uniform(size=n ** 3); rng.normal(0, 0.05, n ** 3); rng.integers(0, n ** 3, 500)
+        rng.uniform(-0.499, 0.499, (500, 3))
+    rgb = rng.uniform(size=(M, 3)).astype(np.float32)
+    sigma = rng.uniform(0, 60, (M, 1)).astype(np.float32)
+    sdf = (scene.analytic_sdf(c.samples_pos.cpu().numpy()) + rng.normal(0, 2e-3, (M, 1))).astype(np.float32)
+    pred, depth, bgT, w = VR.volume_render_nerf(c, T(rgb, dev), T(sigma, dev), tx, False)
+    assert np.abs(pred.cpu().numpy() - gold["nerf_pred"]).max() < 2e-5
+    assert np.abs(bgT.cpu().numpy() - gold["nerf_bg"]).max() < 2e-5
+    alpha = VR.sdf2alpha(c, T(sdf, dev), 512.0, True, 1.0)
+    assert np.abs(alpha.cpu().numpy() - gold["alpha"]).max() < 2e-6
+    om = 1 - alpha.clamp(0, 1) + 1e-7
+    Tr, bg2 = VR.cumprod_alpha2transmittance(c, om)
+    assert np.abs(Tr.cpu().numpy() - gold["T"]).max() < 2e-6
+    assert np.abs(VR.integrate_with_weights(c, T(rgb, dev), alpha.clamp(0, 1) * Tr).cpu().numpy() - gold["integ"]).max() < 2e-5
