@@ -33,6 +33,14 @@ int psdf_encode_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int
     const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
     float points_scaling, const float* grad_sliced, float* grad_lattice, float* grad_positions, void* stream);
 
+/* same operator with caller-provided device scratch: enables the binned queue + LDS-reduction lattice-gradient path
+   for large batches (psdf_encode_backward_workspace_bytes() == 0 means "not applicable", pass NULL) */
+int64_t psdf_encode_backward_workspace_bytes(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity);
+int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+    const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
+    float points_scaling, const float* grad_sliced, float* grad_lattice, float* grad_positions, void* workspace,
+    int64_t workspace_bytes, void* stream);
+
 /* replaces: permutohedral_encoding `double_backward_from_positions_gpu` (create_graph=True at models.py:245-251) */
 int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float*
     positions, const float* lattice, const float* scale_factor, const float* shifts, const float* window, int

@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // points of one level, and flushes with one global atomic per live entry at the end.  A row whose slot is
 // taken by another row bypasses the cache (plain global atomic), so the structure is exact for any
 // distribution; a workgroup whose hit rate is poor after its first tiles (fine, fully hashed levels)
-// switches the cache off for the rest of its walk.
+// switches the cache off for the rest of its walk (vote after its first tile: share of contributions that hit an
+// entry which already existed).
 constexpr uint32_t SC_EMPTY = 0xFFFFFFFFu;
 
 template <int F>
@@ -200,17 +201,18 @@ struct ScatterCache {
     }
     __syncthreads();
   }
-  // returns true when the contribution was absorbed by the cache
-  __device__ __forceinline__ bool add(uint32_t row, const float* v) {
+  // 0: slot taken by another row (caller adds to HBM / queues); 1: absorbed, claimed an empty slot;
+  // 2: absorbed into an entry that already existed (a genuine re-use: what the adaptive vote counts)
+  __device__ __forceinline__ int add(uint32_t row, const float* v) {
     const uint32_t slot = (row ^ (row >> 12)) & (SC_SLOTS - 1);
     uint32_t old = tags[slot];
     if (old == SC_EMPTY) old = atomicCAS(&tags[slot], SC_EMPTY, row);
     if (old == SC_EMPTY || old == row) {
 #pragma unroll
       for (int f = 0; f < F; f++) atomicAdd(&sums[slot * F + f], v[f]);
-      return true;
+      return old == row ? 2 : 1;
     }
-    return false;
+    return 0;
   }
   __device__ __forceinline__ void flush(float* __restrict__ table_grad) {
     __syncthreads();
@@ -234,7 +236,7 @@ struct ScatterCache {
 // Launch: grid (B, Lt), workgroup b of level l walks point tiles b, b+B, ...
 template <int F>
 __device__ __forceinline__ bool cache_vote(ScatterCache<F>& sc, int hits, int tries) {
-  // called by every thread of the workgroup after its second tile; returns the workgroup-uniform decision
+  // called by every thread of the workgroup after its first tile; returns the workgroup-uniform decision
   hits = (int)psdf::wave_sum((float)hits);
   tries = (int)psdf::wave_sum((float)tries);
   if (psdf::lane_id() == 0) {
@@ -242,16 +244,91 @@ __device__ __forceinline__ bool cache_vote(ScatterCache<F>& sc, int hits, int tr
     atomicAdd(&sc.stats[1], tries);
   }
   __syncthreads();
-  return sc.stats[0] * 2 >= sc.stats[1];
+  return sc.stats[0] * 8 >= sc.stats[1];  // keep the cache when >= 1/8 of the first tile hit an existing entry
 }
 
-template <int P, int F, bool LATTICE, bool POS>
+// Binned hand-off to the LDS reduction (large batches, fully hashed levels).  fp32 global atomics are capped at
+// ~21 G/s on this chip whatever the placement (tools/atomic_bench.hip) while LDS atomics sustain >= 185 G/s, so
+// the contributions of a workgroup that is NOT served by its scatter cache are appended to per-(level, partition)
+// queues instead of being added to HBM one atomic at a time: partition p owns table rows [p*RPP, (p+1)*RPP),
+// RPP*F floats = 128 KiB = one workgroup's LDS.  Slots are reserved per tile with LDS counters and ONE global
+// atomic per (tile, partition); encode_bwd_reduce_kernel then folds every queue into LDS and adds the slice to
+// the gradient with plain stores.  A queue that is full falls back to the global atomic (exact either way).
+struct Queues {
+  uint16_t* rows;  // [L, NP, cap]      row index inside the partition
+  float* vals;     // [L, NP, cap, F]
+  int* tails;      // [L, NP]           zeroed per call
+  int cap, np, shift;  // rows per partition = 1 << shift
+};
+constexpr int Q_MAX_PARTS = 64;
+
+// Workgroup-collective append of up to NC contributions per thread to the level's partition queues.
+// Slots are reserved with an LDS counter per partition and ONE global atomic per (call, partition).
+template <int NC, int F>
+__device__ __forceinline__ void queue_push(const Queues& Q, int level, int* q_cnt, int* q_base, const bool (&pending)[NC],
+                                           const uint32_t (&crow)[NC], const float (&cval)[NC][F],
+                                           float* __restrict__ table_grad) {
+  if (threadIdx.x < Q.np) q_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int slot[NC];
+#pragma unroll
+  for (int r = 0; r < NC; r++)
+    if (pending[r]) slot[r] = atomicAdd(&q_cnt[crow[r] >> Q.shift], 1);
+  __syncthreads();
+  if (threadIdx.x < Q.np) {
+    const int c = q_cnt[threadIdx.x];
+    q_base[threadIdx.x] = c ? atomicAdd(&Q.tails[level * Q.np + threadIdx.x], c) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NC; r++) {
+    if (!pending[r]) continue;
+    const int part = crow[r] >> Q.shift;
+    const int idx = q_base[part] + slot[r];
+    if (idx < Q.cap) {
+      const int64_t o = ((int64_t)level * Q.np + part) * Q.cap + idx;
+      Q.rows[o] = (uint16_t)(crow[r] - ((uint32_t)part << Q.shift));
+      if (F == 2) {
+        *reinterpret_cast<float2*>(Q.vals + o * 2) = make_float2(cval[r][0], cval[r][F - 1]);
+      } else {
+#pragma unroll
+        for (int f = 0; f < F; f++) Q.vals[o * F + f] = cval[r][f];
+      }
+    } else {  // queue full: exact fallback
+#pragma unroll
+      for (int f = 0; f < F; f++) atomicAdd(table_grad + (int64_t)crow[r] * F + f, cval[r][f]);
+    }
+  }
+}
+
+// The scatter cache was switched off: hand its live entries to the queues too (instead of flushing them with one
+// global atomic each at the end) and empty it.
+template <int F>
+__device__ __forceinline__ void cache_drain_to_queue(ScatterCache<F>& sc, const Queues& Q, int level, int* q_cnt,
+                                                     int* q_base, float* __restrict__ table_grad) {
+  for (int base = 0; base < ScatterCache<F>::SC_SLOTS; base += PSDF_BLOCK) {
+    const int i = base + threadIdx.x;
+    bool pending[1];
+    uint32_t crow[1];
+    float cval[1][F];
+    const uint32_t tag = sc.tags[i];
+    pending[0] = tag != SC_EMPTY;
+    crow[0] = pending[0] ? tag : 0u;
+#pragma unroll
+    for (int f = 0; f < F; f++) cval[0][f] = sc.sums[i * F + f];
+    queue_push<1, F>(Q, level, q_cnt, q_base, pending, crow, cval, table_grad);
+    sc.tags[i] = SC_EMPTY;
+  }
+  __syncthreads();
+}
+
+template <int P, int F, bool LATTICE, bool POS, bool QUEUE>
 __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_bwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                       const float* __restrict__ grad_sliced, float* __restrict__ grad_lattice,
-                      float* __restrict__ grad_positions) {
+                      float* __restrict__ grad_positions, Queues Q) {
   extern __shared__ __align__(16) float lds[];
   const int level = blockIdx.y;
   const int64_t ntiles = (N + PSDF_BLOCK - 1) / PSDF_BLOCK;
@@ -273,6 +350,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
   ScatterCache<F> sc;
   if (LATTICE) sc.init(lds);
+  int* q_cnt = reinterpret_cast<int*>(lds + ScatterCache<F>::bytes() / 4);  // [Q_MAX_PARTS]
+  int* q_base = q_cnt + Q_MAX_PARTS;                                          // [Q_MAX_PARTS]
   bool use_cache = LATTICE;
   int hits = 0, tries = 0, iter = 0;
   const float w = window[level];
@@ -283,70 +362,155 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     sfl[i] = scale_factor[level * P + i];
     shl[i] = shifts[level * P + i];
   }
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, iter++) {
-    const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
-    if (n < N) {
-      float g[F];
+  // In queue mode a thread handles SPT points per tile, so that one round of slot reservation (3 barriers and a
+  // returning global atomic per partition) is amortised over SPT*256 points.
+  constexpr int SPT = QUEUE ? 4 : 1;
+  constexpr int NC = SPT * (P + 1);
+  const int64_t ntiles_w = (N + (int64_t)PSDF_BLOCK * SPT - 1) / ((int64_t)PSDF_BLOCK * SPT);
+  for (int64_t tile = blockIdx.x; tile < ntiles_w; tile += gridDim.x, iter++) {
+    uint32_t crow[NC];
+    float cval[NC][F];
+    bool pending[NC];
 #pragma unroll
-      for (int f = 0; f < F; f++) g[f] = grad_sliced[((int64_t)level * F + f) * N + n];
-      float pos[P];
-      load_pos<P>(positions, n, pos);
-      Simplex<P> s;
-      compute_simplex<P>(pos, shl, sfl, s);
-      float dbary[P + 2];
+    for (int c = 0; c < NC; c++) pending[c] = false;
 #pragma unroll
-      for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
+    for (int sp = 0; sp < SPT; sp++) {
+      const int64_t n = (tile * SPT + sp) * PSDF_BLOCK + threadIdx.x;
+      if (n < N) {
+        float g[F];
 #pragma unroll
-      for (int r = 0; r <= P; r++) {
-        const uint32_t row = vertex_row<P>(s, r, capacity);
-        if (LATTICE) {
-          const float bw = s.bary[r] * w;
-          float v[F];
+        for (int f = 0; f < F; f++) g[f] = grad_sliced[((int64_t)level * F + f) * N + n];
+        float pos[P];
+        load_pos<P>(positions, n, pos);
+        Simplex<P> s;
+        compute_simplex<P>(pos, shl, sfl, s);
+        float dbary[P + 2];
 #pragma unroll
-          for (int f = 0; f < F; f++) v[f] = g[f] * bw;
-          bool absorbed = false;
-          if (use_cache) {
-            absorbed = sc.add(row, v);
-            hits += absorbed;
-            tries++;
+        for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r <= P; r++) {
+          const uint32_t row = vertex_row<P>(s, r, capacity);
+          if (LATTICE) {
+            const int c = sp * (P + 1) + r;
+            const float bw = s.bary[r] * w;
+            crow[c] = row;
+#pragma unroll
+            for (int f = 0; f < F; f++) cval[c][f] = g[f] * bw;
+            bool absorbed = false;
+            if (use_cache) {
+              const int rc = sc.add(row, cval[c]);
+              absorbed = rc != 0;
+              hits += (rc == 2);
+              tries++;
+            }
+            pending[c] = !absorbed;
           }
-          if (!absorbed) {
+          if (POS) {
 #pragma unroll
-            for (int f = 0; f < F; f++) atomicAdd(grad_lattice + tbase + (int64_t)row * F + f, v[f]);
+            for (int f = 0; f < F; f++) dbary[r] = dbary[r] + lattice[tbase + (int64_t)row * F + f] * w * g[f];
           }
         }
         if (POS) {
+          dbary[P + 1] = dbary[P + 1] + dbary[0];  // adjoint of bary[0] += 1 + bary[P+1]
+          float dE[P + 1];
+          const float invp = 1.0f / (P + 1);
 #pragma unroll
-          for (int f = 0; f < F; f++) dbary[r] = dbary[r] + lattice[tbase + (int64_t)row * F + f] * w * g[f];
-        }
-      }
-      if (POS) {
-        dbary[P + 1] = dbary[P + 1] + dbary[0];  // adjoint of bary[0] += 1 + bary[P+1]
-        float dE[P + 1];
-        const float invp = 1.0f / (P + 1);
+          for (int i = 0; i <= P; i++) {
+            float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int i = 0; i <= P; i++) {
-          float a = 0.f, b = 0.f;
-#pragma unroll
-          for (int k = 0; k <= P + 1; k++) {
-            if (k == P - s.rank[i]) a = dbary[k];
-            if (k == P + 1 - s.rank[i]) b = dbary[k];
+            for (int k = 0; k <= P + 1; k++) {
+              if (k == P - s.rank[i]) a = dbary[k];
+              if (k == P + 1 - s.rank[i]) b = dbary[k];
+            }
+            dE[i] = (a - b) * invp;
           }
-          dE[i] = (a - b) * invp;
-        }
 #pragma unroll
-        for (int i = 0; i < P; i++) {
-          float acc = 0.f;
+          for (int i = 0; i < P; i++) {
+            float acc = 0.f;
 #pragma unroll
-          for (int j = 0; j <= i; j++) acc = acc + dE[j];
-          acc = acc - dE[i + 1] * (float)(i + 1);
-          atomicAdd(grad_positions + n * P + i, acc * sfl[i]);
+            for (int j = 0; j <= i; j++) acc = acc + dE[j];
+            acc = acc - dE[i + 1] * (float)(i + 1);
+            atomicAdd(grad_positions + n * P + i, acc * sfl[i]);
+          }
         }
       }
     }
-    if (LATTICE && iter == 1) use_cache = cache_vote<F>(sc, hits, tries);
+    if (LATTICE) {
+      if (QUEUE) {
+        // everything the cache did not absorb goes to the queues (also while the cache is on: rays are spatially
+        // coherent, so a mid level can re-use entries AND overflow the 4096 slots)
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NC; c++) any |= pending[c];
+        if (__syncthreads_or(any))
+          queue_push<NC, F>(Q, level, q_cnt, q_base, pending, crow, cval, grad_lattice + tbase);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+          if (pending[c]) {
+#pragma unroll
+            for (int f = 0; f < F; f++) atomicAdd(grad_lattice + tbase + (int64_t)crow[c] * F + f, cval[c][f]);
+          }
+      }
+    }
+    if (LATTICE && iter == 0) {
+      use_cache = cache_vote<F>(sc, hits, tries);  // re-use rate of the first tile
+      if (QUEUE && !use_cache) cache_drain_to_queue<F>(sc, Q, level, q_cnt, q_base, grad_lattice + tbase);
+    }
   }
   if (LATTICE) sc.flush(grad_lattice + tbase);
+}
+
+// One workgroup per (partition, level): fold the queue into an LDS image of the partition's table slice with LDS
+// atomics, then add the slice to the gradient table (plain read-modify-write: this workgroup is the only writer of
+// these rows after the binning kernel has finished).
+template <int F>
+__global__ void __launch_bounds__(1024)
+    encode_bwd_reduce_kernel(uint32_t capacity, Queues Q, float* __restrict__ grad_lattice) {
+  extern __shared__ __align__(16) float tab[];
+  const int part = blockIdx.x, level = blockIdx.y;
+  int n = Q.tails[level * Q.np + part];
+  if (n == 0) return;
+  if (n > Q.cap) n = Q.cap;
+  const int rpp = 1 << Q.shift;
+  for (int i = threadIdx.x; i < rpp * F; i += blockDim.x) tab[i] = 0.f;
+  __syncthreads();
+  const int64_t qb = ((int64_t)level * Q.np + part) * Q.cap;
+  const uint16_t* __restrict__ rows = Q.rows + qb;
+  const float* __restrict__ vals = Q.vals + qb * F;
+  constexpr int U = 8;  // queue entries in flight per thread (the loop is HBM-latency bound otherwise)
+  for (int base = 0; base < n; base += U * (int)blockDim.x) {
+    int row[U];
+    float v[U][F];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+      row[u] = (i < n) ? (int)rows[i] : -1;
+      if (F == 2) {
+        const float2 t = (i < n) ? *reinterpret_cast<const float2*>(vals + (int64_t)i * 2) : make_float2(0.f, 0.f);
+        v[u][0] = t.x;
+        v[u][F - 1] = t.y;
+      } else {
+#pragma unroll
+        for (int f = 0; f < F; f++) v[u][f] = (i < n) ? vals[(int64_t)i * F + f] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+      if (row[u] >= 0) {
+#pragma unroll
+        for (int f = 0; f < F; f++) atomicAdd(&tab[f * rpp + row[u]], v[u][f]);  // feature-planar LDS image
+      }
+  }
+  __syncthreads();
+  const int64_t row0 = (int64_t)part << Q.shift;
+  int64_t nrows = (int64_t)capacity - row0;
+  if (nrows > rpp) nrows = rpp;
+  float* __restrict__ out = grad_lattice + ((int64_t)level * capacity + row0) * F;
+  for (int64_t i = threadIdx.x; i < nrows * F; i += blockDim.x) {
+    const float v = tab[(i % F) * rpp + (i / F)];
+    if (v != 0.f) out[i] = out[i] + v;
+  }
 }
 
 // ---------------------------------------------------------------------------------- double backward
@@ -447,8 +611,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
           for (int f = 0; f < F; f++) v[f] = qw * g[f];
           bool absorbed = false;
           if (use_cache) {
-            absorbed = sc.add(row, v);
-            hits += absorbed;
+            const int rc = sc.add(row, v);
+            absorbed = rc != 0;
+            hits += (rc == 2);
             tries++;
           }
           if (!absorbed) {
@@ -462,7 +627,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 #pragma unroll
       for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = gg[f];
     }
-    if (LATTICE && iter == 1) use_cache = cache_vote<F>(sc, hits, tries);
+    if (LATTICE && iter == 0) use_cache = cache_vote<F>(sc, hits, tries);  // re-use rate of the first tile
   }
   if (LATTICE) sc.flush(grad_lattice + tbase);
 }
@@ -500,31 +665,90 @@ int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int 
   return PSDF_OK;
 }
 
+// Workspace for the binned (queue + LDS reduction) lattice-gradient path; 0 = the path does not apply (small batch,
+// table too large for 64 partitions) and psdf_encode_backward_ws behaves exactly like psdf_encode_backward.
+static bool queue_plan(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, Queues& Q, int64_t& bytes) {
+  bytes = 0;
+  if (N < (int64_t)1 << 18) return false;  // below ~260k points the plain path is launch-bound anyway
+  const int shift = (nr_feat <= 2) ? 14 : (nr_feat <= 4 ? 13 : 12);   // rows/partition * F * 4 B <= 128 KiB
+  const int rpp = 1 << shift;
+  const int np = (capacity + rpp - 1) / rpp;
+  if (np > Q_MAX_PARTS || rpp * nr_feat * 4 > 128 * 1024) return false;
+  const int64_t contrib = (int64_t)(pos_dim + 1) * N;
+  const int64_t cap = (contrib / np) + (contrib / np) / 4 + 4096;
+  if (cap > 0x7fffffff) return false;
+  Q.cap = (int)cap;
+  Q.np = np;
+  Q.shift = shift;
+  const int64_t entries = (int64_t)nr_levels * np * cap;
+  const int64_t rows_b = (entries * 2 + 255) & ~(int64_t)255, vals_b = (entries * nr_feat * 4 + 255) & ~(int64_t)255;
+  bytes = rows_b + vals_b + (((int64_t)nr_levels * np * 4 + 255) & ~(int64_t)255);
+  return true;
+}
+static void queue_carve(void* ws, int nr_feat, int nr_levels, Queues& Q) {
+  const int64_t entries = (int64_t)nr_levels * Q.np * Q.cap;
+  const int64_t rows_b = (entries * 2 + 255) & ~(int64_t)255, vals_b = (entries * nr_feat * 4 + 255) & ~(int64_t)255;
+  char* p = (char*)ws;
+  Q.rows = (uint16_t*)p;
+  Q.vals = (float*)(p + rows_b);
+  Q.tails = (int*)(p + rows_b + vals_b);
+}
+
+int64_t psdf_encode_backward_workspace_bytes(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity) {
+  Queues Q{};
+  int64_t bytes = 0;
+  queue_plan(pos_dim, nr_feat, N, nr_levels, capacity, Q, bytes);
+  return bytes;
+}
+
 // grad_lattice / grad_positions must be zero-initialised by the caller (or hold a running sum to add to);
-// either may be NULL to skip that gradient.
-int psdf_encode_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
-                         const float* lattice, const float* scale_factor, const float* shifts, const float* window,
-                         int concat_points, float points_scaling, const float* grad_sliced, float* grad_lattice,
-                         float* grad_positions, void* stream) {
+// either may be NULL to skip that gradient.  workspace: device scratch of at least
+// psdf_encode_backward_workspace_bytes() bytes (contents undefined on entry and exit) or NULL.
+int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+                            const float* lattice, const float* scale_factor, const float* shifts, const float* window,
+                            int concat_points, float points_scaling, const float* grad_sliced, float* grad_lattice,
+                            float* grad_positions, void* workspace, int64_t workspace_bytes, void* stream) {
   if (N == 0 || (!grad_lattice && !grad_positions)) return PSDF_OK;
   if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !grad_sliced) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + ((grad_positions != nullptr) ? extra_levels(pos_dim, nr_feat, concat_points) : 0);
   const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
   dim3 grid(nb < 512u ? nb : 512u, Lt);
-#define BWD(P_, F_, A_, B_)                                                                                     \
-  hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, A_, B_>), grid, dim3(PSDF_BLOCK),                                \
-                     (A_) ? ScatterCache<F_>::bytes() : 0, st, N, nr_levels, (uint32_t)capacity, positions,      \
-                     lattice, scale_factor, shifts, window, points_scaling, grad_sliced, grad_lattice,           \
-                     grad_positions)
-#define BWD_PF(P_, F_)                  \
-  do {                                  \
-    if (grad_lattice && grad_positions) \
-      BWD(P_, F_, true, true);          \
-    else if (grad_lattice)              \
-      BWD(P_, F_, true, false);         \
-    else                                \
-      BWD(P_, F_, false, true);         \
+  Queues Q{};
+  int64_t need = 0;
+  const bool use_queue = grad_lattice && workspace && queue_plan(pos_dim, nr_feat, N, nr_levels, capacity, Q, need) &&
+                         workspace_bytes >= need;
+  if (use_queue) {
+    grid.x = 128;  // each workgroup walks >= 16 super-tiles of 1024 points: the warm-up tile is a small share
+    queue_carve(workspace, nr_feat, nr_levels, Q);
+    hipError_t e = hipMemsetAsync(Q.tails, 0, (size_t)nr_levels * Q.np * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+  }
+#define BWD(P_, F_, A_, B_, Q_)                                                                                  \
+  hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, A_, B_, Q_>), grid, dim3(PSDF_BLOCK),                             \
+                     (A_) ? ScatterCache<F_>::bytes() + 2 * Q_MAX_PARTS * sizeof(int) : 0, st, N, nr_levels,      \
+                     (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling,        \
+                     grad_sliced, grad_lattice, grad_positions, Q)
+#define BWD_PF(P_, F_)                                                                                           \
+  do {                                                                                                           \
+    if (use_queue && grad_positions)                                                                             \
+      BWD(P_, F_, true, true, true);                                                                             \
+    else if (use_queue)                                                                                          \
+      BWD(P_, F_, true, false, true);                                                                            \
+    else if (grad_lattice && grad_positions)                                                                     \
+      BWD(P_, F_, true, true, false);                                                                            \
+    else if (grad_lattice)                                                                                       \
+      BWD(P_, F_, true, false, false);                                                                           \
+    else                                                                                                         \
+      BWD(P_, F_, false, true, false);                                                                           \
+    if (use_queue) {                                                                                             \
+      const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                          \
+      hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);                \
+      if (e2 != hipSuccess) return (int)e2;                                                                      \
+      hipLaunchKernelGGL((encode_bwd_reduce_kernel<F_>), dim3(Q.np, nr_levels), dim3(1024), lds_b, st,            \
+                         (uint32_t)capacity, Q, grad_lattice);                                                   \
+    }                                                                                                            \
   } while (0)
   if (pos_dim == 3 && nr_feat == 2)
     BWD_PF(3, 2);
@@ -540,6 +764,15 @@ int psdf_encode_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int
 #undef BWD
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
+}
+
+int psdf_encode_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+                         const float* lattice, const float* scale_factor, const float* shifts, const float* window,
+                         int concat_points, float points_scaling, const float* grad_sliced, float* grad_lattice,
+                         float* grad_positions, void* stream) {
+  return psdf_encode_backward_ws(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts,
+                                 window, concat_points, points_scaling, grad_sliced, grad_lattice, grad_positions,
+                                 nullptr, 0, stream);
 }
 
 // grad_lattice must be zero-initialised (or NULL to skip); grad_grad_sliced is fully overwritten.

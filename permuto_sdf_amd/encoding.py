@@ -53,6 +53,23 @@ def encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window):
     return sliced
 
 
+def encode_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, g_fm, g_lat, g_pos):
+    """Accumulates into g_lat [L,T,F] / g_pos [N,P] (either may be None).  Large batches go through the binned
+    queue + LDS-reduction path, whose scratch buffer comes from torch's caching allocator."""
+    import ctypes
+    N = positions.shape[0]
+    ws, nbytes = None, 0
+    if g_lat is not None:
+        fn = L.lib().psdf_encode_backward_workspace_bytes
+        fn.restype = ctypes.c_int64
+        nbytes = int(fn(L.c_i(cfg.pos_dim), L.c_i(cfg.nr_feat), L.c_l(N), L.c_i(cfg.nr_levels), L.c_i(cfg.capacity)))
+        if nbytes > 0:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=positions.device)
+    L.call("psdf_encode_backward_ws", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
+           L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(g_fm), L.ptr(g_lat), L.ptr(g_pos), L.ptr(ws), L.c_l(nbytes),
+           L.stream())
+
+
 def _feature_major(g):
     """[N, C] gradient (any strides) -> contiguous [C, N]."""
     gt = g.t()
@@ -88,8 +105,7 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
         N = positions.shape[0]
         g_lat = torch.zeros_like(lattice) if need_lat else None
         g_pos = torch.zeros_like(positions) if need_pos else None
-        L.call("psdf_encode_backward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
-               L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(g), L.ptr(g_lat), L.ptr(g_pos), L.stream())
+        encode_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, g, g_lat, g_pos)
         ctx.cfg = cfg
         ctx.save_for_backward(scale_factor, shifts, lattice, positions, window, g)
         if g_lat is None:

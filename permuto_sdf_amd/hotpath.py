@@ -11,7 +11,7 @@ import torch
 from . import _lib as L
 from . import parallel
 from .bridge import VolumeRendering as VR
-from .encoding import PermutoEncoding, _head, _tail
+from .encoding import PermutoEncoding, _head, _tail, encode_backward_raw
 from .mlp import FusedMLP, mlp_backward_raw, mlp_forward_raw, pack_params
 
 
@@ -79,9 +79,8 @@ class SdfHotPath:
         g_lat = torch.zeros_like(self.enc.lattice_values)
         if self.events is not None:
             self.events["enc_bwd"][0].record()
-        L.call("psdf_encode_backward", *_head(cfg, N), L.ptr(rs.samples_pos), L.ptr(self.enc.lattice_values),
-               L.ptr(self.enc.scale_factor), L.ptr(self.enc.random_shift_per_level), L.ptr(self.window), *_tail(cfg),
-               L.ptr(d_feat), L.ptr(g_lat), None, L.stream())
+        encode_backward_raw(cfg, rs.samples_pos, self.enc.lattice_values, self.enc.scale_factor,
+                            self.enc.random_shift_per_level, self.window, d_feat, g_lat, None)
         if self.events is not None:
             self.events["enc_bwd"][1].record()
         if reduce:
