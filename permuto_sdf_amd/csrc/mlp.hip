@@ -327,12 +327,20 @@ __device__ __forceinline__ void dense_chain_T(const f32x16 (&dz)[TO], f32x16 (&d
     }
 }
 
-// dW[to][ti] += dz_nt[to] (A: lane = out neuron, k = sample) x hin_nt[ti] (B: k = sample, lane = in neuron)
-// then LDS-atomic add into the accumulator image at the packed position of W[row][col].
+// dW[to][ti] += dz_nt[to] (A: lane = out neuron, k = sample) x hin_nt[ti] (B: k = sample, lane = in neuron).
+// ds_add_f32 costs ~196 cycles per wave instruction on this chip whatever the access pattern (tools/atomic_bench.hip:
+// LDS float atomics retire ~1 lane per 3 cycles), against 8-15 cycles for a plain LDS read or read-modify-write, and
+// a 64x3 net needs >200 of them per tile: the first version of this kernel spent 90 % of its time there.  So the
+// partial tiles of the workgroup's waves are exchanged through a staging area instead: every wave writes its 32x32
+// partial (16 registers) to stage[wave], and after a barrier ONE owner wave (pair index mod #waves) sums the staged
+// partials and adds them to the accumulator image with plain read-modify-writes (it is the only writer of that pair).
+// All waves of the workgroup call this function together (the tile loop is workgroup-uniform).
 template <int TO, int TI, bool LAYER0>
 __device__ __forceinline__ void weight_grads(const f32x16 (&dz_nt)[TO], const f32x16 (&hin_nt)[TI],
                                              float* __restrict__ acc_w, float* __restrict__ acc_b, int steps0,
-                                             int sl, int hl) {
+                                             int sl, int hl, float* __restrict__ stage, int wave, int nwaves) {
+  const int lane = hl * 32 + sl;
+  __syncthreads();  // the staging area aliases every wave's transpose buffer: wait until all of them are done with it
 #pragma unroll
   for (int to = 0; to < TO; to++) {
 #pragma unroll
@@ -343,20 +351,29 @@ __device__ __forceinline__ void weight_grads(const f32x16 (&dz_nt)[TO], const f3
 #pragma unroll
       for (int q = 0; q < 16; q++) d = __builtin_amdgcn_mfma_f32_32x32x2f32(dz_nt[to][q], hin_nt[ti][q], d, 0, 0, 0);
       // d[q] at lane (sl,hl) = dW[32to + row_of(q,hl)][32ti + sl]
-      if (LAYER0) {
-        const int col = 32 * ti + sl;
-        if ((col >> 1) < steps0) {
-          float* base = acc_w + (to * steps0 + (col >> 1)) * WS + (col & 1) * 32 + 4 * hl;
 #pragma unroll
-          for (int q = 0; q < 16; q++) atomicAdd(base + row_of(q, 0), d[q]);
+      for (int q = 0; q < 16; q++) stage[(wave * 16 + q) * 64 + lane] = d[q];
+      __syncthreads();
+      if (wave == (to * TI + ti) % nwaves) {
+        float* base;
+        bool ok = true;
+        if (LAYER0) {
+          const int col = 32 * ti + sl;
+          ok = (col >> 1) < steps0;
+          base = acc_w + (to * steps0 + (col >> 1)) * WS + (col & 1) * 32 + 4 * hl;
+        } else {
+          base = acc_w + ((to * TI + ti) * 16 + reg_of(sl)) * WS + half_of(sl) * 32 + 4 * hl;
         }
-      } else {
-        float* base = acc_w + ((to * TI + ti) * 16 + reg_of(sl)) * WS + half_of(sl) * 32 + 4 * hl;
 #pragma unroll
-        for (int q = 0; q < 16; q++) atomicAdd(base + row_of(q, 0), d[q]);
+        for (int q = 0; q < 16; q++) {
+          float sum = stage[q * 64 + lane];
+          for (int w = 1; w < nwaves; w++) sum += stage[(w * 16 + q) * 64 + lane];
+          if (ok) base[row_of(q, 0)] += sum;
+        }
       }
+      __syncthreads();
     }
-    // bias: sum over the 32 samples of this tile (16 regs here + the other half-wave)
+    // bias: sum over the 32 samples of this tile (16 regs here + the other half-wave); 2 atomics per layer and tile
     float sb = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; q++) sb += dz_nt[to][q];
@@ -407,6 +424,10 @@ __global__ void __launch_bounds__(BWD_WAVES * 64)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* __restrict__ tbuf = lds + 2 * p.total + wave * (32 * 33 + 32);
   float* __restrict__ dyb = tbuf + 32 * 33;
+  // [wave][16][64] partial dW tiles; aliases the transpose buffers, which are dead while weight_grads runs (its
+  // operands are in registers and it ends on a barrier)
+  float* __restrict__ stage = lds + 2 * p.total;
+  static_assert(BWD_WAVES * (32 * 33 + 32) >= BWD_WAVES * 16 * 64, "stage must fit in the transpose buffers");
   for (int i = threadIdx.x; i < p.total; i += BWD_WAVES * 64) {
     W[i] = packed[i];
     ACC[i] = 0.f;
@@ -417,8 +438,10 @@ __global__ void __launch_bounds__(BWD_WAVES * 64)
   constexpr int TL = (T3 > 0) ? T3 : T2;
   const int lf = p.n_layers - 1;
   const int64_t ntiles = (N + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * BWD_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * BWD_WAVES) {
+  // workgroup-uniform trip count: the waves meet at barriers inside weight_grads (a wave without a tile runs on zeros)
+  for (int64_t tbase_ = (int64_t)blockIdx.x * BWD_WAVES; tbase_ < ntiles; tbase_ += (int64_t)gridDim.x * BWD_WAVES) {
     asm volatile("" ::: "memory");
+    const int64_t tile = tbase_ + wave;
     const int64_t n = tile * 32 + sl;
     const bool live = n < N;
     const int64_t nc = live ? n : N - 1;
@@ -508,7 +531,7 @@ __global__ void __launch_bounds__(BWD_WAVES * 64)
         dense_chain_T<OUT_T, TL>(dyT, dhl, W + p.w_off[lf], sl, hl);
         f32x16 dy_nt[OUT_T];
         transpose_tiles<OUT_T>(dyT, dy_nt, tbuf, sl, hl);
-        weight_grads<OUT_T, TL, false>(dy_nt, hl_nt, ACC + p.w_off[lf], ACC + p.b_off[lf], S0, sl, hl);
+        weight_grads<OUT_T, TL, false>(dy_nt, hl_nt, ACC + p.w_off[lf], ACC + p.b_off[lf], S0, sl, hl, stage, wave, BWD_WAVES);
       }
     }
     // ------------------------------------------------ hidden layers, last to first
@@ -519,7 +542,7 @@ __global__ void __launch_bounds__(BWD_WAVES * 64)
         f32x16 dz_nt[T3], hin_nt[T2];
         transpose_tiles<T3>(dhl, dz_nt, tbuf, sl, hl);
         gelu_and_transpose<T2>(z2, hin_nt, tbuf, sl, hl);
-        weight_grads<T3, T2, false>(dz_nt, hin_nt, ACC + p.w_off[2], ACC + p.b_off[2], S0, sl, hl);
+        weight_grads<T3, T2, false>(dz_nt, hin_nt, ACC + p.w_off[2], ACC + p.b_off[2], S0, sl, hl, stage, wave, BWD_WAVES);
       }
       zero_tiles<T2>(dh2);
       dense_chain_T<T3, T2>(dhl, dh2, W + p.w_off[2], sl, hl);
@@ -532,7 +555,7 @@ __global__ void __launch_bounds__(BWD_WAVES * 64)
       f32x16 dz_nt[T2], hin_nt[T1];
       transpose_tiles<T2>(dh2, dz_nt, tbuf, sl, hl);
       gelu_and_transpose<T1>(z1, hin_nt, tbuf, sl, hl);
-      weight_grads<T2, T1, false>(dz_nt, hin_nt, ACC + p.w_off[1], ACC + p.b_off[1], S0, sl, hl);
+      weight_grads<T2, T1, false>(dz_nt, hin_nt, ACC + p.w_off[1], ACC + p.b_off[1], S0, sl, hl, stage, wave, BWD_WAVES);
     }
     f32x16 dh1[T1];
     zero_tiles<T1>(dh1);
@@ -551,7 +574,7 @@ __global__ void __launch_bounds__(BWD_WAVES * 64)
         for (int r = 0; r < 16; r++) x_nt[t][r] = tbuf[sl * 33 + row_of(r, hl)];
         __builtin_amdgcn_wave_barrier();
       }
-      weight_grads<T1, TI0, true>(dz_nt, x_nt, ACC + p.w_off[0], ACC + p.b_off[0], S0, sl, hl);
+      weight_grads<T1, TI0, true>(dz_nt, x_nt, ACC + p.w_off[0], ACC + p.b_off[0], S0, sl, hl, stage, wave, BWD_WAVES);
     }
     if constexpr (NEED_DX) {
       // dX^T[k][s] = sum_out W0[out][k] dZ1[out][s];  A operand read transposed from the layer-0 image

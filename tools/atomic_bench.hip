@@ -35,6 +35,26 @@ __global__ void scatter_lds(float* out, uint32_t rows_mask){
   __syncthreads();
   if(threadIdx.x==0) out[blockIdx.x]=lds[0];
 }
+template<int PER_THREAD, int MODE>
+__global__ void lds_ops(float* out){
+  extern __shared__ float lds[];
+  for(int i=threadIdx.x;i<16384;i+=blockDim.x) lds[i]=0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0;
+  #pragma unroll 8
+  for(int i=0;i<PER_THREAD;i++){
+    // conflict-free: lane l -> distinct consecutive banks; a different 64-float row per iteration and wave
+    const int a = ((i*4 + wave) * 64 + lane) & 16383;
+    if (MODE==0) atomicAdd(&lds[a], 1.0f);                 // ds_add_f32
+    if (MODE==1) lds[a] = lds[a] + 1.0f;                   // plain read-modify-write
+    if (MODE==2) acc += lds[a];                            // read only
+    if (MODE==3) atomicAdd(&lds[(lane*65 + i) & 16383], 1.0f);   // stride-65: conflict free, scattered rows
+    if (MODE==4) atomicAdd(&lds[(lane*2 + (i&1)*128) & 16383], 1.0f);   // 2-way bank conflict
+  }
+  __syncthreads();
+  if(threadIdx.x==0) out[blockIdx.x]=lds[0]+acc;
+}
 __global__ void gather(const float2* table, uint32_t rows_mask, float* out){
   uint32_t gid = blockIdx.x*blockDim.x + threadIdx.x;
   float acc=0;
@@ -66,6 +86,11 @@ int main(){
   { const int perl=64; int b = total/perl/threads; 
     float t = timeit([&]{ hipLaunchKernelGGL((scatter_lds<perl>), dim3(b), dim3(threads), 16384*4, 0, out, 16383u); });
     printf("LDS atomics (16K floats/block, random): %.3f ms (%.1f Gatom/s)\n", t, total/t/1e6); }
+  { const int perl=256; int b = 1024;
+    #define LDSRUN(M, name) { float t = timeit([&]{ hipLaunchKernelGGL((lds_ops<perl,M>), dim3(b), dim3(threads), 16384*4, 0, out); }); \
+      printf("LDS %s: %.3f ms -> %.1f G lane-ops/s, %.1f cycles per wave-instr per CU (2.4GHz, 256 CU)\n", name, t, (double)b*threads*perl/t/1e6, t*1e-3*2.4e9*256/((double)b*threads*perl/64)); }
+    LDSRUN(0, "ds_add_f32 conflict-free"); LDSRUN(1, "plain RMW conflict-free"); LDSRUN(2, "read conflict-free");
+    LDSRUN(3, "ds_add_f32 stride-65"); LDSRUN(4, "ds_add_f32 2-way conflict"); }
   { float t = timeit([&]{ hipLaunchKernelGGL(gather, dim3(total/8/threads), dim3(threads),0,0,(const float2*)table, rows-1, out); });
     printf("gather float2 from 2MiB table: %.3f ms (%.1f Ggather/s)\n", t, total/t/1e6); }
   return 0;
