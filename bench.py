@@ -137,6 +137,8 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if os.environ.get("PSDF_BENCH_SINGLE_DEVICE") == "1":
+        local = 0  # development aid: run every rank on cuda:0 (with PSDF_DIST_BACKEND=gloo) to exercise the N>1 path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -168,7 +170,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     hp.events = None
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (world == 1 or torch.distributed.get_backend() == "nccl") else "cpu")
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -200,7 +202,17 @@ def main():
         dom = max(cand, key=lambda k: ms[k])
         roof = cand[dom]
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch from the PMC counters: rocprofv3 cannot be driven from inside the timed process, so the
+        # number is the committed summary of a separate-pass --pmc run of this same command (profiles/), corrected
+        # as MI355X_MICROARCH.md prescribes; null when no summary for the dominant kernel is on file.
         roof["traffic"] = None
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")))
+            key = {"enc_bwd": ["encode_bwd_kernel", "encode_bwd_reduce_kernel"], "mlp_bwd": ["mlp_bwd_kernel"]}[dom]
+            roof["traffic"] = int(sum(pmc["kernels"][k]["hbm_bytes"] for k in key))
+            roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+        except Exception:
+            pass
         other = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "avg_launch_ms")} for k, v in cand.items() if k != dom}
         out = {
             "metric": "ray-samples/sec (encode+MLP+composite)",

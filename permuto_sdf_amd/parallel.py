@@ -21,10 +21,10 @@ def init(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("PSDF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend == "nccl":
+        if backend == "nccl" and os.environ.get("PSDF_BENCH_SINGLE_DEVICE") != "1":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -59,6 +59,13 @@ class GradientBuckets:
             return
         tensors = [t for t in tensors if t is not None]
         if not tensors:
+            return
+        if dist.get_backend() == "gloo" and tensors[0].is_cuda:
+            # test-only path (gloo has no device collectives here): stage through host memory, synchronously
+            for t in tensors:
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
             return
         if len(tensors) == 1:
             self.pending.append((dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, async_op=True), None, None))
