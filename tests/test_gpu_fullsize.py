@@ -1,0 +1,100 @@
+"""GPU, BASELINE full sizes (configs[2]: 512x512 rays, <=128 samples per ray, chunked 16 x 16 384 rays like the
+reference's run_net_in_chunks, train_permuto_sdf.py:172-187): size-independent properties of the whole sample
+generation + compositing chain, plus a bit-exact oracle comparison on a 512-ray subset of every 4th chunk."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def camera_rays(res, dev):
+    """pin-hole camera at distance 1.5 looking at the origin, fx = fy = res (SURVEY.md 8d cfg 3)."""
+    ys, xs = torch.meshgrid(torch.arange(res, device=dev), torch.arange(res, device=dev), indexing="ij")
+    d = torch.stack([(xs + 0.5 - res / 2) / res, (ys + 0.5 - res / 2) / res, torch.ones_like(xs, dtype=torch.float32)], -1)
+    d = d.reshape(-1, 3).float()
+    d = d / d.norm(dim=1, keepdim=True)
+    o = torch.tensor([0.0, 0.0, -1.5], device=dev).expand_as(d).contiguous()
+    return o, d.contiguous()
+
+
+def test_cfg3_full_volume_render(dev):
+    from permuto_sdf import OccupancyGrid, RaySamplesPacked, Sphere, VolumeRendering as VR
+    port = O.Oracle("port")
+    n, res, chunk = 256, 512, 16384
+    occ = scene.shell_occupancy(port, n, r0=0.3, width=0.02, drop=0.0)
+    grid = OccupancyGrid(n, 1.0, [0, 0, 0])
+    grid.set_grid_occupancy(torch.from_numpy(occ).to(dev))
+    sphere = Sphere(0.5, [0, 0, 0])
+    o_all, d_all = camera_rays(res, dev)
+    image = torch.zeros(res * res, 3, device=dev)
+    total_samples = 0
+    for ci, (o, d) in enumerate(zip(o_all.split(chunk), d_all.split(chunk))):
+        _, te, _, tx, hit = sphere.ray_intersection(o, d)
+        rs = grid.compute_samples_in_occupied_regions(o, d, te, tx, 1e-4, 128, False)
+        exact = rs.compute_exact_nr_samples()
+        c = rs.compact_to_valid_samples()
+        M = c.samples_pos.shape[0]
+        assert M == exact <= rs.max_nr_samples
+        total_samples += M
+        se = c.ray_start_end_idx.long()
+        cnt = se[:, 1] - se[:, 0]
+        assert int(cnt.sum()) == M
+        assert bool(((cnt == 0) | ((cnt >= 3) & (cnt <= 128))).all())
+        assert bool((cnt[~hit.view(-1)] == 0).all())                          # rays missing the sphere get nothing
+        if M == 0:
+            continue
+        ridx = RaySamplesPacked.compute_per_sample_ray_idx(c.ray_start_end_idx, M).long()
+        z = c.samples_z.view(-1)
+        assert bool((z >= te.view(-1)[ridx]).all()) and bool((z <= tx.view(-1)[ridx]).all())
+        same_ray = ridx[1:] == ridx[:-1]
+        assert bool((z[1:][same_ray] > z[:-1][same_ray]).all())               # strictly increasing along each ray
+        assert bool(grid.check_occupancy(c.samples_pos).all())                # every sample sits in an occupied voxel
+        assert torch.equal(c.samples_pos, o[ridx] + z[:, None] * c.samples_dirs)   # pos = o + z d, same rounding
+        assert bool((c.samples_dt.view(-1) >= 0).all()) and bool((c.samples_dt.view(-1) <= c.ray_fixed_dt.view(-1)[ridx] * (1 + 1e-6)).all())
+        # NeuS compositing on the analytic sphere SDF
+        sdf = (c.samples_pos.norm(dim=1, keepdim=True) - 0.3)
+        alpha = VR.sdf2alpha(c, sdf, 512.0, True, 1.0).clamp(0, 1)
+        T, bg = VR.cumprod_alpha2transmittance(c, 1 - alpha + 1e-7)
+        w = alpha * T
+        wsum, _ = VR.sum_over_each_ray(c, w)
+        live = cnt > 0
+        assert float((wsum + bg - 1).abs()[live].max()) < 5e-4                # sum of weights + background == 1
+        normals = c.samples_pos / c.samples_pos.norm(dim=1, keepdim=True)
+        image[ci * chunk:(ci + 1) * chunk] = VR.integrate_with_weights(c, normals * 0.5 + 0.5, w)
+        if ci % 4 == 0:   # oracle on a subset, bit-exact
+            sub = slice(0, 512)
+            on, dn, ten, txn = (t[sub].cpu().numpy() for t in (o, d, te, tx))
+            ref = port.compact(port.march_samples(on, dn, ten, txn, 1e-4, 128, 1 << 16, grid=(n, 1.0, [0, 0, 0], occ)))
+            k = ref.total()
+            assert np.array_equal(c.ray_start_end_idx[sub].cpu().numpy(), ref.start_end)
+            assert np.array_equal(c.samples_z[:k].cpu().numpy().view(np.uint32), ref.z[:k].view(np.uint32))
+    assert total_samples > 2_000_000
+    img = image.view(res, res, 3)
+    centre = img[res // 2, res // 2]
+    assert float(centre[2]) < 0.1 and abs(float(centre[0]) - 0.5) < 0.05     # normal at the centre faces the camera (-z)
+    assert float(img[0, 0].abs().max()) == 0.0                                 # corner rays miss the object
+
+
+def test_cfg2_fullsize_forward_consistency(dev):
+    """2M points, 16 levels: the encoding of a batch equals the encoding of its halves (no cross-sample coupling),
+    and the fused MLP on the feature-major buffer equals the drop-in [N,C] path."""
+    from permuto_sdf_amd import FusedMLP, PermutoEncoding
+    torch.manual_seed(0)
+    N = 2 * 1024 * 1024
+    enc = PermutoEncoding(3, 2 ** 18, 16, 2, np.geomspace(1.0, 1e-4, 16), concat_points=True, concat_points_scaling=1e-3,
+                          init_scale=1e-2).to(dev)
+    mlp = FusedMLP([enc.output_dims(), 64, 64, 64, 1]).to(dev)
+    pts = torch.rand(N, 3, device=dev) - 0.5
+    win = torch.ones(16, device=dev)
+    with torch.no_grad():
+        full = enc(pts, win)
+        a, b = enc(pts[:N // 2].contiguous(), win), enc(pts[N // 2:].contiguous(), win)
+        assert torch.equal(full[:N // 2], a) and torch.equal(full[N // 2:], b)
+        y1 = mlp(full)
+        y2 = mlp.forward_feature_major(enc.forward_feature_major(pts, win)).t()
+        assert torch.equal(y1, y2)
+        assert bool(torch.isfinite(y1).all())
