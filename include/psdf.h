@@ -139,6 +139,15 @@ int psdf_random_rays_from_reel(int nr_rays, int nr_images, int height, int width
     mask_reel, const float* K_reel, const float* tf_world_cam_reel, const int* pixel_indices, const int* img_indices,
     int has_mask, float* ray_origins, float* ray_dirs, float* gt_rgb, float* gt_mask, void* stream);
 
+/* replaces: the Python loop of sphere_trace(), permuto_sdf_py/utils/sdf_utils.py:120-218 (first hit :127-133, per
+   iteration step :167-185), with one slot per ray so that the loop is a fixed launch sequence (hipGraph) */
+int psdf_first_hit_dense(int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation, const
+    uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs, const float* ray_t_entry, const float*
+    ray_t_exit, float* pos, uint8_t* converged, void* stream);
+int psdf_sphere_trace_step(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const
+    uint8_t* grid_occupancy, const float* dirs, const float* sdf, float sdf_multiplier, float sdf_converged_thresh,
+    float* pts, uint8_t* converged, void* stream);
+
 /* ---- volume_rendering.hip ---- */
 /* replaces: (helper) replaces the atomicAdd slot counters, e.g. kernels/permuto_sdf/OccupancyGridGPU.cuh:599 */
 int psdf_exclusive_scan_i32(int n, const int* in, int* out, int* total, void* stream);

@@ -741,6 +741,8 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   CASE(2, 2, 2, 2, 3, false)
   CASE(2, 2, 2, 2, 2, false)
   CASE(3, 2, 2, 0, 1, true)
+  CASE(1, 2, 2, 2, 1, true)   // <=32 input channels (small encodings, e.g. 8 levels + points)
+  CASE(1, 1, 1, 1, 1, true)
 #undef CASE
   return PSDF_ERR_UNSUPPORTED;
 }

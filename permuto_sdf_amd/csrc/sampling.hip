@@ -364,6 +364,86 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   within[i] = inside;
 }
 
+// ---------------------------------------------------------------------------------- fixed-shape sphere tracing
+// The reference's sphere tracer (permuto_sdf_py/utils/sdf_utils.py:120-218) compacts the unconverged rays with boolean
+// masks every iteration (dynamic shapes, implicit host syncs).  These two kernels keep ONE slot per ray for the whole
+// trace, so the 15-iteration loop is a fixed sequence of launches that a hipGraph can replay.
+// first hit, dense: the per-ray result of compute_first_sample_start_of_occupied_regions without packing
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    first_hit_dense_kernel(int nr_rays, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ origins,
+                           const float* __restrict__ dirs, const float* __restrict__ t_entry,
+                           const float* __restrict__ t_exit_p, float push, float* __restrict__ pos,
+                           uint8_t* __restrict__ converged) {
+  const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (ray >= nr_rays) return;
+  const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
+  const v3 idir = safe_inverse(dir);
+  float t = t_entry[ray];
+  const float t_exit = t_exit_p[ray];
+  int steps = 0;
+  bool hit = false;
+  v3 hp = org;
+  while (t < t_exit && steps < MAX_DDA_STEPS) {
+    const v3 pos_ = along(org, t, dir);
+    const int vox = g.pos_to_idx(pos_);
+    if (!g.in_range(vox)) break;
+    const float d = dist_to_next_voxel(pos_, dir, idir, g.n);
+    t += d;
+    t += DDA_EPS;
+    if (occ[vox]) {
+      hit = true;
+      hp = pos_;
+      break;
+    }
+    steps++;
+  }
+  // move slightly inside the voxel: pos + dirs*voxel_size*0.5 (sdf_utils.py:133), same operation order
+  if (hit) hp = hp + (dir * push) * 0.5f;
+  st3(pos + 3 * (int64_t)ray, hp);
+  converged[ray] = !hit;  // a ray that never meets an occupied voxel takes no part in the trace
+}
+
+// one trace iteration for every ray that has not converged (sdf_utils.py:167-185): step along the ray by
+// sdf*multiplier, mark converged when |sdf| < threshold, march to the next occupied voxel, mark converged when the
+// march leaves the grid.
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    sphere_trace_step_kernel(int count, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ dirs,
+                             const float* __restrict__ sdf, float multiplier, float thresh, float* __restrict__ pts,
+                             uint8_t* __restrict__ converged) {
+  const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (i >= count) return;
+  if (converged[i]) return;
+  const v3 dir = ld3(dirs + 3 * (int64_t)i);
+  const float s = sdf[i];
+  v3 p = ld3(pts + 3 * (int64_t)i) + (dir * s) * multiplier;
+  bool done = fabsf(s) < thresh;
+  const v3 idir = safe_inverse(dir);
+  float t = 0.f;
+  int steps = 0;
+  bool inside = true;
+  v3 out = p;
+  const double limit = (double)g.n * sqrt(3.0);
+  while (inside && (double)steps < limit) {
+    const v3 q = along(p, t, dir);
+    const int vox = g.pos_to_idx(q);
+    if (!g.in_range(vox)) {
+      inside = false;
+      out = q;
+      break;
+    }
+    const float d = dist_to_next_voxel(q, dir, idir, g.n);
+    t += d;
+    t += DDA_EPS;
+    if (occ[vox]) {
+      out = q;
+      break;
+    }
+    steps++;
+  }
+  st3(pts + 3 * (int64_t)i, out);
+  converged[i] = done || !inside;
+}
+
 // ---------------------------------------------------------------------------------- background sampler
 // inverse-depth samples outside the bounding sphere, 3-D point (optionally contracted) + 4-D NeRF++ point
 __global__ void __launch_bounds__(PSDF_BLOCK)
@@ -752,6 +832,32 @@ int psdf_advance_to_next_occupied_voxel(int count, int nr_voxels_per_dim, float 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(advance_kernel, GRID1(count), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
                      grid_occupancy, samples_dirs, samples_pos, is_within_bounds);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// Dense (one slot per ray) first hit for the fixed-shape sphere tracer: pos[ray] = entry point of the first occupied
+// voxel pushed half a voxel inside, converged[ray] = 1 for rays that meet no occupied voxel.
+int psdf_first_hit_dense(int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
+                         const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs,
+                         const float* ray_t_entry, const float* ray_t_exit, float* pos, uint8_t* converged, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const float voxel = (float)(1.0 / nr_voxels_per_dim);
+  hipLaunchKernelGGL(first_hit_dense_kernel, GRID1(nr_rays), nr_rays, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     grid_occupancy, ray_origins, ray_dirs, ray_t_entry, ray_t_exit, voxel, pos, converged);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// One iteration of the fixed-shape sphere tracer; sdf[count] is the SDF at pts before the step.
+int psdf_sphere_trace_step(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
+                           const uint8_t* grid_occupancy, const float* dirs, const float* sdf, float sdf_multiplier,
+                           float sdf_converged_thresh, float* pts, uint8_t* converged, void* stream) {
+  if (count <= 0) return PSDF_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sphere_trace_step_kernel, GRID1(count), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     grid_occupancy, dirs, sdf, sdf_multiplier, sdf_converged_thresh, pts, converged);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

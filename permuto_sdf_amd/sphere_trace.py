@@ -1,0 +1,84 @@
+"""Fixed-shape sphere tracing of an encoded SDF (BASELINE config 5: 1920x1080 rays, 15 iterations).
+
+Mirrors ``sphere_trace`` of the reference (permuto_sdf_py/utils/sdf_utils.py:120-218) on top of the same kernels, but
+keeps one slot per ray instead of compacting the unconverged rays with boolean masks every iteration: the whole trace
+is a fixed sequence of launches (first hit -> [encode -> fused MLP -> step] x n -> final SDF + analytic normal), has
+no host synchronisation and can therefore be captured ONCE into a hipGraph and replayed per frame
+(``SphereTracer.capture``).  Converged rays are masked out inside the step kernel; their SDF evaluation is wasted
+work, which is the price of the static shape (and is cheap: 2M-point encode + MLP is ~1.6 ms).
+"""
+import torch
+
+from . import _lib as L
+from .encoding import _head, _tail, encode_forward_raw
+from .mlp import mlp_backward_raw, mlp_forward_raw, pack_params
+
+
+class SphereTracer:
+    def __init__(self, encoding, mlp, occupancy_grid, sphere, window=None):
+        self.enc, self.mlp, self.grid, self.sphere = encoding, mlp, occupancy_grid, sphere
+        dev = encoding.lattice_values.device
+        self.window = window if window is not None else torch.ones(encoding.nr_levels, device=dev)
+        self._graph = None
+
+    # ---- building blocks -----------------------------------------------------------------------------------
+    def _sdf(self, pts, packed):
+        feat = encode_forward_raw(self.enc.cfg, pts, self.enc.lattice_values.detach(), self.enc.scale_factor,
+                                  self.enc.random_shift_per_level.detach(), self.window)
+        return feat, mlp_forward_raw(self.mlp.dims, feat, packed)          # [C,N], [out,N]
+
+    def _grid_args(self):
+        g = self.grid
+        return L.c_i(g.m_nr_voxels_per_dim), L.c_f(g.m_grid_extent), (L.c_f * 3)(*g.m_grid_translation)
+
+    @torch.no_grad()
+    def trace(self, ray_origins, ray_dirs, nr_sphere_traces=15, sdf_multiplier=0.9, sdf_converged_tresh=2e-4,
+              return_gradients=True):
+        """-> pts [R,3], sdf [R,1], sdf_gradients [R,3] or None, converged [R,1] bool (rays that never met an
+        occupied voxel are reported converged with their point left at the ray origin)."""
+        o, d = ray_origins.contiguous(), ray_dirs.contiguous()
+        R, dev = o.shape[0], o.device
+        _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
+        pts = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        conv = torch.empty((R, 1), dtype=torch.bool, device=dev)
+        occ = self.grid._occ()
+        L.call("psdf_first_hit_dense", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(o), L.ptr(d), L.ptr(te), L.ptr(tx),
+               L.ptr(pts), L.ptr(conv), L.stream())
+        ws = [l.weight for l in self.mlp.layers]
+        bs = [l.bias for l in self.mlp.layers]
+        packed = pack_params(self.mlp.dims, ws, bs)
+        for _ in range(nr_sphere_traces):
+            _, y = self._sdf(pts, packed)
+            sdf = y[0] if y.shape[0] > 1 else y.view(-1)                  # channel 0 is the SDF (models.py:190-192)
+            L.call("psdf_sphere_trace_step", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf.contiguous()),
+                   L.c_f(sdf_multiplier), L.c_f(sdf_converged_tresh), L.ptr(pts), L.ptr(conv), L.stream())
+        feat, y = self._sdf(pts, packed)
+        sdf = y[0:1]
+        grads = None
+        if return_gradients:
+            # analytic normal: d sdf / d x = encode_backward_positions( mlp_backward_dX( e_0 ) )
+            gy = torch.zeros_like(y)
+            gy[0].fill_(1.0)
+            d_feat, _, _ = mlp_backward_raw(self.mlp.dims, feat, packed, gy, need_dx=True)
+            grads = torch.zeros((R, 3), dtype=torch.float32, device=dev)
+            cfg = self.enc.cfg
+            L.call("psdf_encode_backward", *_head(cfg, R), L.ptr(pts), L.ptr(self.enc.lattice_values.detach()),
+                   L.ptr(self.enc.scale_factor), L.ptr(self.enc.random_shift_per_level.detach()), L.ptr(self.window),
+                   *_tail(cfg), L.ptr(d_feat), None, L.ptr(grads), L.stream())
+        return pts, sdf.reshape(-1, 1), grads, conv
+
+    # ---- hipGraph ------------------------------------------------------------------------------------------------
+    def capture(self, ray_origins, ray_dirs, **kw):
+        """Capture one full trace for rays of this shape; `replay()` re-runs it on the CURRENT contents of the two
+        input tensors (update them in place) and returns the same output tensors."""
+        self._o, self._d = ray_origins.contiguous(), ray_dirs.contiguous()
+        self.trace(self._o, self._d, **kw)                      # warm-up outside capture (allocator, lazy init)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._out = self.trace(self._o, self._d, **kw)
+        return self._out
+
+    def replay(self):
+        self._graph.replay()
+        return self._out

@@ -13,6 +13,7 @@ NETS = [
     [52, 64, 64, 64, 65],    # background density net
     [80, 64, 64, 3],         # background colour head
     [51, 32, 32, 32, 1],     # odd input width
+    [20, 64, 64, 64, 1],     # <= 32 input channels
 ]
 
 
@@ -59,7 +60,7 @@ def test_forward_asymmetric_weights(dev):
 
 
 BWD_NETS = [[52, 64, 64, 64, 1], [36, 64, 64, 64, 1], [52, 32, 32, 32, 33], [52, 64, 64, 64, 65], [80, 64, 64, 3],
-            [51, 32, 32, 32, 1]]
+            [51, 32, 32, 32, 1], [20, 64, 64, 64, 1], [20, 32, 32, 32, 1]]
 
 
 @pytest.mark.parametrize("dims", BWD_NETS)

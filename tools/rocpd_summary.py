@@ -4,6 +4,13 @@ import sys
 
 
 def main(db, out=None):
+    import glob
+    import os
+    if os.path.isdir(db):   # rocprofv3 -d <dir>: <dir>/<host>/<pid>_results.db
+        found = sorted(glob.glob(os.path.join(db, "**", "*.db"), recursive=True), key=os.path.getsize)
+        if not found:
+            raise SystemExit("no rocpd .db under %s" % db)
+        db = found[-1]
     c = sqlite3.connect(db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     name_col = "name" if "name" in cols else [x for x in cols if "name" in x][0]
