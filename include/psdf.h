@@ -63,6 +63,14 @@ int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, c
 int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, const float* dY,
     float* dX, float* const* dW, float* const* db, void* stream);
 
+/* ---- fused.hip ---- */
+/* replaces: models.py:186-192 `point_features=self.encoding(points, window); sdf_and_feat=self.mlp_sdf(point_features)`
+   as ONE launch that never materialises the feature tensor (pos_dim 3, 2 features/level).  dims[0] must be
+   2*(nr_levels + (concat_points?2:0)); skip [N] bytes and feat [dims[0],N] are optional (NULL) */
+int psdf_encode_mlp_forward(int64_t N, int nr_levels, int capacity, const float* positions, const float* lattice,
+    const float* scale_factor, const float* shifts, const float* window, int concat_points, float points_scaling,
+    int n_layers, const int* dims, const float* packed, const uint8_t* skip, float* feat, float* Y, void* stream);
+
 /* ---- optim.hip ---- */
 /* replaces: torch.optim.AdamW at permuto_sdf_py/train_permuto_sdf.py:293-304,418 */
 int psdf_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float

@@ -1,0 +1,103 @@
+// Device-side simplex location / hashing of the permutohedral encoding (shared by encode.hip and fused.hip).
+// Conventions: SURVEY.md App. A / oracle/permuto_oracle.py.
+#pragma once
+#include "psdf_common.h"
+
+namespace {
+
+template <int P>
+struct Simplex {
+  int rem0[P + 1];
+  int rank[P + 1];
+  float bary[P + 2];
+};
+
+// elevate -> closest 0-colour point -> rank -> barycentric.  All loops are fully unrolled and every
+// array index is a compile-time constant after unrolling (runtime-indexed arrays would go to scratch).
+template <int P>
+__device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, const float* __restrict__ shift,
+                                                const float* __restrict__ sf, Simplex<P>& s) {
+  float E[P + 1];
+  float sm = 0.f;
+#pragma unroll
+  for (int i = P; i > 0; i--) {
+    float cf = (pos[i - 1] + shift[i - 1]) * sf[i - 1];
+    E[i] = sm - (float)i * cf;
+    sm = sm + cf;
+  }
+  E[0] = sm;
+
+  const double inv = 1.0 / (P + 1);
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i <= P; i++) {
+    float v = (float)((double)E[i] * inv);
+    float up = ceilf(v) * (float)(P + 1);
+    float down = floorf(v) * (float)(P + 1);
+    s.rem0[i] = ((up - E[i]) < (E[i] - down)) ? (int)up : (int)down;
+    sum += s.rem0[i];
+  }
+  sum /= (P + 1);
+
+  float d[P + 1];
+#pragma unroll
+  for (int i = 0; i <= P; i++) {
+    d[i] = E[i] - (float)s.rem0[i];
+    s.rank[i] = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+#pragma unroll
+    for (int j = i + 1; j <= P; j++) {
+      if (d[i] < d[j])
+        s.rank[i]++;
+      else
+        s.rank[j]++;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i <= P; i++) {
+    s.rank[i] += sum;
+    if (s.rank[i] < 0) {
+      s.rank[i] += P + 1;
+      s.rem0[i] += P + 1;
+    } else if (s.rank[i] > P) {
+      s.rank[i] -= P + 1;
+      s.rem0[i] -= P + 1;
+    }
+  }
+  // recompute d after the fix-up (rem0 may have moved by +-(P+1)); same expression as the oracle
+#pragma unroll
+  for (int k = 0; k <= P + 1; k++) s.bary[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i <= P; i++) {
+    float delta = (float)((double)(E[i] - (float)s.rem0[i]) * inv);
+#pragma unroll
+    for (int k = 0; k <= P + 1; k++) {
+      if (k == P - s.rank[i]) s.bary[k] = s.bary[k] + delta;
+      if (k == P + 1 - s.rank[i]) s.bary[k] = s.bary[k] - delta;
+    }
+  }
+  s.bary[0] = (float)((double)s.bary[0] + (1.0 + (double)s.bary[P + 1]));
+}
+
+template <int P>
+__device__ __forceinline__ uint32_t vertex_row(const Simplex<P>& s, int remainder, uint32_t capacity) {
+  uint32_t h = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    int k = s.rem0[i] + remainder;
+    if (s.rank[i] > P - remainder) k -= (P + 1);
+    h += (uint32_t)k;
+    h *= 2531011u;
+  }
+  return h % capacity;
+}
+
+template <int P>
+__device__ __forceinline__ void load_pos(const float* __restrict__ positions, int64_t n, float* pos) {
+#pragma unroll
+  for (int i = 0; i < P; i++) pos[i] = positions[n * P + i];
+}
+
+}  // namespace

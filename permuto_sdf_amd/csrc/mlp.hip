@@ -16,52 +16,9 @@
 // (two 128-B segments per wave load); the result is stored feature-major [OUT, N].
 #include "psdf_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "mlp_device.h"
 
 namespace {
-
-constexpr int MAXL = 5;  // max number of linear layers
-constexpr int WS = 65;   // LDS row stride of a 64-lane weight row (64 + 1 pad float)
-
-struct MlpPlan {
-  int n_layers;        // number of linear layers (hidden layers + 1)
-  int dims[MAXL + 1];  // true widths: dims[0] = input, dims[n_layers] = output
-  int in_steps0;       // ceil(dims[0]/2)
-  int tiles[MAXL + 1]; // tiles[i] = ceil(dims[i]/32) for i>=1
-  int w_off[MAXL];     // float offsets into the packed buffer
-  int b_off[MAXL];
-  int total;           // packed floats
-  int final_dot;       // 1 when the last layer is evaluated with VALU dot products (out <= 4)
-};
-
-__host__ __device__ inline int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-static int make_plan(int n_layers, const int* dims, MlpPlan& p) {
-  if (n_layers < 2 || n_layers > MAXL) return PSDF_ERR_ARG;
-  p.n_layers = n_layers;
-  for (int i = 0; i <= n_layers; i++) {
-    if (dims[i] <= 0) return PSDF_ERR_ARG;
-    p.dims[i] = dims[i];
-    p.tiles[i] = (dims[i] + 31) / 32;
-  }
-  p.in_steps0 = (dims[0] + 1) / 2;
-  p.final_dot = dims[n_layers] <= 4;
-  int off = 0;
-  for (int l = 0; l < n_layers; l++) {
-    p.w_off[l] = off;
-    const bool last = (l == n_layers - 1);
-    if (l == 0)
-      off += p.tiles[1] * p.in_steps0 * WS;
-    else if (last && p.final_dot)
-      off += dims[n_layers] * p.tiles[l] * 32;
-    else
-      off += p.tiles[l + 1] * p.tiles[l] * 16 * WS;
-    p.b_off[l] = off;
-    off += (last && p.final_dot) ? 4 : p.tiles[l + 1] * 32;
-  }
-  p.total = off;
-  return PSDF_OK;
-}
 
 // ---------------------------------------------------------------------------------------- packing
 // One thread per packed float.  W_l is torch layout [dims[l+1]][dims[l]] row major.
@@ -104,77 +61,6 @@ __global__ void mlp_pack_kernel(PackArgs a, float* __restrict__ packed) {
     if (row < out_d && col < in_d) v = a.W[l][(int64_t)row * in_d + col];
   }
   packed[e] = v;
-}
-
-// -------------------------------------------------------------------------------------- device math
-// erf with < 1 ulp error, branch-free (both ranges evaluated, then selected): a ~20-instruction VALU
-// sequence instead of the two-branch library erff, which matters because 96 GELUs per lane sit between
-// the MFMA chains of every tile.  Polynomials: the widely used single-precision minimax pair
-// (|x| <= 0.927734375: odd polynomial in x; above: 1 - exp(p(|x|))).
-__device__ __forceinline__ float erf_fast(float a) {
-  const float t = fabsf(a);
-  const float s = a * a;
-  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-  float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-  r = fmaf(r, s, u);
-  r = fmaf(r, t, -1.06777877e-1f);
-  r = fmaf(r, t, -6.34846687e-1f);
-  r = fmaf(r, t, -1.28717512e-1f);
-  r = fmaf(r, t, -t);
-  const float hi = copysignf(1.0f - __expf(r), a);
-  float q = -5.96761703e-4f;
-  q = fmaf(q, s, 4.99119423e-3f);
-  q = fmaf(q, s, -2.67681349e-2f);
-  q = fmaf(q, s, 1.12819925e-1f);
-  q = fmaf(q, s, -3.76125336e-1f);
-  q = fmaf(q, s, 1.28379166e-1f);
-  const float lo = fmaf(q, a, a);
-  return t > 0.927734375f ? hi : lo;
-}
-
-__device__ __forceinline__ float gelu_exact(float x) {
-  // torch.nn.GELU() default (erf form): 0.5*x*(1+erf(x/sqrt(2)))
-  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
-}
-
-// d/dx gelu(x) = Phi(x) + x*phi(x)
-__device__ __forceinline__ float gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return fmaf(x, pdf, cdf);
-}
-
-template <int T>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[T], const float* __restrict__ bias_lds, int h) {
-#pragma unroll
-  for (int to = 0; to < T; to++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[to][r] = bias_lds[32 * to + row_of(r, h)];
-}
-
-template <int T>
-__device__ __forceinline__ void apply_gelu(f32x16 (&acc)[T]) {
-#pragma unroll
-  for (int to = 0; to < T; to++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[to][r] = gelu_exact(acc[to][r]);
-}
-
-// out^T = W * in^T for register-resident activations (chained layout, see header).
-template <int TI, int TO>
-__device__ __forceinline__ void dense_chain(const f32x16 (&in)[TI], f32x16 (&out)[TO], const float* __restrict__ w_lds,
-                                            int lane) {
-#pragma unroll
-  for (int ti = 0; ti < TI; ti++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float b = in[ti][r];
-#pragma unroll
-      for (int to = 0; to < TO; to++) {
-        const float a = w_lds[((to * TI + ti) * 16 + r) * WS + lane];
-        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[to], 0, 0, 0);
-      }
-    }
 }
 
 // Forward of the whole net for one 32-sample tile; fills the hidden pre-activation free result in `hid`.

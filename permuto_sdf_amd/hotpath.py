@@ -11,7 +11,7 @@ import torch
 from . import _lib as L
 from . import parallel
 from .bridge import VolumeRendering as VR
-from .encoding import PermutoEncoding, _head, _tail, encode_backward_raw
+from .encoding import PermutoEncoding, encode_backward_raw, encode_forward_raw
 from .mlp import FusedMLP, mlp_backward_raw, mlp_forward_raw, pack_params
 
 
@@ -40,10 +40,13 @@ class SdfHotPath:
         cfg = self.enc.cfg
         pos = rs.samples_pos
         N = pos.shape[0]
-        feat = torch.empty((cfg.channels, N), dtype=torch.float32, device=self.dev)
-        L.call("psdf_encode_forward", *_head(cfg, N), L.ptr(pos), L.ptr(self.enc.lattice_values), L.ptr(self.enc.scale_factor),
-               L.ptr(self.enc.random_shift_per_level), L.ptr(self.window), *_tail(cfg), L.ptr(feat), L.stream())
         packed = pack_params(self.mlp.dims, [l.weight for l in self.mlp.layers], [l.bias for l in self.mlp.layers])
+        # Two launches on purpose: the level-major encode kernel keeps one 2-MiB table at a time in every XCD's L2 and
+        # runs at full occupancy, which measured faster than the single fused launch of csrc/fused.hip at this size
+        # (tools/fused_bench.py: 0.38 + 0.67 ms against 1.13 ms); the fused launch is used where its per-sample skip
+        # mask pays (sphere tracing).
+        feat = encode_forward_raw(cfg, pos, self.enc.lattice_values.detach(), self.enc.scale_factor,
+                                  self.enc.random_shift_per_level.detach(), self.window)
         sdf = mlp_forward_raw(self.mlp.dims, feat, packed)                    # [1, N] feature-major == [N,1] memory
         sdf_col = sdf.view(-1, 1)
         alpha = VR.sdf2alpha(rs, sdf_col, 512.0, True, 1.0)

@@ -11,6 +11,7 @@ import torch
 
 from . import _lib as L
 from .encoding import _head, _tail, encode_forward_raw
+from .fused import encode_mlp_forward_raw, fused_supported
 from .mlp import mlp_backward_raw, mlp_forward_raw, pack_params
 
 
@@ -22,10 +23,22 @@ class SphereTracer:
         self._graph = None
 
     # ---- building blocks -----------------------------------------------------------------------------------
-    def _sdf(self, pts, packed):
-        feat = encode_forward_raw(self.enc.cfg, pts, self.enc.lattice_values.detach(), self.enc.scale_factor,
-                                  self.enc.random_shift_per_level.detach(), self.window)
-        return feat, mlp_forward_raw(self.mlp.dims, feat, packed)          # [C,N], [out,N]
+    def _sdf(self, pts, dims, packed, skip=None, out=None, want_feat=False):
+        """SDF channel of the net at `pts` -> (feat [C,N] or None, sdf [1,N]).  Fused single launch when the encoding
+        is 3-D with 2 features per level (every reference model), otherwise encode + MLP."""
+        e = self.enc
+        args = (e.cfg, pts, e.lattice_values.detach(), e.scale_factor, e.random_shift_per_level.detach(), self.window)
+        if skip is not None and fused_supported(e.cfg, dims):
+            # single launch with the per-ray mask: tiles of converged rays cost nothing.  (Without a mask the two
+            # level-major/occupancy-friendly launches below are faster, tools/fused_bench.py.)
+            y, feat = encode_mlp_forward_raw(*args, dims, packed, skip=skip, want_feat=want_feat, out=out)
+            return feat, y
+        feat = encode_forward_raw(*args)
+        y = mlp_forward_raw(dims, feat, packed)
+        if out is not None:
+            out.copy_(y)
+            y = out
+        return feat, y
 
     def _grid_args(self):
         g = self.grid
@@ -44,22 +57,24 @@ class SphereTracer:
         occ = self.grid._occ()
         L.call("psdf_first_hit_dense", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(o), L.ptr(d), L.ptr(te), L.ptr(tx),
                L.ptr(pts), L.ptr(conv), L.stream())
-        ws = [l.weight for l in self.mlp.layers]
-        bs = [l.bias for l in self.mlp.layers]
-        packed = pack_params(self.mlp.dims, ws, bs)
+        # channel 0 of the last layer is the SDF (models.py:190-192); the geometry features are not needed to trace,
+        # so the net is evaluated with a 1-row head (same arithmetic for that row, 1/33 of the output traffic)
+        ws = [l.weight.detach() for l in self.mlp.layers]
+        bs = [l.bias.detach() for l in self.mlp.layers]
+        ws[-1], bs[-1] = ws[-1][0:1].contiguous(), bs[-1][0:1].contiguous()
+        dims = list(self.mlp.dims[:-1]) + [1]
+        packed = pack_params(dims, ws, bs)
+        sdf = torch.zeros((1, R), dtype=torch.float32, device=dev)
         for _ in range(nr_sphere_traces):
-            _, y = self._sdf(pts, packed)
-            sdf = y[0] if y.shape[0] > 1 else y.view(-1)                  # channel 0 is the SDF (models.py:190-192)
-            L.call("psdf_sphere_trace_step", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf.contiguous()),
+            self._sdf(pts, dims, packed, skip=conv.view(-1), out=sdf)     # tiles of converged rays are skipped
+            L.call("psdf_sphere_trace_step", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf),
                    L.c_f(sdf_multiplier), L.c_f(sdf_converged_tresh), L.ptr(pts), L.ptr(conv), L.stream())
-        feat, y = self._sdf(pts, packed)
-        sdf = y[0:1]
+        feat, sdf = self._sdf(pts, dims, packed, want_feat=return_gradients)
         grads = None
         if return_gradients:
-            # analytic normal: d sdf / d x = encode_backward_positions( mlp_backward_dX( e_0 ) )
-            gy = torch.zeros_like(y)
-            gy[0].fill_(1.0)
-            d_feat, _, _ = mlp_backward_raw(self.mlp.dims, feat, packed, gy, need_dx=True)
+            # analytic normal: d sdf / d x = encode_backward_positions( mlp_backward_dX( 1 ) )
+            gy = torch.ones_like(sdf)
+            d_feat, _, _ = mlp_backward_raw(dims, feat, packed, gy, need_dx=True)
             grads = torch.zeros((R, 3), dtype=torch.float32, device=dev)
             cfg = self.enc.cfg
             L.call("psdf_encode_backward", *_head(cfg, R), L.ptr(pts), L.ptr(self.enc.lattice_values.detach()),
