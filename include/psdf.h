@@ -59,9 +59,11 @@ int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, co
 int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y, void*
     stream);
 
-/* replaces: autograd backward of the same evaluators */
-int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, const float* dY,
-    float* dX, float* const* dW, float* const* db, void* stream);
+/* ---- mlp_bwd.hip ---- */
+/* replaces: autograd backward of the same evaluators (dX, dW_l, db_l in one launch; forward recomputed from X).
+   weights[l]/biases[l]: torch-layout parameters; dW[l]/db[l] are accumulated into (caller zero-fills) */
+int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights, const
+    float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 
 /* ---- fused.hip ---- */
 /* replaces: models.py:186-192 `point_features=self.encoding(points, window); sdf_and_feat=self.mlp_sdf(point_features)`

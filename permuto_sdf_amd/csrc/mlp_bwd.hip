@@ -1,0 +1,594 @@
+// Fused small-MLP BACKWARD for gfx950: dX, dW_l, db_l of Linear/GELU stacks in ONE kernel.
+// Autograd backward of the reference's torch.nn.Sequential(Linear, GELU, ...) evaluators
+// (permuto_sdf_py/models/models.py:153-161 SDF net, :451-470 background nets) and of the BASELINE 64x3 net.
+//
+// Design (third version; the two earlier ones are kept under tools/rejected/ with their measurements):
+//   * 16-sample tiles, v_mfma_f32_16x16x4_f32.  Same FLOP/cycle as the 32x32x2 instruction, but the per-wave state of
+//     a tile (activations and their derivatives of three 64-wide layers) is 96 registers instead of 192.
+//   * The weight gradient dW_l = dZ_l^T H_{l-1} is a product whose k dimension is the SAMPLE index, so its MFMA
+//     accumulators can simply stay in registers for the whole life of the wave: every tile adds into them with the
+//     accumulate operand of the instruction.  176 registers for the 36-64-64-64-1 net; with the tile state that fits
+//     the 512-register file at one wave per SIMD without scratch.  Nothing is exchanged between waves in the tile
+//     loop: no barriers, no LDS atomics (ds_add_f32 costs ~196 cycles per wave instruction on this chip,
+//     tools/atomic_bench.hip -- the first version spent 90 % of its time there), no staging.
+//   * Each activation is visited ONCE: gelu(z) and gelu'(z) come out of one erf + one exp evaluation and are kept;
+//     z itself is dropped.
+//   * The forward is recomputed from X (the encoding output) -- nothing but X is saved by the forward pass.
+//   * At the end every wave adds its accumulators into a workgroup image in LDS (once per launch, so the slow LDS
+//     atomics do not matter) and the workgroup flushes that image with one global atomic per parameter.
+//
+// Layouts (lane l: g = l>>4, c = l&15):
+//   MFMA 16x16x4:  A[i=c][k=g],  B[k=g][j=c],  D reg r = D[row 4g+r][col c]
+//   "T" tile  (chain layout):  lane (g, c=sample), reg r = value(neuron 16t+4g+r, sample c)
+//             -> register r of a T tile IS the B operand of k-step (t, r) of the next layer: no data movement;
+//   "NT" tile (lane = neuron): lane (g, c=neuron), reg r = value(neuron 16t+c, sample 4g+r)
+//             -> A (dZ) and B (H) operands of dW; obtained from a T tile by one 16x17-float LDS transpose per wave.
+//   weights in LDS: chain layer  Wp[((to*TI+ti)*4 + r)*65 + lane] = W[16to + c][16ti + 4g + r]
+//                   layer 0      Wp[(to*S0 + s)*65 + lane]        = W[16to + c][4s + g]
+//   The same image serves the data-gradient chain (A operand = W^T) through a transposed read (2-way bank conflict).
+//   The image is built by the kernel itself from the torch-layout parameters (no separate packing pass).
+#include "mlp_device.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct Plan16 {
+  int n_layers;
+  int dims[MAXL + 1];
+  int tiles[MAXL + 1];  // ceil(dims/16); tiles[0] = input tiles
+  int steps0;           // ceil(dims[0]/4)
+  int w_off[MAXL], b_off[MAXL];
+  int total;
+  int final_dot;
+};
+
+int make_plan16(int n_layers, const int* dims, Plan16& p) {
+  if (n_layers < 2 || n_layers > MAXL) return PSDF_ERR_ARG;
+  p.n_layers = n_layers;
+  for (int i = 0; i <= n_layers; i++) {
+    if (dims[i] <= 0) return PSDF_ERR_ARG;
+    p.dims[i] = dims[i];
+    p.tiles[i] = (dims[i] + 15) / 16;
+  }
+  p.steps0 = (dims[0] + 3) / 4;
+  p.final_dot = dims[n_layers] <= 4;
+  int off = 0;
+  for (int l = 0; l < n_layers; l++) {
+    const bool last = l == n_layers - 1;
+    p.w_off[l] = off;
+    if (l == 0)
+      off += p.tiles[1] * p.steps0 * WS;
+    else if (last && p.final_dot)
+      off += dims[n_layers] * p.tiles[l] * 16;
+    else
+      off += p.tiles[l + 1] * p.tiles[l] * 4 * WS;
+    p.b_off[l] = off;
+    off += (last && p.final_dot) ? 4 : p.tiles[l + 1] * 16;
+  }
+  p.total = off;
+  return PSDF_OK;
+}
+
+// image index -> (layer, row, col | bias row); row/col may be out of range (padding)
+__device__ __forceinline__ void unpack_index(const Plan16& p, int e, int& l, int& row, int& col, bool& is_bias) {
+  l = 0;
+#pragma unroll
+  for (int i = 1; i < MAXL; i++)
+    if (i < p.n_layers && e >= p.w_off[i]) l = i;
+  const bool last = l == p.n_layers - 1;
+  is_bias = e >= p.b_off[l];
+  if (is_bias) {
+    row = e - p.b_off[l];
+    col = 0;
+    return;
+  }
+  const int q = e - p.w_off[l];
+  if (l == 0) {
+    const int lane = q % WS, s = (q / WS) % p.steps0, to = (q / WS) / p.steps0;
+    row = lane < 64 ? 16 * to + (lane & 15) : (1 << 20);
+    col = 4 * s + (lane >> 4);
+  } else if (last && p.final_dot) {  // [o][ti][r][g]
+    const int g = q & 3, r = (q >> 2) & 3, ti = (q >> 4) % p.tiles[l], o = (q >> 4) / p.tiles[l];
+    row = o;
+    col = 16 * ti + 4 * g + r;
+  } else {
+    const int lane = q % WS, r = (q / WS) & 3, ti = (q / (WS * 4)) % p.tiles[l], to = (q / (WS * 4)) / p.tiles[l];
+    row = lane < 64 ? 16 * to + (lane & 15) : (1 << 20);
+    col = 16 * ti + 4 * (lane >> 4) + r;
+  }
+}
+
+struct BwdPtrs {
+  const float* W[MAXL];
+  const float* b[MAXL];
+  float* dW[MAXL];
+  float* db[MAXL];
+};
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int T>
+__device__ __forceinline__ void init_bias16(f32x4 (&acc)[T], const float* __restrict__ b_lds, int g) {
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[t][r] = b_lds[16 * t + 4 * g + r];
+}
+template <int T>
+__device__ __forceinline__ void zero16(f32x4 (&a)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) a[t][r] = 0.f;
+}
+
+// z -> (gelu(z), gelu'(z)) with one erf and one exp; same formulas as gelu_exact / gelu_grad (mlp_device.h)
+template <int T>
+__device__ __forceinline__ void gelu_both(const f32x4 (&z)[T], f32x4 (&h)[T], f32x4 (&dg)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float x = z[t][r];
+      const float one_erf = 1.0f + erf_fast(x * 0.70710678118654752440f);
+      h[t][r] = 0.5f * x * one_erf;
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      dg[t][r] = fmaf(x, pdf, 0.5f * one_erf);
+    }
+}
+
+// out^T = W * in^T  (chain layout)
+template <int TI, int TO>
+__device__ __forceinline__ void chain_fwd(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* __restrict__ w, int lane) {
+#pragma unroll
+  for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float b = in[ti][r];
+#pragma unroll
+      for (int to = 0; to < TO; to++) out[to] = MFMA16(w[((to * TI + ti) * 4 + r) * WS + lane], b, out[to]);
+    }
+}
+// dh^T[in] += W^T dz^T[out]  (transposed read of the same image)
+template <int TO, int TI>
+__device__ __forceinline__ void chain_bwd(const f32x4 (&dz)[TO], f32x4 (&dh)[TI], const float* __restrict__ w, int g, int c) {
+  const int lane_off = (c & 3) * WS + (c >> 2) * 16 + 4 * g;
+#pragma unroll
+  for (int to = 0; to < TO; to++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float b = dz[to][r];
+#pragma unroll
+      for (int ti = 0; ti < TI; ti++) dh[ti] = MFMA16(w[(to * TI + ti) * 4 * WS + lane_off + r], b, dh[ti]);
+    }
+}
+// Cross-LANE exchange through LDS: the compiler proves that, for ONE thread, the write of register r and the read of
+// register r' != r never alias and interleaves them freely across __builtin_amdgcn_wave_barrier() (which is not a
+// memory barrier for LLVM).  A wavefront-scope fence pair is: it costs no instruction (LDS is in order within a wave).
+#define NT_FENCE()                                         \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+// T tile -> NT tile through a 16x17 LDS buffer private to the wave
+// (`buf` must NOT be __restrict__: that would tell LLVM nothing else -- not even a fence -- touches it.)
+__device__ __forceinline__ void to_nt(const f32x4& in, f32x4& out, float* buf, int g, int c) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) buf[(4 * g + r) * 17 + c] = in[r];
+  NT_FENCE();
+#pragma unroll
+  for (int r = 0; r < 4; r++) out[r] = buf[c * 17 + 4 * g + r];
+  NT_FENCE();
+}
+
+// Persistent accumulators of one chain layer: aw[to][ti] (reg q) = dW[16to+4g+q][16ti+c], ab[to] = per-lane partial of
+// db[16to+c] (summed over g at the end).
+template <int TO, int TI>
+struct LayerAcc {
+  f32x4 aw[TO][TI];
+  float ab[TO];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int to = 0; to < TO; to++) {
+      ab[to] = 0.f;
+#pragma unroll
+      for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) aw[to][ti][q] = 0.f;
+    }
+  }
+  // aw += dz_nt x hin_nt over the 16 samples of the tile
+  __device__ __forceinline__ void add(const f32x4 (&dz_nt)[TO], const f32x4 (&hin_nt)[TI]) {
+#pragma unroll
+    for (int to = 0; to < TO; to++) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) aw[to][ti] = MFMA16(dz_nt[to][s], hin_nt[ti][s], aw[to][ti]);
+      ab[to] += (dz_nt[to][0] + dz_nt[to][1]) + (dz_nt[to][2] + dz_nt[to][3]);
+    }
+  }
+  // once per wave: into the workgroup image (chain-layer layout)
+  __device__ __forceinline__ void flush_chain(float* __restrict__ acc_w, float* __restrict__ acc_b, int g, int c) {
+    const int lane_off = (c & 3) * WS + (c >> 2) * 16 + 4 * g;
+#pragma unroll
+    for (int to = 0; to < TO; to++) {
+#pragma unroll
+      for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) atomicAdd(acc_w + (to * TI + ti) * 4 * WS + lane_off + q, aw[to][ti][q]);
+      float sb = ab[to];
+      sb += __shfl_xor(sb, 16, 64);
+      sb += __shfl_xor(sb, 32, 64);
+      if (g == 0) atomicAdd(acc_b + 16 * to + c, sb);
+    }
+  }
+  // layer 0 image layout: [(to*S0 + 4t + c>>2)][(c&3)*16 + 4g + q]
+  __device__ __forceinline__ void flush_layer0(float* __restrict__ acc_w, float* __restrict__ acc_b, int S0, int g, int c) {
+#pragma unroll
+    for (int to = 0; to < TO; to++) {
+#pragma unroll
+      for (int t = 0; t < TI; t++) {
+        if ((4 * t + (c >> 2)) < S0) {
+          float* base = acc_w + (to * S0 + 4 * t + (c >> 2)) * WS + (c & 3) * 16 + 4 * g;
+#pragma unroll
+          for (int q = 0; q < 4; q++) atomicAdd(base + q, aw[to][t][q]);
+        }
+      }
+      float sb = ab[to];
+      sb += __shfl_xor(sb, 16, 64);
+      sb += __shfl_xor(sb, 32, 64);
+      if (g == 0) atomicAdd(acc_b + 16 * to + c, sb);
+    }
+  }
+};
+
+constexpr int BW = 4;  // waves per workgroup (one per SIMD: the kernel wants the whole 512-register file)
+
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool NEED_DX>
+__global__ void __launch_bounds__(BW * 64)
+    mlp_bwd_kernel(Plan16 p, int64_t N, const float* __restrict__ X, const float* __restrict__ dY,
+                   float* __restrict__ dX, BwdPtrs a) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int SX = 4 * TI0;                       // k-steps of layer 0 (upper bound of p.steps0)
+  constexpr int WAVE_LDS = 16 * 17 + 16 + 2 * SX * 64;
+  const int img = (p.total + 3) & ~3;
+  float* tbuf = lds + img + wave * WAVE_LDS;        // 16x17 transpose buffer
+  float* dyb = tbuf + 16 * 17;                      // 16 floats
+  float* xbuf = dyb + 16;                           // 2 x [SX][64]: layer-0 operand tiles landed by LDS-DMA
+  for (int e = threadIdx.x; e < p.total; e += BW * 64) {
+    int l, row, col;
+    bool is_bias;
+    unpack_index(p, e, l, row, col, is_bias);
+    float v = 0.f;
+    if (is_bias) {
+      if (row < p.dims[l + 1]) v = a.b[l][row];
+    } else if (row < p.dims[l + 1] && col < p.dims[l]) {
+      v = a.W[l][(int64_t)row * p.dims[l] + col];
+    }
+    lds[e] = v;
+  }
+  __syncthreads();
+  const int g = lane >> 4, c = lane & 15;
+  const int K0 = p.dims[0], OUT = p.dims[p.n_layers], S0 = p.steps0;
+  constexpr int TL = (T3 > 0) ? T3 : T2;
+  constexpr int T3S = (T3 > 0) ? T3 : 1;      // storage sizes for the (absent) third hidden layer
+  constexpr int OTS = FINAL_DOT ? 1 : OUT_T;
+  const int lf = p.n_layers - 1;
+
+  LayerAcc<T1, TI0> acc0;
+  LayerAcc<T2, T1> acc1;
+  LayerAcc<T3S, T2> acc2;
+  LayerAcc<OTS, TL> acco;      // MFMA output layer
+  float accf[4][TL];           // VALU (dot) output layer: per-lane partial of dW[o][16t+c]
+  float accfb[4];
+  acc0.zero();
+  acc1.zero();
+  acc2.zero();
+  acco.zero();
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    accfb[o] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TL; t++) accf[o][t] = 0.f;
+  }
+
+  {  // ---- scope of the read-only weight image
+  const float* __restrict__ W = lds;
+  // The wave runs alone on its SIMD (register budget), so nothing hides a memory latency for it.  The layer-0 operand
+  // of the NEXT tile is therefore requested at the top of the current one with global_load_lds (memory -> LDS without
+  // passing through registers: lane (g,c) of k-step s fetches X[4s+g][sample c] to xbuf[s][lane]); a tile later it is
+  // read back both as the forward B operand and, transposed, as the B operand of dW0 (so X is read from HBM once).
+  auto prefetch = [&](int64_t t, float* buf) {
+    int64_t n = t * 16 + c;
+    n = n < N ? n : N - 1;
+    for (int s = 0; s < S0; s++) {
+      int k = 4 * s + g;
+      k = k < K0 ? k : K0 - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)k * N + n),
+                                       (__attribute__((address_space(3))) void*)(buf + s * 64), 4, 0, 0);
+    }
+  };
+  const int64_t ntiles = (N + 15) / 16;
+  const int64_t tile0 = (int64_t)blockIdx.x * BW + wave, tstride = (int64_t)gridDim.x * BW;
+  if (tile0 < ntiles) prefetch(tile0, xbuf);
+  int cur = 0;
+  for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
+    // the compiler does not track LDS-DMA completion: wait for the tile requested one iteration ago (this is also a
+    // compiler barrier that keeps the LDS weight reads inside the tile loop)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* xb = xbuf + cur * (SX * 64);
+    if (tile + tstride < ntiles) prefetch(tile + tstride, xbuf + (cur ^ 1) * (SX * 64));
+    const int64_t n = tile * 16 + c;
+    const bool live = n < N;
+    // ---------------------------------------------------------------- forward: activations and their derivatives
+    f32x4 h1[T1], d1[T1], h2[T2], d2[T2], h3[T3S], d3[T3S];
+    {
+      f32x4 z[T1];
+      init_bias16<T1>(z, W + p.b_off[0], g);
+      for (int s = 0; s < S0; s++) {
+        const float xv = xb[s * 64 + lane];
+        const float b = (4 * s + g < K0 && live) ? xv : 0.f;
+#pragma unroll
+        for (int to = 0; to < T1; to++) z[to] = MFMA16(W[p.w_off[0] + (to * S0 + s) * WS + lane], b, z[to]);
+      }
+      gelu_both<T1>(z, h1, d1);
+    }
+    {
+      f32x4 z[T2];
+      init_bias16<T2>(z, W + p.b_off[1], g);
+      chain_fwd<T1, T2>(h1, z, W + p.w_off[1], lane);
+      gelu_both<T2>(z, h2, d2);
+    }
+    if constexpr (T3 > 0) {
+      f32x4 z[T3S];
+      init_bias16<T3S>(z, W + p.b_off[2], g);
+      chain_fwd<T2, T3S>(h2, z, W + p.w_off[2], lane);
+      gelu_both<T3S>(z, h3, d3);
+    }
+    // ---------------------------------------------------------------- output layer
+    f32x4 dhl[TL];
+    zero16<TL>(dhl);
+    {
+      f32x4 hl_nt[TL];
+#pragma unroll
+      for (int t = 0; t < TL; t++) {
+        if constexpr (T3 > 0)
+          to_nt(h3[t], hl_nt[t], tbuf, g, c);
+        else
+          to_nt(h2[t], hl_nt[t], tbuf, g, c);
+      }
+      if constexpr (FINAL_DOT) {
+        const float* __restrict__ wf = W + p.w_off[lf];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+          if (o < OUT) {
+            const float dy = live ? dY[(int64_t)o * N + n] : 0.f;
+#pragma unroll
+            for (int t = 0; t < TL; t++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) dhl[t][r] = fmaf(wf[((o * TL + t) * 4 + r) * 4 + g], dy, dhl[t][r]);
+            if (g == 0) dyb[c] = dy;
+            NT_FENCE();
+#pragma unroll
+            for (int t = 0; t < TL; t++) {
+              float pr = 0.f;
+#pragma unroll
+              for (int r = 0; r < 4; r++) pr = fmaf(hl_nt[t][r], dyb[4 * g + r], pr);
+              accf[o][t] += pr;
+            }
+            accfb[o] += (g == 0) ? dy : 0.f;
+            NT_FENCE();
+          }
+        }
+      } else {
+        f32x4 dyT[OTS];
+#pragma unroll
+        for (int to = 0; to < OTS; to++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = 16 * to + 4 * g + r;
+            dyT[to][r] = (row < OUT && live) ? dY[(int64_t)row * N + n] : 0.f;
+          }
+        chain_bwd<OTS, TL>(dyT, dhl, W + p.w_off[lf], g, c);
+        f32x4 dy_nt[OTS];
+#pragma unroll
+        for (int to = 0; to < OTS; to++) to_nt(dyT[to], dy_nt[to], tbuf, g, c);
+        acco.add(dy_nt, hl_nt);
+      }
+    }
+    // ---------------------------------------------------------------- hidden layers, last to first
+    f32x4 dh2[T2];
+    if constexpr (T3 > 0) {
+#pragma unroll
+      for (int t = 0; t < T3S; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dhl[t][r] = dhl[t][r] * d3[t][r];  // dZ3
+      {
+        f32x4 dz_nt[T3S], hin_nt[T2];
+#pragma unroll
+        for (int t = 0; t < T3S; t++) to_nt(dhl[t], dz_nt[t], tbuf, g, c);
+#pragma unroll
+        for (int t = 0; t < T2; t++) to_nt(h2[t], hin_nt[t], tbuf, g, c);
+        acc2.add(dz_nt, hin_nt);
+      }
+      zero16<T2>(dh2);
+      chain_bwd<T3S, T2>(dhl, dh2, W + p.w_off[2], g, c);
+    } else {
+#pragma unroll
+      for (int t = 0; t < T2; t++) dh2[t] = dhl[t];
+    }
+#pragma unroll
+    for (int t = 0; t < T2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) dh2[t][r] = dh2[t][r] * d2[t][r];  // dZ2
+    {
+      f32x4 dz_nt[T2], hin_nt[T1];
+#pragma unroll
+      for (int t = 0; t < T2; t++) to_nt(dh2[t], dz_nt[t], tbuf, g, c);
+#pragma unroll
+      for (int t = 0; t < T1; t++) to_nt(h1[t], hin_nt[t], tbuf, g, c);
+      acc1.add(dz_nt, hin_nt);
+    }
+    f32x4 dh1[T1];
+    zero16<T1>(dh1);
+    chain_bwd<T2, T1>(dh2, dh1, W + p.w_off[1], g, c);
+#pragma unroll
+    for (int t = 0; t < T1; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) dh1[t][r] = dh1[t][r] * d1[t][r];  // dZ1
+    {
+      // dW0[out][k] = sum_s dZ1[out][s] X[k][s]:  A = dZ1 NT, B = X NT = transposed read of the staged tile
+      // (lane (g, c): feature k = 16t+c lives at k-step 4t + c>>2, row c&3; its samples 4g..4g+3 are contiguous)
+      f32x4 dz_nt[T1], x_nt[TI0];
+#pragma unroll
+      for (int t = 0; t < T1; t++) to_nt(dh1[t], dz_nt[t], tbuf, g, c);
+      const int64_t n0 = tile * 16 + 4 * g;
+#pragma unroll
+      for (int t = 0; t < TI0; t++) {
+        const int k = 16 * t + c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (4 * t + (c >> 2)) * 64 + (c & 3) * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) x_nt[t][r] = (k < K0 && n0 + r < N) ? v[r] : 0.f;
+      }
+      acc0.add(dz_nt, x_nt);
+    }
+    if constexpr (NEED_DX) {
+#pragma unroll
+      for (int t = 0; t < TI0; t++) {
+        f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+        const int s = 4 * t + (c >> 2);
+        const bool colok = s < S0;
+        const float* __restrict__ wrow = W + p.w_off[0] + s * WS + (c & 3) * 16 + 4 * g;
+#pragma unroll
+        for (int to = 0; to < T1; to++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float wv = colok ? wrow[to * S0 * WS + r] : 0.f;  // W0[16to + 4g + r][16t + c]
+            dx = MFMA16(wv, dh1[to][r], dx);
+          }
+        if (live) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int k = 16 * t + 4 * g + q;
+            if (k < K0) dX[(int64_t)k * N + n] = dx[q];
+          }
+        }
+      }
+    }
+  }
+  }  // ---- end of the weight image scope
+  // ---------------------------------------------------------------- wave accumulators -> workgroup image -> global
+  // (the weight image is dead once every wave has left the tile loop: the gradient image takes its place)
+  __syncthreads();
+  float* ACC = lds;
+  for (int e = threadIdx.x; e < p.total; e += BW * 64) ACC[e] = 0.f;
+  __syncthreads();
+  acc0.flush_layer0(ACC + p.w_off[0], ACC + p.b_off[0], S0, g, c);
+  acc1.flush_chain(ACC + p.w_off[1], ACC + p.b_off[1], g, c);
+  if constexpr (T3 > 0) acc2.flush_chain(ACC + p.w_off[2], ACC + p.b_off[2], g, c);
+  if constexpr (FINAL_DOT) {
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      if (o < OUT) {
+#pragma unroll
+        for (int t = 0; t < TL; t++) {
+          float pr = accf[o][t];
+          pr += __shfl_xor(pr, 16, 64);
+          pr += __shfl_xor(pr, 32, 64);
+          // neuron 16t + c sits at [o][t][r = c&3][g = c>>2]
+          if (g == 0) atomicAdd(ACC + p.w_off[lf] + ((o * TL + t) * 4 + (c & 3)) * 4 + (c >> 2), pr);
+        }
+        const float sb = psdf::wave_sum(accfb[o]);
+        if (lane == 0) atomicAdd(ACC + p.b_off[lf] + o, sb);
+      }
+    }
+  } else {
+    acco.flush_chain(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < p.total; e += BW * 64) {
+    const float v = ACC[e];
+    if (v == 0.f) continue;
+    int l, row, col;
+    bool is_bias;
+    unpack_index(p, e, l, row, col, is_bias);
+    if (is_bias) {
+      if (row < p.dims[l + 1]) atomicAdd(a.db[l] + row, v);
+    } else if (row < p.dims[l + 1] && col < p.dims[l]) {
+      atomicAdd(a.dW[l] + (int64_t)row * p.dims[l] + col, v);
+    }
+  }
+}
+
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
+  const size_t shmem = ((size_t)((p.total + 3) & ~3) + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
+  if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
+  const int64_t ntiles = (N + 15) / 16;
+  int64_t blocks = (ntiles + BW - 1) / BW;
+  if (blocks > 256) blocks = 256;  // one workgroup per CU, one wave per SIMD; each wave walks many tiles
+#define GO(DX)                                                                                                     \
+  do {                                                                                                             \
+    auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, DX>;                                              \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
+    if (e != hipSuccess) return (int)e;                                                                            \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, dY, dX, a);                  \
+  } while (0)
+  if (dX)
+    GO(true);
+  else
+    GO(false);
+#undef GO
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Backward of psdf_mlp_forward.  weights[l] / biases[l]: the torch-layout parameters (W_l [dims[l+1], dims[l]]);
+// X [dims[0], N], dY [dims[n_layers], N] and dX [dims[0], N] (or NULL) are feature-major; dW[l] (torch layout) and
+// db[l] are ACCUMULATED INTO (caller zero-fills).
+int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                      const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                      void* stream) {
+  Plan16 p;
+  int rc = make_plan16(n_layers, dims, p);
+  if (rc != PSDF_OK) return rc;
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !X || !weights || !biases || !dY || !dW || !db) return PSDF_ERR_ARG;
+  if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
+  BwdPtrs a;
+  for (int l = 0; l < MAXL; l++) {
+    a.W[l] = l < n_layers ? weights[l] : nullptr;
+    a.b[l] = l < n_layers ? biases[l] : nullptr;
+    a.dW[l] = l < n_layers ? dW[l] : nullptr;
+    a.db[l] = l < n_layers ? db[l] : nullptr;
+    if (l < n_layers && (!a.W[l] || !a.b[l] || !a.dW[l] || !a.db[l])) return PSDF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ti0 = p.tiles[0], t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0,
+            to = p.tiles[n_layers];
+#define CASE(I, A, B, C, O, D)                                                   \
+  if (ti0 == I && t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
+    return launch_bwd<I, A, B, C, O, D>(p, N, X, dY, dX, a, st);
+  CASE(3, 4, 4, 4, 1, true)   // 33..48 -> 64x3 -> 1..4   (BASELINE SDF net on a 16-level encoding)
+  CASE(4, 4, 4, 4, 1, true)   // 49..64 -> 64x3 -> 1..4   (24-level encoding)
+  CASE(2, 4, 4, 4, 1, true)   // 17..32 -> 64x3 -> 1..4   (small encodings)
+  CASE(4, 2, 2, 2, 1, true)   // 49..64 -> 32x3 -> 1..4
+  CASE(3, 2, 2, 2, 1, true)   // 33..48 -> 32x3 -> 1..4
+  CASE(2, 2, 2, 2, 1, true)   // 17..32 -> 32x3 -> 1..4
+  CASE(4, 2, 2, 2, 3, false)  // 52 -> 32x3 -> 33         (reference SDF net, models.py:153-161)
+  CASE(4, 4, 4, 4, 5, false)  // 52 -> 64x3 -> 65         (background density net, models.py:451-459)
+  CASE(4, 4, 4, 4, 3, false)  // 52 -> 64x3 -> 33
+  CASE(5, 4, 4, 0, 1, true)   // 80 -> 64x2 -> 3          (background colour head, models.py:463-469)
+#undef CASE
+  return PSDF_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

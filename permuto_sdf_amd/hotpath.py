@@ -73,7 +73,8 @@ class SdfHotPath:
             grad_sdf = torch.ones((1, N), dtype=torch.float32, device=self.dev)
         if self.events is not None:
             self.events["mlp_bwd"][0].record()
-        d_feat, dWs, dbs = mlp_backward_raw(self.mlp.dims, saved["feat"], saved["packed"], grad_sdf, need_dx=True)
+        d_feat, dWs, dbs = mlp_backward_raw(self.mlp.dims, saved["feat"], [l.weight for l in self.mlp.layers],
+                                            [l.bias for l in self.mlp.layers], grad_sdf, need_dx=True)
         if self.events is not None:
             self.events["mlp_bwd"][1].record()
         buckets = parallel.GradientBuckets()

@@ -47,17 +47,22 @@ def mlp_forward_raw(dims, x_fm, packed):
     return y
 
 
-def mlp_backward_raw(dims, x_fm, packed, gy_fm, need_dx=True):
-    """-> (dx_fm [dims[0], N] or None, [dW_l], [db_l])"""
+def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True):
+    """weights/biases: the torch-layout parameters (the backward kernel builds its own LDS image from them)
+    -> (dx_fm [dims[0], N] or None, [dW_l], [db_l])"""
     N = x_fm.shape[1]
     n_layers = len(dims) - 1
     dev = x_fm.device
+    ws = [w.detach().contiguous() for w in weights]
+    bs = [b.detach().contiguous() for b in biases]
     dx = torch.empty((dims[0], N), dtype=torch.float32, device=dev) if need_dx else None
     dWs = [torch.zeros((dims[l + 1], dims[l]), dtype=torch.float32, device=dev) for l in range(n_layers)]
     dbs = [torch.zeros((dims[l + 1],), dtype=torch.float32, device=dev) for l in range(n_layers)]
+    Wp = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
+    Bp = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
     W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
     B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
-    L.call("psdf_mlp_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(gy_fm),
+    L.call("psdf_mlp_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), Wp, Bp, L.ptr(gy_fm),
            L.ptr(dx), W, B, L.stream())
     return dx, dWs, dbs
 
@@ -73,17 +78,20 @@ class _FusedMLPFunc(torch.autograd.Function):
         packed = pack_params(module.dims, weights, biases)
         y = mlp_forward_raw(module.dims, x_fm, packed)
         ctx.module = module
-        ctx.save_for_backward(x_fm, packed)
+        ctx.n_layers = n_layers
+        ctx.save_for_backward(x_fm, *weights, *biases)
         return y.t()
 
     @staticmethod
     def backward(ctx, gy):
         module = ctx.module
-        x_fm, packed = ctx.saved_tensors
+        x_fm = ctx.saved_tensors[0]
+        weights = ctx.saved_tensors[1:1 + ctx.n_layers]
+        biases = ctx.saved_tensors[1 + ctx.n_layers:]
         gy_fm = gy.t()
         if not gy_fm.is_contiguous():
             gy_fm = gy_fm.contiguous()
-        dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, packed, gy_fm, need_dx=ctx.needs_input_grad[1])
+        dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=ctx.needs_input_grad[1])
         return (None, dx.t() if dx is not None else None, *dWs, *dbs)
 
 
