@@ -87,6 +87,66 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // entry which already existed).
 constexpr uint32_t SC_EMPTY = 0xFFFFFFFFu;
 
+// LDS float accumulation without ds_add_f32.  Measured on this chip (tools/atomic_bench.hip): a wave-wide ds_add_f32
+// costs ~197 cycles whatever the access pattern (1 lane per ~3 cycles), while INTEGER LDS atomics run at LDS speed
+// (ds_add_u32 10 cycles, ds_cmpst_rtn_b32 12, ds_add_u64 16, plain 8-byte read-modify-write 18).  So a pair of
+// floats is added with one 64-bit compare-and-swap: read, add in registers, ds_cmpst_rtn_b64; lanes that lose the
+// race (another lane or wave changed the pair) retry up to 3 times, and whatever is still pending after that -- heavy
+// same-address contention, where the constant-cost float atomic is the better tool -- falls back to ds_add_f32.
+// `hot` remembers that fallback per thread for a few adds so that a contended stream stops paying for doomed attempts.
+__device__ __forceinline__ void lds_add_pair(float* p, float a, float b, int& hot) {
+  if (hot == 0) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    unsigned long long old = *q;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {  // k lanes of a wave on one pair need k rounds: covers multiplicity <= 4
+      const float x = __uint_as_float((uint32_t)old) + a;
+      const float y = __uint_as_float((uint32_t)(old >> 32)) + b;
+      const unsigned long long want = (unsigned long long)__float_as_uint(x) | ((unsigned long long)__float_as_uint(y) << 32);
+      const unsigned long long prev = atomicCAS(q, old, want);
+      if (prev == old) return;
+      old = prev;
+    }
+    hot = 8;  // heavily shared pair: use the float atomic for the next few adds, then probe again
+  } else {
+    hot--;
+  }
+  atomicAdd(p, a);
+  atomicAdd(p + 1, b);
+}
+
+// Adjacent lanes are adjacent samples of a ray, and at coarse and medium levels they sit in the same simplex: their
+// contributions go to the same rows.  Such runs of equal rows are summed in registers (segmented inclusive scan
+// inside each 16-lane DPP row, Hillis-Steele with head flags) and only the LAST lane of a run hands the sum on, so
+// that what reaches LDS has a multiplicity of at most 4 per wave -- within reach of the retries of lds_add_pair.
+// Returns true on the lanes that own a (partial) run sum.
+template <int F>
+__device__ __forceinline__ bool combine_runs16(uint32_t key, bool valid, float (&v)[F]) {
+  constexpr int ROW_SHR = 0x110, ROW_SHL = 0x100;
+  const int k = valid ? (int)key : -1 - (int)psdf::lane_id();  // invalid lanes never match a neighbour
+  const int kprev = __builtin_amdgcn_update_dpp(-1000, k, ROW_SHR | 1, 0xf, 0xf, false);
+  const int head = (kprev != k) ? 1 : 0;  // first lane of a row: kprev = -1000 -> head
+  int f = head;
+#define PSDF_SCAN_STEP(D)                                                                                        \
+  {                                                                                                              \
+    const int f2 = __builtin_amdgcn_update_dpp(1, f, ROW_SHR | D, 0xf, 0xf, false);                              \
+    float v2[F];                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < F; i++) v2[i] =                                                        \
+        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), ROW_SHR | D, 0xf, 0xf, false));      \
+    if (!f) {                                                                                                    \
+      _Pragma("unroll") for (int i = 0; i < F; i++) v[i] = v[i] + v2[i];                                         \
+      f = f2;                                                                                                    \
+    }                                                                                                            \
+  }
+  PSDF_SCAN_STEP(1)
+  PSDF_SCAN_STEP(2)
+  PSDF_SCAN_STEP(4)
+  PSDF_SCAN_STEP(8)
+#undef PSDF_SCAN_STEP
+  const int next_head = __builtin_amdgcn_update_dpp(1, head, ROW_SHL | 1, 0xf, 0xf, false);  // last lane of a row: 1
+  return valid && next_head != 0;
+}
+
 template <int F>
 struct ScatterCache {
   static constexpr int SC_SLOTS = 8192 / F;  // F=2: 16 KiB tags + 32 KiB sums
@@ -108,13 +168,14 @@ struct ScatterCache {
   }
   // 0: slot taken by another row (caller adds to HBM / queues); 1: absorbed, claimed an empty slot;
   // 2: absorbed into an entry that already existed (a genuine re-use: what the adaptive vote counts)
-  __device__ __forceinline__ int add(uint32_t row, const float* v) {
+  __device__ __forceinline__ int add(uint32_t row, const float* v, int& hot) {
     const uint32_t slot = (row ^ (row >> 12)) & (SC_SLOTS - 1);
     uint32_t old = tags[slot];
     if (old == SC_EMPTY) old = atomicCAS(&tags[slot], SC_EMPTY, row);
     if (old == SC_EMPTY || old == row) {
+      static_assert(F % 2 == 0, "pairs");
 #pragma unroll
-      for (int f = 0; f < F; f++) atomicAdd(&sums[slot * F + f], v[f]);
+      for (int f = 0; f < F; f += 2) lds_add_pair(&sums[slot * F + f], v[f], v[f + 1], hot);
       return old == row ? 2 : 1;
     }
     return 0;
@@ -206,6 +267,59 @@ __device__ __forceinline__ void queue_push(const Queues& Q, int level, int* q_cn
   }
 }
 
+// Same hand-off with COALESCED stores, for workgroups whose scatter cache is switched off (its 48 KiB of LDS are free):
+// a direct append makes every lane of a store instruction hit a different partition's queue, and the address
+// processing of such scattered 2-/8-byte stores (one lane per cycle per CU) was the limiter of the binning kernel.
+// Here the contributions of the super-tile are first laid out in LDS grouped by partition (counting sort: the slot
+// inside the group comes from the same LDS counter that reserves the queue segment), then written out linearly, so a
+// wave writes 64 consecutive queue entries.
+template <int NC>
+__device__ __forceinline__ void queue_push_staged(const Queues& Q, int level, int* q_cnt, int* q_base, int* q_off,
+                                                  float* stage, const bool (&pending)[NC], const uint32_t (&crow)[NC],
+                                                  const float (&cval)[NC][2], float* __restrict__ table_grad) {
+  uint32_t* st_row = reinterpret_cast<uint32_t*>(stage);                 // [NC * PSDF_BLOCK]
+  float2* st_val = reinterpret_cast<float2*>(stage + NC * PSDF_BLOCK);   // [NC * PSDF_BLOCK]
+  if (threadIdx.x < Q.np) q_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  int slot[NC];
+#pragma unroll
+  for (int r = 0; r < NC; r++)
+    if (pending[r]) slot[r] = atomicAdd(&q_cnt[crow[r] >> Q.shift], 1);
+  __syncthreads();
+  if (threadIdx.x < Q.np) {
+    const int c = q_cnt[threadIdx.x];
+    q_base[threadIdx.x] = c ? atomicAdd(&Q.tails[level * Q.np + threadIdx.x], c) : 0;
+    int off = 0;
+    for (int j = 0; j < (int)threadIdx.x; j++) off += q_cnt[j];
+    q_off[threadIdx.x] = off;
+    if ((int)threadIdx.x == Q.np - 1) q_off[Q.np] = off + c;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < NC; r++)
+    if (pending[r]) {
+      const int i = q_off[crow[r] >> Q.shift] + slot[r];
+      st_row[i] = crow[r];
+      st_val[i] = make_float2(cval[r][0], cval[r][1]);
+    }
+  __syncthreads();
+  const int total = q_off[Q.np];
+  for (int i = threadIdx.x; i < total; i += PSDF_BLOCK) {
+    const uint32_t row = st_row[i];
+    const float2 v = st_val[i];
+    const int part = row >> Q.shift;
+    const int idx = q_base[part] + (i - q_off[part]);
+    if (idx < Q.cap) {
+      const int64_t o = ((int64_t)level * Q.np + part) * Q.cap + idx;
+      Q.rows[o] = (uint16_t)(row - ((uint32_t)part << Q.shift));
+      *reinterpret_cast<float2*>(Q.vals + o * 2) = v;
+    } else {  // queue full: exact fallback
+      atomicAdd(table_grad + (int64_t)row * 2, v.x);
+      atomicAdd(table_grad + (int64_t)row * 2 + 1, v.y);
+    }
+  }
+}
+
 // The scatter cache was switched off: hand its live entries to the queues too (instead of flushing them with one
 // global atomic each at the end) and empty it.
 template <int F>
@@ -257,7 +371,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   if (LATTICE) sc.init(lds);
   int* q_cnt = reinterpret_cast<int*>(lds + ScatterCache<F>::bytes() / 4);  // [Q_MAX_PARTS]
   int* q_base = q_cnt + Q_MAX_PARTS;                                          // [Q_MAX_PARTS]
+  int* q_off = q_base + Q_MAX_PARTS;                                          // [Q_MAX_PARTS + 1]
   bool use_cache = LATTICE;
+  int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
   int hits = 0, tries = 0, iter = 0;
   const float w = window[level];
   const int64_t tbase = (int64_t)level * capacity * F;
@@ -277,7 +393,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     float cval[NC][F];
     bool pending[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) pending[c] = false;
+    for (int c = 0; c < NC; c++) {
+      pending[c] = false;
+      crow[c] = 0u;
+#pragma unroll
+      for (int f = 0; f < F; f++) cval[c][f] = 0.f;
+    }
 #pragma unroll
     for (int sp = 0; sp < SPT; sp++) {
       const int64_t n = (tile * SPT + sp) * PSDF_BLOCK + threadIdx.x;
@@ -301,14 +422,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
             crow[c] = row;
 #pragma unroll
             for (int f = 0; f < F; f++) cval[c][f] = g[f] * bw;
-            bool absorbed = false;
-            if (use_cache) {
-              const int rc = sc.add(row, cval[c]);
-              absorbed = rc != 0;
-              hits += (rc == 2);
-              tries++;
-            }
-            pending[c] = !absorbed;
+            pending[c] = true;  // provisional: resolved after the run combine below (outside this divergent branch)
           }
           if (POS) {
 #pragma unroll
@@ -341,14 +455,38 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       }
     }
     if (LATTICE) {
+      // all lanes (also those past the end of the batch) take part in the DPP run combine
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const bool own = combine_runs16<F>(crow[c], pending[c], cval[c]);
+        bool absorbed = false;
+        if (own && use_cache) {
+          const int rc = sc.add(crow[c], cval[c], hot);
+          absorbed = rc != 0;
+          hits += (rc == 2);
+          tries++;
+        }
+        pending[c] = own && !absorbed;
+      }
+    }
+    if (LATTICE) {
       if (QUEUE) {
         // everything the cache did not absorb goes to the queues (also while the cache is on: rays are spatially
         // coherent, so a mid level can re-use entries AND overflow the 4096 slots)
         bool any = false;
 #pragma unroll
         for (int c = 0; c < NC; c++) any |= pending[c];
-        if (__syncthreads_or(any))
-          queue_push<NC, F>(Q, level, q_cnt, q_base, pending, crow, cval, grad_lattice + tbase);
+        if (__syncthreads_or(any)) {
+          // cache off (and drained): its LDS is the staging area of the coalesced hand-off
+          if constexpr (F == 2 && NC * PSDF_BLOCK * 3 * 4 <= ScatterCache<F>::SC_SLOTS * (1 + F) * 4) {
+            if (!use_cache && iter > 0)
+              queue_push_staged<NC>(Q, level, q_cnt, q_base, q_off, lds, pending, crow, cval, grad_lattice + tbase);
+            else
+              queue_push<NC, F>(Q, level, q_cnt, q_base, pending, crow, cval, grad_lattice + tbase);
+          } else {
+            queue_push<NC, F>(Q, level, q_cnt, q_base, pending, crow, cval, grad_lattice + tbase);
+          }
+        }
       } else {
 #pragma unroll
         for (int c = 0; c < NC; c++)
@@ -363,16 +501,17 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       if (QUEUE && !use_cache) cache_drain_to_queue<F>(sc, Q, level, q_cnt, q_base, grad_lattice + tbase);
     }
   }
-  if (LATTICE) sc.flush(grad_lattice + tbase);
+  // (a cache that was switched off in queue mode has been drained and its LDS re-used: nothing to flush)
+  if (LATTICE && !(QUEUE && !use_cache)) sc.flush(grad_lattice + tbase);
 }
 
-// One workgroup per (partition, level): fold the queue into an LDS image of the partition's table slice with LDS
-// atomics, then add the slice to the gradient table (plain read-modify-write: this workgroup is the only writer of
-// these rows after the binning kernel has finished).
+// One workgroup per (partition, level): fold the queue into an LDS image of the partition's table slice (64-bit
+// compare-and-swap per feature pair, lds_add_pair), then add the slice to the gradient table (plain read-modify-write:
+// this workgroup is the only writer of these rows after the binning kernel has finished).
 template <int F>
 __global__ void __launch_bounds__(1024)
     encode_bwd_reduce_kernel(uint32_t capacity, Queues Q, float* __restrict__ grad_lattice) {
-  extern __shared__ __align__(16) float tab[];
+  extern __shared__ __align__(16) float tab[];  // [rows per partition][F]
   const int part = blockIdx.x, level = blockIdx.y;
   int n = Q.tails[level * Q.np + part];
   if (n == 0) return;
@@ -384,6 +523,7 @@ __global__ void __launch_bounds__(1024)
   const uint16_t* __restrict__ rows = Q.rows + qb;
   const float* __restrict__ vals = Q.vals + qb * F;
   constexpr int U = 8;  // queue entries in flight per thread (the loop is HBM-latency bound otherwise)
+  int hot = 0;
   for (int base = 0; base < n; base += U * (int)blockDim.x) {
     int row[U];
     float v[U][F];
@@ -404,7 +544,7 @@ __global__ void __launch_bounds__(1024)
     for (int u = 0; u < U; u++)
       if (row[u] >= 0) {
 #pragma unroll
-        for (int f = 0; f < F; f++) atomicAdd(&tab[f * rpp + row[u]], v[u][f]);  // feature-planar LDS image
+        for (int f = 0; f < F; f += 2) lds_add_pair(&tab[row[u] * F + f], v[u][f], v[u][f + 1], hot);
       }
   }
   __syncthreads();
@@ -413,7 +553,7 @@ __global__ void __launch_bounds__(1024)
   if (nrows > rpp) nrows = rpp;
   float* __restrict__ out = grad_lattice + ((int64_t)level * capacity + row0) * F;
   for (int64_t i = threadIdx.x; i < nrows * F; i += blockDim.x) {
-    const float v = tab[(i % F) * rpp + (i / F)];
+    const float v = tab[i];
     if (v != 0.f) out[i] = out[i] + v;
   }
 }
@@ -457,6 +597,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   ScatterCache<F> sc;
   if (LATTICE) sc.init(lds);
   bool use_cache = LATTICE;
+  int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
   int hits = 0, tries = 0, iter = 0;
   const float w = window[level];
   const int64_t tbase = (int64_t)level * capacity * F;
@@ -516,7 +657,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
           for (int f = 0; f < F; f++) v[f] = qw * g[f];
           bool absorbed = false;
           if (use_cache) {
-            const int rc = sc.add(row, v);
+            const int rc = sc.add(row, v, hot);
             absorbed = rc != 0;
             hits += (rc == 2);
             tries++;
@@ -631,7 +772,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   }
 #define BWD(P_, F_, A_, B_, Q_)                                                                                  \
   hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, A_, B_, Q_>), grid, dim3(PSDF_BLOCK),                             \
-                     (A_) ? ScatterCache<F_>::bytes() + 2 * Q_MAX_PARTS * sizeof(int) : 0, st, N, nr_levels,      \
+                     (A_) ? ScatterCache<F_>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int) : 0, st, N, nr_levels,      \
                      (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling,        \
                      grad_sliced, grad_lattice, grad_positions, Q)
 #define BWD_PF(P_, F_)                                                                                           \

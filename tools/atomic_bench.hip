@@ -51,6 +51,13 @@ __global__ void lds_ops(float* out){
     if (MODE==2) acc += lds[a];                            // read only
     if (MODE==3) atomicAdd(&lds[(lane*65 + i) & 16383], 1.0f);   // stride-65: conflict free, scattered rows
     if (MODE==4) atomicAdd(&lds[(lane*2 + (i&1)*128) & 16383], 1.0f);   // 2-way bank conflict
+    if (MODE==5) atomicAdd((unsigned*)&lds[a], 1u);                                     // ds_add_u32
+    if (MODE==6) acc += __uint_as_float(atomicAdd((unsigned*)&lds[a], 1u));             // ds_add_rtn_u32
+    if (MODE==7) acc += __uint_as_float(atomicCAS((unsigned*)&lds[a], 0u, (unsigned)lane)); // ds_cmpst_rtn_b32
+    if (MODE==8) atomicAdd((unsigned long long*)&lds[a & 16382], 1ull);                 // ds_add_u64
+    if (MODE==9) atomicMax((unsigned*)&lds[a], (unsigned)i);                            // ds_max_u32
+    if (MODE==10) acc += atomicAdd(&lds[a], 1.0f);                                      // ds_add_rtn_f32
+    if (MODE==11) { float2* q = (float2*)&lds[a & 16382]; float2 v = *q; v.x += 1.f; v.y += 2.f; *q = v; }  // b64 RMW
   }
   __syncthreads();
   if(threadIdx.x==0) out[blockIdx.x]=lds[0]+acc;
@@ -90,7 +97,9 @@ int main(){
     #define LDSRUN(M, name) { float t = timeit([&]{ hipLaunchKernelGGL((lds_ops<perl,M>), dim3(b), dim3(threads), 16384*4, 0, out); }); \
       printf("LDS %s: %.3f ms -> %.1f G lane-ops/s, %.1f cycles per wave-instr per CU (2.4GHz, 256 CU)\n", name, t, (double)b*threads*perl/t/1e6, t*1e-3*2.4e9*256/((double)b*threads*perl/64)); }
     LDSRUN(0, "ds_add_f32 conflict-free"); LDSRUN(1, "plain RMW conflict-free"); LDSRUN(2, "read conflict-free");
-    LDSRUN(3, "ds_add_f32 stride-65"); LDSRUN(4, "ds_add_f32 2-way conflict"); }
+    LDSRUN(3, "ds_add_f32 stride-65"); LDSRUN(4, "ds_add_f32 2-way conflict");
+    LDSRUN(5, "ds_add_u32"); LDSRUN(6, "ds_add_rtn_u32"); LDSRUN(7, "ds_cmpst_rtn_b32"); LDSRUN(8, "ds_add_u64");
+    LDSRUN(9, "ds_max_u32"); LDSRUN(10, "ds_add_rtn_f32"); LDSRUN(11, "plain b64 RMW"); }
   { float t = timeit([&]{ hipLaunchKernelGGL(gather, dim3(total/8/threads), dim3(threads),0,0,(const float2*)table, rows-1, out); });
     printf("gather float2 from 2MiB table: %.3f ms (%.1f Ggather/s)\n", t, total/t/1e6); }
   return 0;
