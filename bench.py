@@ -191,13 +191,14 @@ def main():
             "enc_bwd": {"bound": "hbm", "kernel": "encode_bwd_kernel<3,2,true,false,true> + encode_bwd_reduce_kernel<2>",
                         "achieved": enc_bytes / (ms["enc_bwd"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "avg_launch_ms": ms["enc_bwd"], "algorithmic_bytes_per_launch": enc_bytes,
-                        "note": "scatter-add bound: fp32 global atomics cap at ~21 G/s and LDS atomics at ~185 G/s on this chip "
-                                "(tools/atomic_bench.hip); HBM is not the limiter"},
-            "mlp_bwd": {"bound": "mfma", "kernel": "mlp_bwd_kernel<2,2,2,2,1,true,true>",
+                        "note": "scatter-add: fp32 global atomics cap at ~21 G/s and ds_add_f32 at ~200 G/s on this chip "
+                                "(tools/atomic_bench.hip), so runs are summed in registers, pairs are added in LDS with 64-bit "
+                                "CAS and the rest is binned to per-partition queues; HBM is not the limiter"},
+            "mlp_bwd": {"bound": "mfma", "kernel": "mlp_bwd_kernel<3,4,4,4,1,true,true>",
                         "achieved": mlp_flops / (ms["mlp_bwd"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "avg_launch_ms": ms["mlp_bwd"], "algorithmic_flops_per_launch": mlp_flops,
-                        "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak 157.3 TF; forward recomputation inside the "
-                                "kernel is extra, uncounted work"},
+                        "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32, same 157.3 TF peak as 32x32x2); the forward "
+                                "recomputation inside the kernel is extra, uncounted work (MFMA pipe busy 42 % by SQ counters)"},
         }
         dom = max(cand, key=lambda k: ms[k])
         roof = cand[dom]
@@ -207,10 +208,10 @@ def main():
         # as MI355X_MICROARCH.md prescribes; null when no summary for the dominant kernel is on file.
         roof["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")))
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic_v2.json")))
             key = {"enc_bwd": ["encode_bwd_kernel", "encode_bwd_reduce_kernel"], "mlp_bwd": ["mlp_bwd_kernel"]}[dom]
             roof["traffic"] = int(sum(pmc["kernels"][k]["hbm_bytes"] for k in key))
-            roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+            roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic_v2.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
         except Exception:
             pass
         other = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "avg_launch_ms")} for k, v in cand.items() if k != dom}

@@ -5,6 +5,6 @@ HIP kernels through the C-ABI library declared in include/psdf.h.  No CPU fallba
 """
 from . import _lib
 from .encoding import PermutoEncoding, Coarse2Fine
-from .mlp import FusedMLP
+from .mlp import FusedMLP, LipshitzMLP
 
-__all__ = ["PermutoEncoding", "Coarse2Fine", "FusedMLP"]
+__all__ = ["PermutoEncoding", "Coarse2Fine", "FusedMLP", "LipshitzMLP"]

@@ -584,8 +584,10 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   CASE(3, 2, 2, 2, 1, true)   // 33..48 -> 32x3 -> 1..4
   CASE(2, 2, 2, 2, 1, true)   // 17..32 -> 32x3 -> 1..4
   CASE(4, 2, 2, 2, 3, false)  // 52 -> 32x3 -> 33         (reference SDF net, models.py:153-161)
+  CASE(3, 2, 2, 2, 3, false)  // 36 -> 32x3 -> 33         (same net on a 16-level encoding)
   CASE(4, 4, 4, 4, 5, false)  // 52 -> 64x3 -> 65         (background density net, models.py:451-459)
   CASE(4, 4, 4, 4, 3, false)  // 52 -> 64x3 -> 33
+  CASE(3, 4, 4, 4, 3, false)  // 36 -> 64x3 -> 33
   CASE(5, 4, 4, 0, 1, true)   // 80 -> 64x2 -> 3          (background colour head, models.py:463-469)
 #undef CASE
   return PSDF_ERR_UNSUPPORTED;

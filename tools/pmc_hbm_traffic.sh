@@ -1,0 +1,42 @@
+#!/bin/bash
+# HBM bytes per launch of the hot-path kernels from the TCC counters, collected as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), kernel-trace only, CSV output.
+# Run on the GPU box from the repo root:  bash tools/pmc_hbm_traffic.sh <tag>   -> gpurun_out/pmc_hbm_<tag>.json
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+TAG=${1:-cur}
+OUT=$R/gpurun_out/pmc_hbm_$TAG
+mkdir -p $OUT
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+done
+cd $R
+python - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, collections, sys
+out, tag = sys.argv[1], sys.argv[2]
+names = ["encode_fwd_kernel", "mlp_fwd_kernel", "mlp_bwd_kernel", "encode_bwd_kernel", "encode_bwd_reduce_kernel", "adamw_kernel"]
+res = {n: {} for n in names}
+for c, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(out + "/" + c + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != c:
+                continue
+            for n in names:
+                if n + "<" in r["Kernel_Name"] or n + "(" in r["Kernel_Name"]:
+                    agg[n][0] += float(r["Counter_Value"]); agg[n][1] += 1
+    for n, (v, k) in agg.items():
+        res[n][key] = v / k
+for n in names:
+    if "fetch_kib" in res[n] and "write_kib" in res[n]:
+        res[n]["hbm_bytes"] = int(2 * res[n]["fetch_kib"] * 1024 + res[n]["write_kib"] * 1024)
+doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 3 "
+                 "--warmup 1 --no-cpu-baseline; MI355X; units KiB per launch (mean over launches)",
+       "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section; "
+                     "confirmed here: mlp_fwd reads 302 MB of features, counter says ~151 MB) -> hbm_bytes = 2*FETCH_SIZE*1024 + "
+                     "WRITE_SIZE*1024; WRITE_SIZE calibrated exact on encode_fwd (294912 KiB = 36*2097152*4 B)",
+       "kernels": {n: v for n, v in res.items() if v}}
+json.dump(doc, open(out + ".json", "w"), indent=1)
+print(json.dumps(doc["kernels"], indent=1))
+PY
