@@ -34,6 +34,15 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def shard_rays(nr_rays_global, rank, world):
     """Contiguous [start, end) slice of a global ray batch owned by `rank` (remainder spread over the first ranks)."""
     base, rem = divmod(nr_rays_global, world)

@@ -1,0 +1,349 @@
+"""BASELINE config 4: one optimisation step of PermutoSDF training (SDF + colour + background networks), data parallel.
+
+What the reference does in permuto_sdf_py/train_permuto_sdf.py:311-429 (post sphere-init phase) and run_net (:111-169),
+restated on this repository's operators -- same order of operations, same hyper-parameters (:76-105), same losses
+(permuto_sdf_py/utils/permuto_sdf_utils.py:43-51) -- for ONE process per GPU with ray sharding:
+
+  rays from the image reel -> sphere intersection -> occupancy-grid sampling (<= 64/ray) -> two rounds of SDF-driven
+  importance sampling (no grad, sdf_utils.py:383-423) -> SDF + analytic gradient (autograd, create_graph) -> colour
+  network (2nd lattice, SH(5), normals, geometry features, LipshitzMLP) -> NeuS weights -> integrate; background NeRF on
+  32 inverse-depth samples of a 4-D lattice -> composite; losses: L1 colour, eikonal, curvature (2nd gradient evaluation
+  at a tangentially shifted point), off-surface, Lipschitz bound; backward (double backward through the encoding);
+  gradient all-reduce (RCCL) overlapped with nothing it depends on; fused AdamW; every 8th step the occupancy grid is
+  refreshed from 262 144 random voxel centres (same seed on every rank: replicas stay identical without communication).
+
+Differences from the reference, all structural: no-grad SDF evaluations run in the fused single-launch evaluator with
+a 1-row head (csrc/fused.hip); the samplers are exact-size (no second compaction pass); the per-step ray count adapts
+from the sample count the step already knows (no extra sync).  The image data are synthetic (DTU is not available
+offline): `SyntheticReel` has the TensorReel fields `random_rays_from_reel` reads (src/PermutoSDF.cu:70-102).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import parallel
+from .bridge import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRendering
+from .encoding import Coarse2Fine, PermutoEncoding
+from .fused import encode_mlp_forward_raw
+from .mlp import FusedMLP, LipshitzMLP, pack_params
+from .optim import FusedAdamW
+
+
+class HyperParams:
+    """train_permuto_sdf.py:76-105"""
+    lr = 1e-3
+    forced_variance_finish_iter = 35000
+    forced_variance_finish = 0.8
+    eikonal_weight = 0.04
+    curvature_weight = 0.65
+    lipshitz_weight = 3e-6
+    offsurface_weight = 1e-4
+    iter_start_reduce_curv = 50000
+    iter_finish_reduce_curv = 50000 + 1001
+    nr_samples_bg = 32
+    min_dist_between_samples = 1e-4
+    max_nr_samples_per_ray = 64
+    nr_samples_imp_sampling = 16
+    nr_rays = 512
+    sdf_geom_feat_size = 32
+    sdf_nr_iters_for_c2f = 10000
+    target_nr_of_samples = 512 * (64 + 16 + 16)
+
+
+def map_range_val(v, in_lo, in_hi, out_lo, out_hi):
+    t = min(max((v - in_lo) / (in_hi - in_lo), 0.0), 1.0)
+    return out_lo + t * (out_hi - out_lo)
+
+
+# ------------------------------------------------------------------------------------- differentiable compositing
+class _Cumprod(torch.autograd.Function):  # volume_rendering_funcs.py:55-118
+    @staticmethod
+    def forward(ctx, rs, one_minus_alpha):
+        T, bg = VolumeRendering.cumprod_alpha2transmittance(rs, one_minus_alpha)
+        ctx.save_for_backward(one_minus_alpha, T, bg)
+        ctx.rs = rs
+        return T, bg
+
+    @staticmethod
+    def backward(ctx, gT, gbg):
+        a, T, bg = ctx.saved_tensors
+        cs = VolumeRendering.cumsum_over_each_ray(ctx.rs, gT * T, True)
+        return None, VolumeRendering.cumprod_alpha2transmittance_backward(gT, gbg, ctx.rs, a, T, bg, cs)
+
+
+class _Integrate(torch.autograd.Function):  # volume_rendering_funcs.py:161-190
+    @staticmethod
+    def forward(ctx, rs, vals, w):
+        out = VolumeRendering.integrate_with_weights(rs, vals, w)
+        ctx.save_for_backward(vals, w, out)
+        ctx.rs = rs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        vals, w, out = ctx.saved_tensors
+        gv, gw = VolumeRendering.integrate_with_weights_backward(g.contiguous(), ctx.rs, vals, w, out)
+        return None, gv, gw
+
+
+class _SumRay(torch.autograd.Function):  # volume_rendering_funcs.py:194-224
+    @staticmethod
+    def forward(ctx, rs, v):
+        per_ray, per_sample = VolumeRendering.sum_over_each_ray(rs, v)
+        ctx.save_for_backward(v)
+        ctx.rs = rs
+        return per_ray, per_sample
+
+    @staticmethod
+    def backward(ctx, g_ray, g_sample):
+        (v,) = ctx.saved_tensors
+        return None, VolumeRendering.sum_over_each_ray_backward(g_ray.contiguous(), g_sample.contiguous(), ctx.rs, v)
+
+
+# --------------------------------------------------------------------------------------------------- networks
+def _lattice(pos_dim, points_scaling):
+    return PermutoEncoding(pos_dim, 2 ** 18, 24, 2, np.geomspace(1.0, 1e-4, 24), appply_random_shift_per_level=True,
+                           concat_points=True, concat_points_scaling=points_scaling)
+
+
+class SdfNet(torch.nn.Module):
+    """models.py:131-251: 24-level lattice + Linear(52,32)-GELU-(32,32)-GELU-(32,32)-GELU-(32,1+32).  The MLP stays a
+    torch.nn.Sequential on the differentiable path because the eikonal/curvature losses differentiate THROUGH its
+    gradient (create_graph=True); the no-grad path (`sdf_only`) is one fused launch."""
+
+    def __init__(self, hp):
+        super().__init__()
+        self.encoding = _lattice(3, 1e-3)
+        g = hp.sdf_geom_feat_size
+        self.mlp_sdf = torch.nn.Sequential(torch.nn.Linear(self.encoding.output_dims(), 32), torch.nn.GELU(),
+                                           torch.nn.Linear(32, 32), torch.nn.GELU(), torch.nn.Linear(32, 32),
+                                           torch.nn.GELU(), torch.nn.Linear(32, 1 + g))
+        with torch.no_grad():  # start as a sphere-ish field of radius ~0.3 so that the samplers have something to hit
+            self.mlp_sdf[-1].bias[0] += 1e-2
+        self.c2f = Coarse2Fine(24)
+        self.nr_iters_for_c2f = hp.sdf_nr_iters_for_c2f
+
+    def window(self, it):
+        return self.c2f(map_range_val(it, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)).to(self.encoding.lattice_values.device)
+
+    def forward(self, points, it):
+        y = self.mlp_sdf(self.encoding(points, self.window(it)))
+        return y[:, 0:1], y[:, 1:]
+
+    @torch.no_grad()
+    def sdf_only(self, points, it):
+        """[N,1]; the SDF is row 0 of the last layer (models.py:190)"""
+        lin = [m for m in self.mlp_sdf if isinstance(m, torch.nn.Linear)]
+        ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+        ws[-1], bs[-1] = ws[-1][0:1].contiguous(), bs[-1][0:1].contiguous()
+        dims = [lin[0].in_features, 32, 32, 32, 1]
+        e = self.encoding
+        y, _ = encode_mlp_forward_raw(e.cfg, points.contiguous(), e.lattice_values.detach(), e.scale_factor,
+                                      e.random_shift_per_level.detach(), self.window(it).contiguous(), dims,
+                                      pack_params(dims, ws, bs))
+        return y.view(-1, 1)
+
+    def sdf_and_gradient(self, points, it):  # models.py:236-251
+        with torch.enable_grad():
+            points = points.detach().requires_grad_(True)
+            sdf, feat = self.forward(points, it)
+            (grad,) = torch.autograd.grad(sdf, points, torch.ones_like(sdf), create_graph=True, retain_graph=True)
+        return sdf, grad, feat
+
+    def curvature(self, points, sdf_gradients, it):  # models.py:261-296
+        normals = F.normalize(sdf_gradients, dim=-1)
+        tangent = torch.cross(normals, F.normalize(torch.randn_like(points), dim=-1), dim=-1)
+        _, g2, _ = self.sdf_and_gradient(points.detach() + tangent * 1e-4, it)
+        dot = (normals * F.normalize(g2, dim=-1)).sum(-1, keepdim=True)
+        return torch.acos(torch.clamp(dot, -1.0 + 1e-6, 1.0 - 1e-6)) / math.pi
+
+
+class RgbNet(torch.nn.Module):
+    """models.py:310-391: 2nd lattice (points scaling 1) + SH(5) of the view direction + normal + geometry features ->
+    LipshitzMLP [128,128,64,3] -> sigmoid."""
+
+    def __init__(self, hp):
+        super().__init__()
+        self.encoding = _lattice(3, 1.0)
+        self.mlp = LipshitzMLP(self.encoding.output_dims() + 25 + 3 + hp.sdf_geom_feat_size, [128, 128, 64, 3], True)
+        self.variance = torch.nn.Parameter(torch.tensor(0.3))  # SingleVarianceNetwork, volume_rendering_modules.py:96-115
+        self.last_inv_s = None
+
+    def forward(self, points, dirs, sdf_gradients, geom_feat):
+        win = torch.ones(24, device=points.device)  # rgb_nr_iters_for_c2f = 1: window is 1 from the first step
+        with torch.no_grad():
+            sh = PermutoSDF.spherical_harmonics(dirs, 5)
+        x = torch.cat([self.encoding(points, win), sh, F.normalize(sdf_gradients.view(-1, 3), dim=1), geom_feat], 1)
+        return torch.sigmoid(self.mlp(x))
+
+    def neus_weights(self, rs, sdf, gradients, cos_anneal_ratio, forced_variance):  # volume_rendering_modules.py:129-174
+        v = self.variance if forced_variance is None else torch.tensor(float(forced_variance), device=sdf.device)
+        inv_s = torch.exp(v * 10.0).clip(1e-6, 1e6)
+        self.last_inv_s = inv_s.detach()
+        true_cos = (rs.samples_dirs * gradients).sum(-1, keepdim=True)
+        iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-true_cos) * cos_anneal_ratio)
+        half = iter_cos * rs.samples_dt.reshape(-1, 1) * 0.5
+        prev_cdf, next_cdf = torch.sigmoid((sdf - half) * inv_s), torch.sigmoid((sdf + half) * inv_s)
+        alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+        T, bg = _Cumprod.apply(rs, 1 - alpha + 1e-7)
+        w = (alpha * T).view(-1, 1)
+        w_sum, _ = _SumRay.apply(rs, w)
+        return w, w_sum, bg
+
+
+class BgNet(torch.nn.Module):
+    """NerfHash, models.py:431-526: 4-D lattice, density+feature net 52->64x3->65, colour head [64+16]->64->64->3."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoding = _lattice(4, 1.0)
+        self.mlp_feat_and_density = FusedMLP([self.encoding.output_dims(), 64, 64, 64, 65])
+        self.mlp_rgb = FusedMLP([64 + 16, 64, 64, 3])
+
+    def forward(self, pos4d, dirs):
+        win = torch.ones(24, device=pos4d.device)
+        with torch.no_grad():
+            sh = PermutoSDF.spherical_harmonics(dirs, 4)
+        fd = self.mlp_feat_and_density(self.encoding(pos4d, win))
+        rgb = self.mlp_rgb(torch.cat([F.gelu(fd[:, 1:65]), sh], 1))
+        return torch.sigmoid(rgb), F.softplus(fd[:, 0:1])
+
+    @staticmethod
+    def nerf_weights(rs, density):  # volume_rendering_modules.py:72-86
+        alpha = 1.0 - torch.exp(-density * rs.samples_dt)
+        T, bg = _Cumprod.apply(rs, 1 - alpha + 1e-7)
+        return (alpha * T).view(-1, 1)
+
+
+class SyntheticReel:
+    """The TensorReel fields read by random_rays_from_reel (src/PermutoSDF.cu:70-102): `nr_images` random images, pinhole
+    cameras on a sphere of radius `dist` looking at the origin."""
+
+    def __init__(self, device, nr_images=49, height=300, width=400, dist=1.5, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.rgb_reel = torch.rand(nr_images, 3, height, width, generator=g).to(device)
+        self.mask_reel = torch.ones(nr_images, 1, height, width, device=device)
+        self.has_mask = False
+        K = torch.tensor([[1.2 * width, 0, width / 2], [0, 1.2 * width, height / 2], [0, 0, 1.0]])
+        self.K_reel = K.expand(nr_images, 3, 3).contiguous().to(device)
+        tf = torch.zeros(nr_images, 4, 4)
+        for i in range(nr_images):
+            c = F.normalize(torch.randn(3, generator=g), dim=0) * dist
+            z = F.normalize(-c, dim=0)
+            x = F.normalize(torch.cross(torch.tensor([0.0, 1.0, 0.0]), z, dim=0), dim=0)
+            y = torch.cross(z, x, dim=0)
+            tf[i, :3, 0], tf[i, :3, 1], tf[i, :3, 2], tf[i, :3, 3], tf[i, 3, 3] = x, y, z, c, 1.0
+        self.tf_world_cam_reel = tf.to(device)
+
+
+# ------------------------------------------------------------------------------------------------------ trainer
+class Trainer:
+    def __init__(self, device, hp=None, seed=0):
+        self.hp = hp or HyperParams()
+        self.dev = torch.device(device)
+        torch.manual_seed(seed)  # identical replicas on every rank
+        self.sdf, self.rgb, self.bg = SdfNet(self.hp).to(self.dev), RgbNet(self.hp).to(self.dev), BgNet().to(self.dev)
+        self.sphere = Sphere(0.5, [0, 0, 0])
+        self.grid = OccupancyGrid(256, 1.0, [0, 0, 0], device=self.dev)
+        self.params = [p for m in (self.sdf, self.rgb, self.bg) for p in m.parameters() if p.requires_grad]
+        self.opt = FusedAdamW(self.params, lr=self.hp.lr, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+        self.nr_rays = self.hp.nr_rays
+        self.iter = 0
+        self.last = {}
+        # per-rank random streams for rays/jitter, one shared stream for the grid refresh
+        self._rank_seed = parallel.rank_seed(seed + 1, parallel.rank())
+
+    # ---- sampling (no grad): nerf_utils.py:502-525 + sdf_utils.py:383-423
+    @torch.no_grad()
+    def _samples(self, o, d, it):
+        hp = self.hp
+        _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
+        fg = self.grid.compute_samples_in_occupied_regions(o, d, te, tx, hp.min_dist_between_samples,
+                                                           hp.max_nr_samples_per_ray, True).compact_to_valid_samples()
+        bg = RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius, self.sphere.m_center_tensor,
+                                           True, False)
+        if fg.samples_pos.shape[0] == 0:
+            return fg, bg
+        fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it))
+        for rnd, mult in ((0, 1.0), (1, 2.0)):
+            alpha = VolumeRendering.sdf2alpha(fg, fg.samples_sdf, 512.0, True, mult).clip(0.0, 1.0)
+            T, _ = VolumeRendering.cumprod_alpha2transmittance(fg, 1 - alpha + 1e-7)
+            w = alpha * T
+            _, per_sample = VolumeRendering.sum_over_each_ray(fg, w)
+            cdf = VolumeRendering.compute_cdf(fg, w / torch.clamp(per_sample, min=1e-6))
+            imp = VolumeRendering.importance_sample(o, d, fg, cdf, hp.nr_samples_imp_sampling, True)
+            if rnd == 0:
+                imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it))
+            else:
+                fg.remove_sdf()
+            fg = VolumeRendering.combine_uniform_samples_with_imp(o, d, tx, fg, imp).compact_to_valid_samples()
+        return fg, bg
+
+    # ---- run_net: train_permuto_sdf.py:111-169
+    def _render(self, o, d, it, cos_anneal_ratio, forced_variance):
+        fg, bg = self._samples(o, d, it)
+        R = o.shape[0]
+        if fg.samples_pos.shape[0] == 0:
+            pred = torch.zeros(R, 3, device=self.dev)
+            sdf_grad, bgT = torch.zeros(0, 3, device=self.dev), torch.ones(R, 1, device=self.dev)
+        else:
+            sdf, sdf_grad, feat = self.sdf.sdf_and_gradient(fg.samples_pos, it)
+            rgb = self.rgb(fg.samples_pos, fg.samples_dirs, sdf_grad, feat)
+            w, _, bgT = self.rgb.neus_weights(fg, sdf, sdf_grad, cos_anneal_ratio, forced_variance)
+            pred = _Integrate.apply(fg, rgb, w)
+        rgb_bg, dens = self.bg(bg.samples_pos_4d, bg.samples_dirs)
+        pred = pred + bgT.view(-1, 1) * _Integrate.apply(bg, rgb_bg, BgNet.nerf_weights(bg, dens.view(-1, 1)))
+        return pred, sdf_grad, fg
+
+    def step(self, reel):
+        """one optimisation step; returns the loss (device tensor, no sync)"""
+        hp, it = self.hp, self.iter
+        torch.manual_seed(self._rank_seed + it)  # this rank's rays / jitter
+        cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
+        forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
+        with torch.no_grad():
+            o, d, gt, _, _ = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
+            _, _, _, _, hit = self.sphere.ray_intersection(o, d)
+        pred, sdf_grad, fg = self._render(o, d, it, cos_anneal_ratio, forced_variance)
+        loss = ((gt - pred).abs() * hit).mean()                                                # rgb_loss
+        n_fg = fg.samples_pos.shape[0]
+        if n_fg:
+            loss = loss + ((torch.linalg.norm(sdf_grad, ord=2, dim=-1) - 1.0) ** 2).mean() * hp.eikonal_weight
+            gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
+            if gw > 0.0:
+                loss = loss + self.sdf.curvature(fg.samples_pos, sdf_grad, it).mean() * hp.curvature_weight * gw
+        off = self.sphere.rand_points_inside(1024)
+        sdf_off, _ = self.sdf(off, it)
+        loss = loss + torch.exp(-1e2 * sdf_off.abs()).mean() * hp.offsurface_weight
+        if it >= hp.iter_start_reduce_curv:
+            loss = loss + self.rgb.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
+        # ---- backward, all-reduce, optimiser
+        for p in self.params:
+            p.grad = None
+        loss.backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        for p, g in zip(self.params, grads):
+            p.grad = g
+        if parallel.world_size() > 1:
+            buckets = parallel.GradientBuckets()
+            small = [g for g in grads if g.numel() < (1 << 20)]
+            big = [g for g in grads if g.numel() >= (1 << 20)]
+            buckets.reduce(small)
+            for g in big:           # one bucket per lattice (50 MB): the ring is per-link bound, fewer larger messages
+                buckets.reduce([g])
+            buckets.finish()
+        self.opt.step(grad_scale=1.0 / parallel.world_size())
+        # ---- occupancy refresh, every 8th step, same random voxels on every rank (train_permuto_sdf.py:386-391)
+        with torch.no_grad():
+            if it % 8 == 0:
+                torch.manual_seed(977 + it)
+                centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
+                inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
+                self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it), inv_s.view(1), 1e-4)
+            if n_fg:  # adaptive ray count (train_permuto_sdf.py:393-397); the count is already on the host
+                self.nr_rays = max(64, min(8192, int(self.nr_rays * hp.target_nr_of_samples / n_fg)))
+        self.iter += 1
+        self.last = {"nr_rays": o.shape[0], "nr_fg_samples": n_fg}
+        return loss.detach()

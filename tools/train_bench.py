@@ -1,0 +1,56 @@
+"""BASELINE config 4: training iterations per second of the full SDF + colour + background step
+(permuto_sdf_amd/train_step.py) on a synthetic image reel; one process per GPU (launch with torch.distributed.run
+for N > 1, same contract as bench.py).  Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from permuto_sdf_amd import parallel  # noqa: E402
+from permuto_sdf_amd.train_step import SyntheticReel, Trainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=20)
+    args = ap.parse_args()
+    rank, world, local = parallel.init()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    tr = Trainer(dev)
+    reel = SyntheticReel(dev)
+    for _ in range(args.warmup):
+        tr.step(reel)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(args.steps):
+        tr.step(reel)
+        samples += tr.last["nr_fg_samples"]
+    barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    if rank == 0:
+        el = float(el.item())
+        print(json.dumps({"metric": "train iters/sec (cfg 4: SDF + colour + background step, synthetic reel)",
+                          "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                          "fg_samples_per_step_per_gpu": samples / args.steps, "rays_last_step": tr.last["nr_rays"],
+                          "scaling": "weak", "dtype": "f32", "data": "synthetic"}))
+    parallel.shutdown()
+
+
+if __name__ == "__main__":
+    main()
