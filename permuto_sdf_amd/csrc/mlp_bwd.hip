@@ -526,11 +526,11 @@ __global__ void __launch_bounds__(BW * 64)
 
 template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
 int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
-  const size_t shmem = ((size_t)((p.total + 3) & ~3) + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
-  if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
   const int64_t ntiles = (N + 15) / 16;
   int64_t blocks = (ntiles + BW - 1) / BW;
-  if (blocks > 256) blocks = 256;  // one workgroup per CU, one wave per SIMD; each wave walks many tiles
+  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave (pair) walks many tiles
+  const size_t shmem = ((size_t)((p.total + 3) & ~3) + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
+  if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
 #define GO(DX)                                                                                                     \
   do {                                                                                                             \
     auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, DX>;                                              \

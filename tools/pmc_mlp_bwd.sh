@@ -24,7 +24,7 @@ tot = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
-        if "mlp_bwd_kernel" in r["Kernel_Name"]:
+        if "mlp_bwd" in r["Kernel_Name"]:
             a = agg[r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
     for k, (v, n) in agg.items():
