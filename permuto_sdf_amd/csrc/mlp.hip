@@ -95,12 +95,24 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
     {
       const float* __restrict__ w0 = lds + p.w_off[0];
       const int steps = p.in_steps0;
-      for (int s = 0; s < steps; s++) {
-        const int k = 2 * s + h;
-        const float b = (k < K0) ? X[(int64_t)k * N + nc] : 0.f;
+      // all operand loads of a chunk are issued before the first MFMA consumes one (a load -> MFMA -> load chain
+      // would expose one HBM latency per k-step)
+      constexpr int XC = 16;
+      for (int s0 = 0; s0 < steps; s0 += XC) {
+        float xb[XC];
 #pragma unroll
-        for (int to = 0; to < T1; to++)
-          h1[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(to * steps + s) * WS + lane], b, h1[to], 0, 0, 0);
+        for (int i = 0; i < XC; i++) {
+          const int k = 2 * (s0 + i) + h;
+          xb[i] = (s0 + i < steps && k < K0) ? X[(int64_t)k * N + nc] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < XC; i++) {
+          if (s0 + i < steps) {
+#pragma unroll
+            for (int to = 0; to < T1; to++)
+              h1[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(to * steps + s0 + i) * WS + lane], xb[i], h1[to], 0, 0, 0);
+          }
+        }
       }
     }
     apply_gelu<T1>(h1);
