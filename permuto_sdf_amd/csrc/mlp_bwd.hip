@@ -245,6 +245,76 @@ struct LayerAcc {
   }
 };
 
+// Weight images of the kernel, laid out so that ONE ds_read_b128 per lane delivers the A operands of four
+// consecutive MFMAs (the per-MFMA ds_read_b32 of the first version of this kernel was a third of its LDS traffic in
+// instructions and the main thing a lone wave waited on).  Separate images for the forward product (A = W) and the
+// transposed one (A = W^T), lane = (g, c), 4 floats per lane:
+//   FWD chain layer (to,ti):  [lane][r] = W[16to + c][16ti + 4g + r]
+//   BWD chain layer (to,ti):  [lane][r] = W[16to + 4g + r][16ti + c]
+//   layer 0 forward (to,s4):  [lane][j] = W0[16to + c][4(4 s4 + j) + g]          (k-steps grouped by four)
+//   layer 0 transposed (t,to):[lane][r] = W0[16to + 4g + r][16t + c]             (dX)
+// followed by the hidden biases and the dot-head rows ([o][ti][r][g]).
+template <int TI0, int T1, int T2, int T3, int OTS, bool FINAL_DOT>
+struct Img {
+  static constexpr int TL = (T3 > 0) ? T3 : T2;
+  static constexpr int F0 = 0;
+  static constexpr int B0 = F0 + T1 * TI0 * 256;
+  static constexpr int F1 = B0 + TI0 * T1 * 256;
+  static constexpr int B1 = F1 + T2 * T1 * 256;
+  static constexpr int F2 = B1 + T2 * T1 * 256;
+  static constexpr int B2 = F2 + T3 * T2 * 256;
+  static constexpr int BO = B2 + T3 * T2 * 256;                 // transposed image of an MFMA output layer
+  static constexpr int BIAS1 = BO + (FINAL_DOT ? 0 : OTS * TL * 256);
+  static constexpr int BIAS2 = BIAS1 + T1 * 16;
+  static constexpr int BIAS3 = BIAS2 + T2 * 16;
+  static constexpr int WF = BIAS3 + T3 * 16;                    // dot head [4][TL][4][4]
+  static constexpr int TOTAL = WF + (FINAL_DOT ? 4 * TL * 16 : 0);
+};
+
+__device__ __forceinline__ float ld_w(const float* W, int rows, int cols, int row, int col) {
+  return (row < rows && col < cols) ? W[(int64_t)row * cols + col] : 0.f;
+}
+// stage one chain-layer pair of images (forward + transposed) of W [rows x cols]
+__device__ __forceinline__ void stage_chain(float* fwd, float* bwd, const float* W, int rows, int cols, int TO, int TI,
+                                            int tid, int nthreads) {
+  const int n = TO * TI * 256;
+  for (int e = tid; e < n; e += nthreads) {
+    const int r = e & 3, lane = (e >> 2) & 63, pr = e >> 8, ti = pr % TI, to = pr / TI;
+    const int g = lane >> 4, c = lane & 15;
+    if (fwd) fwd[e] = ld_w(W, rows, cols, 16 * to + c, 16 * ti + 4 * g + r);
+    if (bwd) bwd[e] = ld_w(W, rows, cols, 16 * to + 4 * g + r, 16 * ti + c);
+  }
+}
+
+// out^T = W * in^T  (chain layout), A operands by 128-bit reads
+template <int TI, int TO>
+__device__ __forceinline__ void chain_fwd4(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* __restrict__ w, int lane) {
+#pragma unroll
+  for (int ti = 0; ti < TI; ti++) {
+    f32x4 wv[TO];
+#pragma unroll
+    for (int to = 0; to < TO; to++) wv[to] = *reinterpret_cast<const f32x4*>(w + ((to * TI + ti) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int to = 0; to < TO; to++) out[to] = MFMA16(wv[to][r], in[ti][r], out[to]);
+  }
+}
+// dh^T[in] += W^T dz^T[out]
+template <int TO, int TI>
+__device__ __forceinline__ void chain_bwd4(const f32x4 (&dz)[TO], f32x4 (&dh)[TI], const float* __restrict__ w, int lane) {
+#pragma unroll
+  for (int to = 0; to < TO; to++) {
+    f32x4 wv[TI];
+#pragma unroll
+    for (int ti = 0; ti < TI; ti++) wv[ti] = *reinterpret_cast<const f32x4*>(w + ((to * TI + ti) * 64 + lane) * 4);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int ti = 0; ti < TI; ti++) dh[ti] = MFMA16(wv[ti][r], dz[to][r], dh[ti]);
+  }
+}
+
 constexpr int BW = 4;  // waves per workgroup (one per SIMD: the kernel wants the whole 512-register file)
 
 template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool NEED_DX>
@@ -255,21 +325,40 @@ __global__ void __launch_bounds__(BW * 64)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int SX = 4 * TI0;                       // k-steps of layer 0 (upper bound of p.steps0)
   constexpr int WAVE_LDS = 16 * 17 + 16 + 2 * SX * 64;
-  const int img = (p.total + 3) & ~3;
+  constexpr int OTS_ = FINAL_DOT ? 1 : OUT_T;
+  using IM = Img<TI0, T1, T2, T3, OTS_, FINAL_DOT>;
+  const int img = IM::TOTAL > p.total ? IM::TOTAL : ((p.total + 3) & ~3);  // the gradient image re-uses this region later
   float* tbuf = lds + img + wave * WAVE_LDS;        // 16x17 transpose buffer
   float* dyb = tbuf + 16 * 17;                      // 16 floats
   float* xbuf = dyb + 16;                           // 2 x [SX][64]: layer-0 operand tiles landed by LDS-DMA
-  for (int e = threadIdx.x; e < p.total; e += BW * 64) {
-    int l, row, col;
-    bool is_bias;
-    unpack_index(p, e, l, row, col, is_bias);
-    float v = 0.f;
-    if (is_bias) {
-      if (row < p.dims[l + 1]) v = a.b[l][row];
-    } else if (row < p.dims[l + 1] && col < p.dims[l]) {
-      v = a.W[l][(int64_t)row * p.dims[l] + col];
+  {
+    const int tid = threadIdx.x, nt = BW * 64;
+    const int d0 = p.dims[0], d1 = p.dims[1], d2 = p.dims[2], d3 = p.dims[3];
+    for (int e = tid; e < T1 * TI0 * 256; e += nt) {  // layer 0: forward (k-steps by four) and transposed (dX)
+      const int j = e & 3, ln = (e >> 2) & 63, gg = ln >> 4, cc = ln & 15;
+      {
+        const int pr = e >> 8, s4 = pr % TI0, to = pr / TI0;
+        lds[IM::F0 + e] = ld_w(a.W[0], d1, d0, 16 * to + cc, 4 * (4 * s4 + j) + gg);
+      }
+      {
+        const int pr = e >> 8, to = pr % T1, t = pr / T1;
+        lds[IM::B0 + e] = ld_w(a.W[0], d1, d0, 16 * to + 4 * gg + j, 16 * t + cc);
+      }
     }
-    lds[e] = v;
+    stage_chain(lds + IM::F1, lds + IM::B1, a.W[1], d2, d1, T2, T1, tid, nt);
+    if constexpr (T3 > 0) stage_chain(lds + IM::F2, lds + IM::B2, a.W[2], d3, d2, T3, T2, tid, nt);
+    const int lfi = p.n_layers - 1;
+    if constexpr (!FINAL_DOT)
+      stage_chain(nullptr, lds + IM::BO, a.W[lfi], p.dims[lfi + 1], p.dims[lfi], OTS_, IM::TL, tid, nt);
+    for (int e = tid; e < T1 * 16; e += nt) lds[IM::BIAS1 + e] = e < d1 ? a.b[0][e] : 0.f;
+    for (int e = tid; e < T2 * 16; e += nt) lds[IM::BIAS2 + e] = e < d2 ? a.b[1][e] : 0.f;
+    if constexpr (T3 > 0)
+      for (int e = tid; e < T3 * 16; e += nt) lds[IM::BIAS3 + e] = e < d3 ? a.b[2][e] : 0.f;
+    if constexpr (FINAL_DOT)
+      for (int e = tid; e < 4 * IM::TL * 16; e += nt) {  // [o][ti][r][g] = W[o][16ti + 4g + r]
+        const int gg = e & 3, r = (e >> 2) & 3, ti = (e >> 4) % IM::TL, o = (e >> 4) / IM::TL;
+        lds[IM::WF + e] = ld_w(a.W[lfi], p.dims[lfi + 1], p.dims[lfi], o, 16 * ti + 4 * gg + r);
+      }
   }
   __syncthreads();
   const int g = lane >> 4, c = lane & 15;
@@ -328,25 +417,36 @@ __global__ void __launch_bounds__(BW * 64)
     f32x4 h1[T1], d1[T1], h2[T2], d2[T2], h3[T3S], d3[T3S];
     {
       f32x4 z[T1];
-      init_bias16<T1>(z, W + p.b_off[0], g);
-      for (int s = 0; s < S0; s++) {
-        const float xv = xb[s * 64 + lane];
-        const float b = (4 * s + g < K0 && live) ? xv : 0.f;
+      init_bias16<T1>(z, W + IM::BIAS1, g);
+      const int S4 = (S0 + 3) >> 2;
+      for (int s4 = 0; s4 < S4; s4++) {
+        f32x4 wv[T1];
 #pragma unroll
-        for (int to = 0; to < T1; to++) z[to] = MFMA16(W[p.w_off[0] + (to * S0 + s) * WS + lane], b, z[to]);
+        for (int to = 0; to < T1; to++)
+          wv[to] = *reinterpret_cast<const f32x4*>(W + IM::F0 + ((to * TI0 + s4) * 64 + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int sj = 4 * s4 + j;
+          if (sj < S0) {  // wave-uniform
+            const float xv = xb[sj * 64 + lane];
+            const float b = (4 * sj + g < K0 && live) ? xv : 0.f;
+#pragma unroll
+            for (int to = 0; to < T1; to++) z[to] = MFMA16(wv[to][j], b, z[to]);
+          }
+        }
       }
       gelu_both<T1>(z, h1, d1);
     }
     {
       f32x4 z[T2];
-      init_bias16<T2>(z, W + p.b_off[1], g);
-      chain_fwd<T1, T2>(h1, z, W + p.w_off[1], lane);
+      init_bias16<T2>(z, W + IM::BIAS2, g);
+      chain_fwd4<T1, T2>(h1, z, W + IM::F1, lane);
       gelu_both<T2>(z, h2, d2);
     }
     if constexpr (T3 > 0) {
       f32x4 z[T3S];
-      init_bias16<T3S>(z, W + p.b_off[2], g);
-      chain_fwd<T2, T3S>(h2, z, W + p.w_off[2], lane);
+      init_bias16<T3S>(z, W + IM::BIAS3, g);
+      chain_fwd4<T2, T3S>(h2, z, W + IM::F2, lane);
       gelu_both<T3S>(z, h3, d3);
     }
     // ---------------------------------------------------------------- output layer
@@ -362,7 +462,7 @@ __global__ void __launch_bounds__(BW * 64)
           to_nt(h2[t], hl_nt[t], tbuf, g, c);
       }
       if constexpr (FINAL_DOT) {
-        const float* __restrict__ wf = W + p.w_off[lf];
+        const float* __restrict__ wf = W + IM::WF;
 #pragma unroll
         for (int o = 0; o < 4; o++) {
           if (o < OUT) {
@@ -393,7 +493,7 @@ __global__ void __launch_bounds__(BW * 64)
             const int row = 16 * to + 4 * g + r;
             dyT[to][r] = (row < OUT && live) ? dY[(int64_t)row * N + n] : 0.f;
           }
-        chain_bwd<OTS, TL>(dyT, dhl, W + p.w_off[lf], g, c);
+        chain_bwd4<OTS, TL>(dyT, dhl, W + IM::BO, lane);
         f32x4 dy_nt[OTS];
 #pragma unroll
         for (int to = 0; to < OTS; to++) to_nt(dyT[to], dy_nt[to], tbuf, g, c);
@@ -416,7 +516,7 @@ __global__ void __launch_bounds__(BW * 64)
         acc2.add(dz_nt, hin_nt);
       }
       zero16<T2>(dh2);
-      chain_bwd<T3S, T2>(dhl, dh2, W + p.w_off[2], g, c);
+      chain_bwd4<T3S, T2>(dhl, dh2, W + IM::B2, lane);
     } else {
 #pragma unroll
       for (int t = 0; t < T2; t++) dh2[t] = dhl[t];
@@ -435,7 +535,7 @@ __global__ void __launch_bounds__(BW * 64)
     }
     f32x4 dh1[T1];
     zero16<T1>(dh1);
-    chain_bwd<T2, T1>(dh2, dh1, W + p.w_off[1], g, c);
+    chain_bwd4<T2, T1>(dh2, dh1, W + IM::B1, lane);
 #pragma unroll
     for (int t = 0; t < T1; t++)
 #pragma unroll
@@ -460,16 +560,12 @@ __global__ void __launch_bounds__(BW * 64)
 #pragma unroll
       for (int t = 0; t < TI0; t++) {
         f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-        const int s = 4 * t + (c >> 2);
-        const bool colok = s < S0;
-        const float* __restrict__ wrow = W + p.w_off[0] + s * WS + (c & 3) * 16 + 4 * g;
 #pragma unroll
-        for (int to = 0; to < T1; to++)
+        for (int to = 0; to < T1; to++) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(W + IM::B0 + ((t * T1 + to) * 64 + lane) * 4);
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const float wv = colok ? wrow[to * S0 * WS + r] : 0.f;  // W0[16to + 4g + r][16t + c]
-            dx = MFMA16(wv, dh1[to][r], dx);
-          }
+          for (int r = 0; r < 4; r++) dx = MFMA16(wv[r], dh1[to][r], dx);  // W0[16to + 4g + r][16t + c]
+        }
         if (live) {
 #pragma unroll
           for (int q = 0; q < 4; q++) {
@@ -529,7 +625,9 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
   const int64_t ntiles = (N + 15) / 16;
   int64_t blocks = (ntiles + BW - 1) / BW;
   if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave (pair) walks many tiles
-  const size_t shmem = ((size_t)((p.total + 3) & ~3) + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
+  using IM = Img<TI0, T1, T2, T3, FINAL_DOT ? 1 : OUT_T, FINAL_DOT>;
+  const int img = IM::TOTAL > p.total ? IM::TOTAL : ((p.total + 3) & ~3);
+  const size_t shmem = ((size_t)img + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
   if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
 #define GO(DX)                                                                                                     \
   do {                                                                                                             \
