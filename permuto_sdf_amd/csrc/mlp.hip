@@ -53,9 +53,10 @@ __global__ void mlp_pack_kernel(PackArgs a, float* __restrict__ packed) {
       const int h = q & 1, r = (q >> 1) & 15, ti = (q >> 5) % p.tiles[l], o = (q >> 5) / p.tiles[l];
       row = o;
       col = 32 * ti + row_of(r, h);
-    } else {  // [to][ti][r][lane], row stride WS
-      const int lane = q % WS, r = (q / WS) & 15, ti = (q / (WS * 16)) % p.tiles[l], to = (q / (WS * 16)) / p.tiles[l];
-      row = (lane < 64) ? 32 * to + (lane & 31) : (1 << 20);
+    } else {  // [to][ti][r/4][lane][r%4]: one 128-bit read per lane = the A operands of 4 consecutive k-steps
+      const int j = q & 3, lane = (q >> 2) & 63, rq = (q >> 8) & 3, pr = q >> 10;
+      const int r = 4 * rq + j, ti = pr % p.tiles[l], to = pr / p.tiles[l];
+      row = 32 * to + (lane & 31);
       col = 32 * ti + row_of(r, lane >> 5);
     }
     if (row < out_d && col < in_d) v = a.W[l][(int64_t)row * in_d + col];

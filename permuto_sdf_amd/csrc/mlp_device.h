@@ -42,7 +42,7 @@ static int make_plan(int n_layers, const int* dims, MlpPlan& p) {
     else if (last && p.final_dot)
       off += dims[n_layers] * p.tiles[l] * 32;
     else
-      off += p.tiles[l + 1] * p.tiles[l] * 16 * WS;
+      off += p.tiles[l + 1] * p.tiles[l] * 16 * 64;  // [to][ti][r/4][lane][r%4]: one ds_read_b128 feeds 4 MFMAs
     p.b_off[l] = off;
     off += (last && p.final_dot) ? 4 : p.tiles[l + 1] * 32;
   }
@@ -105,18 +105,25 @@ __device__ __forceinline__ void apply_gelu(f32x16 (&acc)[T]) {
 }
 
 // out^T = W * in^T for register-resident activations (chained layout, see header).
+// Weight image of a chain layer: [(to,ti)][rq][lane][j] = A operand of k-step r = 4 rq + j, so one 128-bit LDS read
+// per lane (conflict free: consecutive lanes, 16 bytes each) serves four MFMAs.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
 template <int TI, int TO>
 __device__ __forceinline__ void dense_chain(const f32x16 (&in)[TI], f32x16 (&out)[TO], const float* __restrict__ w_lds,
                                             int lane) {
 #pragma unroll
   for (int ti = 0; ti < TI; ti++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float b = in[ti][r];
+    for (int rq = 0; rq < 4; rq++) {
+      f32x4w a[TO];
 #pragma unroll
-      for (int to = 0; to < TO; to++) {
-        const float a = w_lds[((to * TI + ti) * 16 + r) * WS + lane];
-        out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, out[to], 0, 0, 0);
+      for (int to = 0; to < TO; to++)
+        a[to] = *reinterpret_cast<const f32x4w*>(w_lds + (((to * TI + ti) * 4 + rq) * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float b = in[ti][4 * rq + j];
+#pragma unroll
+        for (int to = 0; to < TO; to++) out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[to][j], b, out[to], 0, 0, 0);
       }
     }
 }
