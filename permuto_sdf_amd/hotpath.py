@@ -58,7 +58,8 @@ class SdfHotPath:
         return pred, dict(feat=feat, packed=packed, sdf=sdf, alpha=alpha, one_minus=one_minus, T=T, bg=bg, w=w, w_sum=w_sum)
 
     # ------------------------------------------------------------------ backward (+ optional all-reduce and optimiser)
-    def backward(self, rs, rgb_samples, saved, grad_pred, grad_sdf=None, reduce=True, optimizer_step=True):
+    def backward(self, rs, rgb_samples, saved, grad_pred, grad_sdf=None, reduce=True, optimizer_step=True,
+                 split_levels=None):
         """Backward through integrate -> weights -> transmittance (the reference's native backward kernels), then the
         fused MLP and the encoding.  The reference has no native sdf->alpha backward (its training path computes alpha
         with torch elementwise ops); `grad_sdf` is therefore an input (default: ones), as in SURVEY.md section 8d cfg 2."""
@@ -83,12 +84,27 @@ class SdfHotPath:
         g_lat = torch.zeros_like(self.enc.lattice_values)
         if self.events is not None:
             self.events["enc_bwd"][0].record()
-        encode_backward_raw(cfg, rs.samples_pos, self.enc.lattice_values, self.enc.scale_factor,
-                            self.enc.random_shift_per_level, self.window, d_feat, g_lat, None)
+        if split_levels is None:
+            split_levels = reduce and parallel.world_size() > 1
+        if split_levels:
+            # Data parallel: the lattice gradient (4*L*T*F bytes) is the only large message of the step.  The levels
+            # are independent, so the backward runs as two launches over level ranges of about equal cost (fine levels
+            # are the expensive ones) and the all-reduce of the first range travels over xGMI while the second range is
+            # still being computed.
+            L_ = cfg.nr_levels
+            cut = max(1, min(L_ - 1, (9 * L_ + 15) // 16))
+            for l0, l1 in ((0, cut), (cut, L_)):
+                self._encode_backward_levels(rs.samples_pos, d_feat, g_lat, l0, l1)
+                if reduce:
+                    buckets.reduce([g_lat[l0:l1]])
+        else:
+            encode_backward_raw(cfg, rs.samples_pos, self.enc.lattice_values, self.enc.scale_factor,
+                                self.enc.random_shift_per_level, self.window, d_feat, g_lat, None)
+            if reduce:
+                buckets.reduce([g_lat])
         if self.events is not None:
             self.events["enc_bwd"][1].record()
         if reduce:
-            buckets.reduce([g_lat])
             buckets.finish()
         grads = [g_lat] + [t for pair in zip(dWs, dbs) for t in pair]
         if optimizer_step:
@@ -96,6 +112,18 @@ class SdfHotPath:
                 p.grad = g
             self.opt.step(grad_scale=1.0 / parallel.world_size())
         return dict(g_rgb=g_rgb, g_one_minus=g_om, grads=grads)
+
+    def _encode_backward_levels(self, pos, d_feat, g_lat, l0, l1):
+        """lattice gradient of levels [l0, l1) only: every operand of the kernel is contiguous per level (tables
+        [L,T,F], constants [L,P], window [L], feature-major upstream gradient [2L+.., N]), so a level range is just a
+        set of offset pointers and the C ABI needs no extra entry point."""
+        from .encoding import _Cfg
+        c = self.enc.cfg
+        sub = _Cfg(c.pos_dim, c.capacity, l1 - l0, c.nr_feat, False, 1.0)
+        F = c.nr_feat
+        encode_backward_raw(sub, pos, self.enc.lattice_values[l0:l1], self.enc.scale_factor[l0:l1],
+                            self.enc.random_shift_per_level[l0:l1], self.window[l0:l1], d_feat[F * l0:F * l1],
+                            g_lat[l0:l1], None)
 
     def step(self, rs, rgb_samples, grad_pred, **kw):
         pred, saved = self.forward(rs, rgb_samples)

@@ -98,3 +98,21 @@ def test_cfg2_fullsize_forward_consistency(dev):
         y2 = mlp.forward_feature_major(enc.forward_feature_major(pts, win)).t()
         assert torch.equal(y1, y2)
         assert bool(torch.isfinite(y1).all())
+
+
+def test_level_split_backward_equals_single_launch(dev):
+    """hotpath.backward(split_levels=True) (the data-parallel schedule: two launches over level ranges, all-reduce of
+    the first range overlapping the second) produces the same lattice gradient as the single launch."""
+    import bench
+    from permuto_sdf_amd.hotpath import SdfHotPath
+    hp = SdfHotPath(nr_levels=16, hidden=64, out_channels=1, device=dev, seed=0)
+    rs, rgb, _ = bench.make_batch(dev, 11, nr_rays=4096)
+    grad_pred = torch.ones(4096, 3, device=dev)
+    pred, saved = hp.forward(rs, rgb)
+    a = hp.backward(rs, rgb, saved, grad_pred, reduce=False, optimizer_step=False, split_levels=False)["grads"][0]
+    b = hp.backward(rs, rgb, saved, grad_pred, reduce=False, optimizer_step=False, split_levels=True)["grads"][0]
+    scale = float(a.abs().max())
+    assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale
+    for l in range(16):     # per level, not only globally
+        s = float(a[l].abs().max())
+        assert float((a[l] - b[l]).abs().max()) <= 5e-5 * max(s, 1e-12), l
