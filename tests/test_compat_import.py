@@ -1,0 +1,47 @@
+"""the reference's Python imports UNMODIFIED against the drop-in packages + compat/ stand-ins.
+Needs the reference checkout (this container only; skipped elsewhere).  Runs in a subprocess so that the stand-ins
+(PYTHONPATH, sitecustomize) never leak into the other tests."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+SCRIPT = r'''
+import importlib
+mods = ["permuto_sdf_py.utils.common_utils", "permuto_sdf_py.volume_rendering.volume_rendering_funcs",
+        "permuto_sdf_py.volume_rendering.volume_rendering_modules", "permuto_sdf_py.models.modules",
+        "permuto_sdf_py.models.models", "permuto_sdf_py.utils.nerf_utils", "permuto_sdf_py.utils.sdf_utils",
+        "permuto_sdf_py.utils.permuto_sdf_utils", "permuto_sdf_py.schedulers.multisteplr",
+        "permuto_sdf_py.schedulers.warmup", "permuto_sdf_py.callbacks.callback_utils"]
+for m in mods:
+    importlib.import_module(m)
+import permuto_sdf, permutohedral_encoding, torch
+from permuto_sdf_py.models.models import SDF, LipshitzMLP
+assert permuto_sdf.OccupancyGrid.__module__.startswith("permuto_sdf_amd")
+assert permutohedral_encoding.PermutoEncoding.__module__.startswith("permuto_sdf_amd")
+# the reference's SDF model builds on the drop-in encoding (CPU construction; evaluation needs the GPU)
+sdf = SDF(3, None, 32, 10000)
+assert sdf.encoding.output_dims() == sdf.mlp_sdf[0].in_features
+names = dict(sdf.named_parameters())
+assert any("lattice_values" in k for k in names)            # models.py:408-420 looks parameters up by this name
+# the training script itself: everything up to the first CUDA call at module level must import
+try:
+    importlib.import_module("permuto_sdf_py.train_permuto_sdf")
+    print("TRAIN_IMPORT full")
+except (RuntimeError, AssertionError, TypeError) as e:
+    assert "cuda" in str(e).lower() or "CUDA" in str(e) or "not available" in str(e), e
+    print("TRAIN_IMPORT up-to-cuda")
+print("COMPAT_OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "permuto_sdf_py")), reason="reference checkout not present")
+def test_reference_python_imports_unmodified():
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "compat"), REF])
+    r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
+    assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
