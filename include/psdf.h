@@ -96,7 +96,8 @@ int psdf_grid_update_with_sdf(int count, const int* voxel_indices, const float* 
 int psdf_grid_check_occupancy(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const
     uint8_t* grid_occupancy, const float* points, uint8_t* out, void* stream);
 
-/* replaces: OccupancyGrid::compute_samples_in_occupied_regions (src/OccupancyGrid.cu:212-257) and RaySampler::compute_samples_fg (src/RaySampler.cu:104-152) */
+/* replaces: OccupancyGrid::compute_samples_in_occupied_regions (src/OccupancyGrid.cu:212-257) and RaySampler::compute_samples_fg (src/RaySampler.cu:104-152);
+   scratch: nr_rays * (3 + max_nr_samples_per_ray) 4-byte words */
 int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
     const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs, const float* ray_t_entry, const
     float* ray_t_exit, float min_dist_between_samples, int max_nr_samples_per_ray, int max_nr_samples, uint64_t

@@ -358,7 +358,7 @@ class OccupancyGrid:
         L.require_cuda(o, d, te, tx)
         R = o.shape[0]
         rs = RaySamplesPacked(R, self.max_nr_samples, device=o.device)
-        scratch = torch.empty(2 * max(R, 1), dtype=torch.int32, device=o.device)
+        scratch = torch.empty(max(R, 1) * (3 + int(max_nr_samples_per_ray)), dtype=torch.int32, device=o.device)
         rng = OccupancyGrid._rng
         L.call("psdf_march_samples", L.c_i(1), L.c_i(R), *self._grid_args(), L.ptr(self._occ()), L.ptr(o), L.ptr(d),
                L.ptr(te), L.ptr(tx), L.c_f(min_dist_between_samples), L.c_i(int(max_nr_samples_per_ray)),
@@ -439,7 +439,7 @@ class RaySampler:
         L.require_cuda(o, d, te, tx)
         R = o.shape[0]
         rs = RaySamplesPacked(R, R * int(max_nr_samples_per_ray), device=o.device)
-        scratch = torch.empty(2 * max(R, 1), dtype=torch.int32, device=o.device)
+        scratch = torch.empty(max(R, 1) * (3 + int(max_nr_samples_per_ray)), dtype=torch.int32, device=o.device)
         rng = RaySampler._rng
         L.call("psdf_march_samples", L.c_i(0), L.c_i(R), L.c_i(1), L.c_f(1.0), _host3([0.0, 0.0, 0.0]), None, L.ptr(o),
                L.ptr(d), L.ptr(te), L.ptr(tx), L.c_f(min_dist_between_samples), L.c_i(int(max_nr_samples_per_ray)),

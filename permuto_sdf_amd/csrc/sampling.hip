@@ -164,13 +164,18 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // One thread per ray (the march is inherently serial and its float sequence is an index-exact contract).
 // WRITE=false: count the samples this ray will emit.  WRITE=true: emit them at offsets[ray].
 // USE_GRID=false gives the reference's compute_samples_fg (RaySamplerGPU.cuh:162) = same march without occupancy.
-template <bool WRITE, bool USE_GRID>
+// Pass 1 of 3 (thread per ray): the reference's two marches (occupied length, then sample placement) run ONCE; the
+// distances t of the samples it places go to a per-ray scratch row, the count and the spacing to per-ray scratch.
+// Pass 2 is an exclusive scan of the counts; pass 3 (march_fill_kernel, wave per ray) turns the t values into samples
+// at the ray's exact offset with coalesced stores.  (The first version of this file ran the whole march twice, once
+// to count and once to write: the DDA loop is a chain of dependent 1-byte grid probes, the most expensive thing in a
+// volume render after the network itself.)
+template <bool USE_GRID>
 __global__ void __launch_bounds__(PSDF_BLOCK)
     march_kernel(int nr_rays, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ origins,
                  const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
-                 float min_dist, int max_per_ray, int max_nr_samples, Pcg rng, int jitter, const int* __restrict__ offsets,
-                 int* __restrict__ counts, float* __restrict__ s_pos, float* __restrict__ s_dirs, float* __restrict__ s_z,
-                 float* __restrict__ s_dt, float* __restrict__ ray_fixed_dt, int* __restrict__ start_end) {
+                 float min_dist, int max_per_ray, Pcg rng, int jitter, int* __restrict__ counts,
+                 float* __restrict__ spacings, float* __restrict__ ztemp) {
   const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (ray >= nr_rays) return;
   const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
@@ -200,26 +205,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   to_create = clampi(to_create, 0, max_per_ray);
   const float spacing = occupied / to_create;
   int created = 0;
-  int base = 0;
-  float last_z = 0.f;
-  bool go = USE_GRID ? (to_create > 1) : (to_create > 1 && occupied > DDA_EPS);
-  if (WRITE) {
-    // the count pass already ran the identical march: skip rays that emit nothing, and never write past the pool
-    const int cnt = counts[ray];
-    base = offsets[ray];
-    if (cnt == 0) {  // empty range at the running offset: the layout the reference has after its compaction pass
-      start_end[2 * ray] = base;
-      start_end[2 * ray + 1] = base;
-      ray_fixed_dt[ray] = 0.f;
-      return;
-    }
-    if (base + cnt > max_nr_samples) {  // reservation overflows the pool: keep the range so consumers skip the ray
-      start_end[2 * ray] = base;
-      start_end[2 * ray + 1] = base + cnt;
-      ray_fixed_dt[ray] = spacing;
-      return;
-    }
-  }
+  float* __restrict__ zrow = ztemp + (int64_t)ray * max_per_ray;
+  const bool go = USE_GRID ? (to_create > 1) : (to_create > 1 && occupied > DDA_EPS);
   if (go) {
     float t = t_start;
     int steps = 0;
@@ -229,22 +216,15 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     }
     while (t < t_exit && steps < MAX_DDA_STEPS) {
       t = fmaxf(t_start, fminf(t, t_exit));
-      const v3 pos = along(org, t, dir);
       bool occupied_here = true;
+      v3 pos = along(org, t, dir);
       if (USE_GRID) {
         const int vox = g.pos_to_idx(pos);
         if (!g.in_range(vox)) break;
         occupied_here = occ[vox];
       }
       if (occupied_here && created < to_create) {
-        if (WRITE) {
-          const int64_t o = base + created;
-          st3(s_pos + 3 * o, pos);
-          st3(s_dirs + 3 * o, dir);
-          s_z[o] = t;
-          s_dt[o] = spacing;
-        }
-        last_z = t;
+        zrow[created] = t;
         t += spacing;
         created++;
       } else if (USE_GRID) {
@@ -259,20 +239,48 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     }
     if (created <= 2) created = 0;  // rays with <= 2 samples are dropped (OccupancyGridGPU.cuh:685-689)
   }
-  if (!WRITE) {
-    counts[ray] = created;
+  counts[ray] = created;
+  spacings[ray] = spacing;
+}
+
+// Pass 3 (wave per ray): samples from the stored distances, at the ray's exact offset.
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    march_fill_kernel(int nr_rays, const float* __restrict__ origins, const float* __restrict__ dirs,
+                      const float* __restrict__ t_exit_p, int max_per_ray, int max_nr_samples,
+                      const int* __restrict__ offsets, const int* __restrict__ counts, const float* __restrict__ spacings,
+                      const float* __restrict__ ztemp, float* __restrict__ s_pos, float* __restrict__ s_dirs,
+                      float* __restrict__ s_z, float* __restrict__ s_dt, float* __restrict__ ray_fixed_dt,
+                      int* __restrict__ start_end) {
+  const int ray = blockIdx.x * (PSDF_BLOCK / 64) + (threadIdx.x >> 6);
+  if (ray >= nr_rays) return;
+  const int lane = threadIdx.x & 63;
+  const int cnt = counts[ray], base = offsets[ray];
+  const float spacing = spacings[ray];
+  if (cnt == 0) {  // empty range at the running offset: the layout the reference has after its compaction pass
+    if (lane == 0) {
+      start_end[2 * ray] = base;
+      start_end[2 * ray + 1] = base;
+      ray_fixed_dt[ray] = 0.f;
+    }
     return;
   }
-  if (created > 0) {
+  if (lane == 0) {
     start_end[2 * ray] = base;
-    start_end[2 * ray + 1] = base + created;
+    start_end[2 * ray + 1] = base + cnt;
     ray_fixed_dt[ray] = spacing;
+  }
+  if (base + cnt > max_nr_samples) return;  // reservation overflows the pool: the range stays so consumers skip the ray
+  const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
+  const float t_exit = t_exit_p[ray];
+  const float* __restrict__ zrow = ztemp + (int64_t)ray * max_per_ray;
+  for (int i = lane; i < cnt; i += 64) {
+    const float t = zrow[i];
+    const int64_t o = base + i;
+    st3(s_pos + 3 * o, along(org, t, dir));
+    st3(s_dirs + 3 * o, dir);
+    s_z[o] = t;
     // the last sample may sit closer than `spacing` to the exit
-    s_dt[base + created - 1] = fmaxf(0.0f, fminf(t_exit - last_z, spacing));
-  } else {
-    start_end[2 * ray] = 0;
-    start_end[2 * ray + 1] = 0;
-    ray_fixed_dt[ray] = 0.f;
+    s_dt[o] = (i == cnt - 1) ? fmaxf(0.0f, fminf(t_exit - t, spacing)) : spacing;
   }
 }
 
@@ -771,7 +779,7 @@ int psdf_grid_check_occupancy(int count, int nr_voxels_per_dim, float extent, co
 }
 
 // use_grid=1: OccupancyGrid::compute_samples_in_occupied_regions; use_grid=0: RaySampler::compute_samples_fg.
-// scratch: 2*nr_rays ints.  cur_nr_samples (device int) receives the exact total.
+// scratch: nr_rays * (3 + max_nr_samples_per_ray) 4-byte words.  cur_nr_samples (device int) receives the exact total.
 int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
                        const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs,
                        const float* ray_t_entry, const float* ray_t_exit, float min_dist_between_samples,
@@ -779,26 +787,26 @@ int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float e
                        float* samples_pos, float* samples_dirs, float* samples_z, float* samples_dt, float* ray_fixed_dt,
                        int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream) {
   if (nr_rays <= 0) return PSDF_OK;
+  if (max_nr_samples_per_ray < 0 || !scratch) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   Grid g = use_grid ? mk_grid(nr_voxels_per_dim, extent, grid_translation) : Grid{1, 1.f, 0.f, 0.f, 0.f};
   Pcg rng{rng_state, rng_inc};
   int* counts = scratch;
   int* offsets = scratch + nr_rays;
-#define MARCH(W_, G_)                                                                                                  \
-  hipLaunchKernelGGL((march_kernel<W_, G_>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs,          \
-                     ray_t_entry, ray_t_exit, min_dist_between_samples, max_nr_samples_per_ray, max_nr_samples, rng,     \
-                     jitter, offsets, counts, samples_pos, samples_dirs, samples_z, samples_dt, ray_fixed_dt,            \
-                     ray_start_end_idx)
+  float* spacings = reinterpret_cast<float*>(scratch + 2 * (int64_t)nr_rays);
+  float* ztemp = reinterpret_cast<float*>(scratch + 3 * (int64_t)nr_rays);
+#define MARCH(G_)                                                                                                     \
+  hipLaunchKernelGGL((march_kernel<G_>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs, ray_t_entry, \
+                     ray_t_exit, min_dist_between_samples, max_nr_samples_per_ray, rng, jitter, counts, spacings, ztemp)
   if (use_grid)
-    MARCH(false, true);
+    MARCH(true);
   else
-    MARCH(false, false);
-  hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, counts, offsets, cur_nr_samples);
-  if (use_grid)
-    MARCH(true, true);
-  else
-    MARCH(true, false);
+    MARCH(false);
 #undef MARCH
+  hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, counts, offsets, cur_nr_samples);
+  hipLaunchKernelGGL(march_fill_kernel, dim3((nr_rays + 3) / 4), dim3(PSDF_BLOCK), 0, st, nr_rays, ray_origins, ray_dirs,
+                     ray_t_exit, max_nr_samples_per_ray, max_nr_samples, offsets, counts, spacings, ztemp, samples_pos,
+                     samples_dirs, samples_z, samples_dt, ray_fixed_dt, ray_start_end_idx);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
