@@ -208,10 +208,10 @@ def main():
         # as MI355X_MICROARCH.md prescribes; null when no summary for the dominant kernel is on file.
         roof["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic_v2.json")))
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic_v3.json")))
             key = {"enc_bwd": ["encode_bwd_kernel", "encode_bwd_reduce_kernel"], "mlp_bwd": ["mlp_bwd_kernel"]}[dom]
             roof["traffic"] = int(sum(pmc["kernels"][k]["hbm_bytes"] for k in key))
-            roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic_v2.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+            roof["traffic_source"] = "profiles/r01_pmc_hbm_traffic_v3.json (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
         except Exception:
             pass
         other = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "avg_launch_ms")} for k, v in cand.items() if k != dom}
