@@ -198,7 +198,7 @@ def main():
                         "achieved": mlp_flops / (ms["mlp_bwd"] * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "avg_launch_ms": ms["mlp_bwd"], "algorithmic_flops_per_launch": mlp_flops,
                         "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32, same 157.3 TF peak as 32x32x2); the forward "
-                                "recomputation inside the kernel is extra, uncounted work (MFMA pipe busy 42 % by SQ counters)"},
+                                "recomputation inside the kernel is extra, uncounted work (MFMA pipe busy 49 % by SQ counters)"},
         }
         dom = max(cand, key=lambda k: ms[k])
         roof = cand[dom]
