@@ -14,6 +14,8 @@
 //   * Each activation is visited ONCE: gelu(z) and gelu'(z) come out of one erf + one exp evaluation and are kept;
 //     z itself is dropped.
 //   * The forward is recomputed from X (the encoding output) -- nothing but X is saved by the forward pass.
+//   * The layer-0 operand of the next tile is prefetched with global_load_lds; weight operands are read 128 bits at a
+//     time (one ds_read_b128 = the A operands of four MFMAs).
 //   * At the end every wave adds its accumulators into a workgroup image in LDS (once per launch, so the slow LDS
 //     atomics do not matter) and the workgroup flushes that image with one global atomic per parameter.
 //
@@ -23,10 +25,9 @@
 //             -> register r of a T tile IS the B operand of k-step (t, r) of the next layer: no data movement;
 //   "NT" tile (lane = neuron): lane (g, c=neuron), reg r = value(neuron 16t+c, sample 4g+r)
 //             -> A (dZ) and B (H) operands of dW; obtained from a T tile by one 16x17-float LDS transpose per wave.
-//   weights in LDS: chain layer  Wp[((to*TI+ti)*4 + r)*65 + lane] = W[16to + c][16ti + 4g + r]
-//                   layer 0      Wp[(to*S0 + s)*65 + lane]        = W[16to + c][4s + g]
-//   The same image serves the data-gradient chain (A operand = W^T) through a transposed read (2-way bank conflict).
-//   The image is built by the kernel itself from the torch-layout parameters (no separate packing pass).
+//   weights in LDS: see struct Img below (separate forward / transposed images read 128 bits at a time); the images
+//   are built by the kernel itself from the torch-layout parameters (no separate packing pass).  The packed layout of
+//   Plan16 (row stride 65) is only the layout of the GRADIENT image the workgroup flushes at the end.
 #include "mlp_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -138,31 +139,6 @@ __device__ __forceinline__ void gelu_both(const f32x4 (&z)[T], f32x4 (&h)[T], f3
     }
 }
 
-// out^T = W * in^T  (chain layout)
-template <int TI, int TO>
-__device__ __forceinline__ void chain_fwd(const f32x4 (&in)[TI], f32x4 (&out)[TO], const float* __restrict__ w, int lane) {
-#pragma unroll
-  for (int ti = 0; ti < TI; ti++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float b = in[ti][r];
-#pragma unroll
-      for (int to = 0; to < TO; to++) out[to] = MFMA16(w[((to * TI + ti) * 4 + r) * WS + lane], b, out[to]);
-    }
-}
-// dh^T[in] += W^T dz^T[out]  (transposed read of the same image)
-template <int TO, int TI>
-__device__ __forceinline__ void chain_bwd(const f32x4 (&dz)[TO], f32x4 (&dh)[TI], const float* __restrict__ w, int g, int c) {
-  const int lane_off = (c & 3) * WS + (c >> 2) * 16 + 4 * g;
-#pragma unroll
-  for (int to = 0; to < TO; to++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float b = dz[to][r];
-#pragma unroll
-      for (int ti = 0; ti < TI; ti++) dh[ti] = MFMA16(w[(to * TI + ti) * 4 * WS + lane_off + r], b, dh[ti]);
-    }
-}
 // Cross-LANE exchange through LDS: the compiler proves that, for ONE thread, the write of register r and the read of
 // register r' != r never alias and interleaves them freely across __builtin_amdgcn_wave_barrier() (which is not a
 // memory barrier for LLVM).  A wavefront-scope fence pair is: it costs no instruction (LDS is in order within a wave).
