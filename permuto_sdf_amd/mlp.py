@@ -98,7 +98,30 @@ def _torch_gpu_backward(dims, x_fm, weights, biases, gy_fm, need_dx):
     return dx, list(outs[k:k + n_layers]), list(outs[k + n_layers:])
 
 
+def _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
+    """VJP of the map (x, params) -> dx = J_x^T gy with the upstream gradient v (what differentiating through the
+    analytic input gradient needs: eikonal / curvature losses, models.py:245-251), by torch autograd ON THE GPU.
+    Generic fallback for widths without a fused double-backward kernel.  -> (dX [C,N], [dW_l], [db_l])"""
+    n_layers = len(dims) - 1
+    with torch.enable_grad():
+        x = x_fm.t().detach().requires_grad_(True)
+        ws = [w.detach().requires_grad_(True) for w in weights]
+        bs = [b.detach().requires_grad_(True) for b in biases]
+        h = x
+        for i in range(n_layers):
+            h = torch.nn.functional.linear(h, ws[i], bs[i])
+            if i < n_layers - 1:
+                h = torch.nn.functional.gelu(h)
+        (gx,) = torch.autograd.grad(h, x, gy_fm.t(), create_graph=True)
+        outs = torch.autograd.grad(gx, [x] + ws + bs, v_fm.t(), allow_unused=True)
+    outs = [o if o is not None else torch.zeros_like(t) for o, t in zip(outs, [x] + ws + bs)]
+    return outs[0].t().contiguous(), list(outs[1:1 + n_layers]), list(outs[1 + n_layers:])
+
+
 class _FusedMLPFunc(torch.autograd.Function):
+    """y = MLP(x).  Its backward is itself a Function (_FusedMLPBackFunc) so that `create_graph=True` works: the
+    reference differentiates through d sdf / d x (models.py:236-251)."""
+
     @staticmethod
     def forward(ctx, module, x, *params):
         n_layers = module.n_layers
@@ -110,23 +133,63 @@ class _FusedMLPFunc(torch.autograd.Function):
         y = mlp_forward_raw(module.dims, x_fm, packed)
         ctx.module = module
         ctx.n_layers = n_layers
-        ctx.save_for_backward(x_fm, *weights, *biases)
+        ctx.save_for_backward(x, *weights, *biases)   # the INPUTS themselves: they keep their place in the graph
         return y.t()
 
     @staticmethod
     def backward(ctx, gy):
-        module = ctx.module
-        x_fm = ctx.saved_tensors[0]
-        weights = ctx.saved_tensors[1:1 + ctx.n_layers]
-        biases = ctx.saved_tensors[1 + ctx.n_layers:]
+        x = ctx.saved_tensors[0]
+        params = ctx.saved_tensors[1:]
+        outs = _FusedMLPBackFunc.apply(ctx.module, ctx.needs_input_grad[1], x, gy, *params)
+        dx = outs[0] if ctx.needs_input_grad[1] else None
+        return (None, dx, *outs[1:])
+
+
+class _FusedMLPBackFunc(torch.autograd.Function):
+    """(x, gy, params) -> (dx, dW.., db..).  backward: only the path from dx is propagated (into x and the parameters);
+    second derivatives through dW/db are never needed by the reference and are not provided."""
+
+    @staticmethod
+    def forward(ctx, module, need_dx, x, gy, *params):
+        n_layers = module.n_layers
+        weights, biases = params[:n_layers], params[n_layers:]
+        x_fm = x.t()
+        if not x_fm.is_contiguous():
+            x_fm = x_fm.contiguous()
         gy_fm = gy.t()
         if not gy_fm.is_contiguous():
             gy_fm = gy_fm.contiguous()
         if backward_supported(module.dims):
-            dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=ctx.needs_input_grad[1])
+            dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=need_dx)
         else:
-            dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, ctx.needs_input_grad[1])
-        return (None, dx.t() if dx is not None else None, *dWs, *dbs)
+            dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, need_dx)
+        ctx.module, ctx.n_layers = module, n_layers
+        ctx.save_for_backward(x_fm, gy_fm, *weights, *biases)
+        if dx is None:
+            dx_out = torch.zeros((), device=x.device)
+            ctx.mark_non_differentiable(dx_out)
+        else:
+            dx_out = dx.t()
+        return (dx_out, *dWs, *dbs)
+
+    @staticmethod
+    def backward(ctx, g_dx, *g_params):
+        n_layers = ctx.n_layers
+        x_fm, gy_fm = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        weights = ctx.saved_tensors[2:2 + n_layers]
+        biases = ctx.saved_tensors[2 + n_layers:]
+        if g_dx is None:
+            return (None,) * (4 + 2 * n_layers)
+        v_fm = g_dx.t()
+        if not v_fm.is_contiguous():
+            v_fm = v_fm.contiguous()
+        dX, dWs, dbs = mlp_double_backward(ctx.module.dims, x_fm, weights, biases, gy_fm, v_fm)
+        return (None, None, dX.t(), None, *dWs, *dbs)
+
+
+def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
+    """-> (dX [C,N], [dW_l], [db_l]) of <dx(x, params; gy), v>; fused kernel where one is built, torch (GPU) otherwise"""
+    return _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm)
 
 
 class FusedMLP(torch.nn.Module):

@@ -128,3 +128,32 @@ def test_lipshitz_mlp_matches_reference_formula(dev, dims, last_linear):
     for a, b in zip(got, ref):
         assert (a - b).abs().max() <= 2e-4 * max(1e-6, b.abs().max().item())
     assert float(m.lipshitz_bound_full()) > 0
+
+
+@pytest.mark.parametrize("dims", [[52, 32, 32, 32, 33], [36, 64, 64, 64, 1], [20, 32, 32, 32, 1]])
+def test_double_backward_through_input_gradient(dev, dims):
+    """create_graph=True through the fused evaluator (reference: models.py:236-251, eikonal loss): gradients of a loss on
+    d y0 / d x with respect to the input and every parameter, against torch.nn in fp64."""
+    from permuto_sdf_amd import FusedMLP
+    torch.manual_seed(3)
+    ref = _ref_net(dims)
+    ref64 = _ref_net(dims).double()
+    ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    m = FusedMLP.from_sequential(ref).to(dev)
+    x = torch.randn(700, dims[0])
+
+    def loss_of(net, xin):
+        y = net(xin)
+        (g,) = torch.autograd.grad(y[:, 0:1], xin, torch.ones_like(y[:, 0:1]), create_graph=True)
+        return ((g.norm(dim=1) - 1.0) ** 2).mean() + 0.1 * y.pow(2).mean()
+
+    x64 = x.double().requires_grad_(True)
+    loss_of(ref64, x64).backward()
+    xd = x.to(dev).requires_grad_(True)
+    loss_of(m, xd).backward()
+    sc = lambda t: max(1e-9, t.abs().max().item())
+    assert (xd.grad.cpu().double() - x64.grad).abs().max() <= 2e-4 * sc(x64.grad)
+    lin64 = [l for l in ref64 if isinstance(l, torch.nn.Linear)]
+    for a, b in zip(m.layers, lin64):
+        assert (a.weight.grad.cpu().double() - b.weight.grad).abs().max() <= 2e-4 * sc(b.weight.grad)
+        assert (a.bias.grad.cpu().double() - b.bias.grad).abs().max() <= 2e-4 * sc(b.bias.grad)
