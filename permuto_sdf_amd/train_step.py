@@ -109,19 +109,17 @@ def _lattice(pos_dim, points_scaling):
 
 
 class SdfNet(torch.nn.Module):
-    """models.py:131-251: 24-level lattice + Linear(52,32)-GELU-(32,32)-GELU-(32,32)-GELU-(32,1+32).  The MLP stays a
-    torch.nn.Sequential on the differentiable path because the eikonal/curvature losses differentiate THROUGH its
-    gradient (create_graph=True); the no-grad path (`sdf_only`) is one fused launch."""
+    """models.py:131-251: 24-level lattice + Linear(52,32)-GELU-(32,32)-GELU-(32,32)-GELU-(32,1+32) in the fused
+    evaluator (twice differentiable: the eikonal/curvature losses differentiate THROUGH its input gradient,
+    create_graph=True); the no-grad path (`sdf_only`) is one fused encode->MLP launch."""
 
     def __init__(self, hp):
         super().__init__()
         self.encoding = _lattice(3, 1e-3)
         g = hp.sdf_geom_feat_size
-        self.mlp_sdf = torch.nn.Sequential(torch.nn.Linear(self.encoding.output_dims(), 32), torch.nn.GELU(),
-                                           torch.nn.Linear(32, 32), torch.nn.GELU(), torch.nn.Linear(32, 32),
-                                           torch.nn.GELU(), torch.nn.Linear(32, 1 + g))
-        with torch.no_grad():  # start as a sphere-ish field of radius ~0.3 so that the samplers have something to hit
-            self.mlp_sdf[-1].bias[0] += 1e-2
+        self.mlp_sdf = FusedMLP([self.encoding.output_dims(), 32, 32, 32, 1 + g])
+        with torch.no_grad():  # models.py:163-165: the shift sits in the bias of the SDF row
+            self.mlp_sdf.layers[-1].bias[0] += 1e-2
         self.c2f = Coarse2Fine(24)
         self.nr_iters_for_c2f = hp.sdf_nr_iters_for_c2f
 
@@ -135,7 +133,7 @@ class SdfNet(torch.nn.Module):
     @torch.no_grad()
     def sdf_only(self, points, it):
         """[N,1]; the SDF is row 0 of the last layer (models.py:190)"""
-        lin = [m for m in self.mlp_sdf if isinstance(m, torch.nn.Linear)]
+        lin = list(self.mlp_sdf.layers)
         ws, bs = [l.weight for l in lin], [l.bias for l in lin]
         ws[-1], bs[-1] = ws[-1][0:1].contiguous(), bs[-1][0:1].contiguous()
         dims = [lin[0].in_features, 32, 32, 32, 1]
