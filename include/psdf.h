@@ -65,6 +65,13 @@ int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, c
 int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights, const
     float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 
+/* replaces: the second differentiation torch autograd performs for the reference's eikonal / curvature losses
+   (get_sdf_and_gradient with create_graph=True, models.py:236-251): VJP of (X, params) -> dX = J^T dY with upstream
+   gradient V [dims[0], N]; dX2 receives d/dX, dW[l] / db[l] are accumulated into; 3 hidden layers */
+int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+    const float* const* biases, const float* dY, const float* V, float* dX2, float* const* dW, float* const* db,
+    void* stream);
+
 /* ---- fused.hip ---- */
 /* replaces: models.py:186-192 `point_features=self.encoding(points, window); sdf_and_feat=self.mlp_sdf(point_features)`
    as ONE launch that never materialises the feature tensor (pos_dim 3, 2 features/level).  dims[0] must be

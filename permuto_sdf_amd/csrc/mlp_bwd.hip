@@ -186,6 +186,15 @@ struct LayerAcc {
       ab[to] += (dz_nt[to][0] + dz_nt[to][1]) + (dz_nt[to][2] + dz_nt[to][3]);
     }
   }
+  // same product without the bias term (contributions that are not d/dz of the forward layer)
+  __device__ __forceinline__ void add_nb(const f32x4 (&a_nt)[TO], const f32x4 (&b_nt)[TI]) {
+#pragma unroll
+    for (int to = 0; to < TO; to++)
+#pragma unroll
+      for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) aw[to][ti] = MFMA16(a_nt[to][s], b_nt[ti][s], aw[to][ti]);
+  }
   // once per wave: into the workgroup image (chain-layer layout)
   __device__ __forceinline__ void flush_chain(float* __restrict__ acc_w, float* __restrict__ acc_b, int g, int c) {
     const int lane_off = (c & 3) * WS + (c >> 2) * 16 + 4 * g;
@@ -596,6 +605,383 @@ __global__ void __launch_bounds__(BW * 64)
   }
 }
 
+// ======================================================================================================
+// DOUBLE backward: the vector-Jacobian product of the map (X, params) -> dX = J_X^T gy with an upstream gradient V,
+// i.e. what differentiating THROUGH the analytic input gradient of the net needs (the reference's eikonal and
+// curvature losses: get_sdf_and_gradient with create_graph=True, permuto_sdf_py/models/models.py:236-251, followed by
+// loss.backward()).  With a_l = gelu'(z_l), c_l = gelu''(z_l) and the first-order chain
+//   q3 = W3^T gy, u3 = a3*q3, q2 = W2^T u3, u2 = a2*q2, q1 = W1^T u2, u1 = a1*q1, dX = W0^T u1
+// the adjoint is one forward-like sweep
+//   du1 = W0 V,  dW0 += u1 V^T,  da1 = du1*q1, dq1 = du1*a1,  du2 = W1 dq1,  dW1 += u2 dq1^T,  ... dW3 += gy dq3^T
+// followed by an ordinary backward sweep of the forward net with the injected pre-activation gradients
+//   dz3 = da3*c3,  dz2 = (W2^T dz3)*a2 + da2*c2,  dz1 = (W1^T dz2)*a1 + da1*c1,  dX2 = W0^T dz1,  dW_l += dz_{l+1} h_l^T.
+// Same tile shape, weight images, persistent dW accumulators and LDS-DMA staging (of X and V) as mlp_bwd_kernel.
+template <int T>
+__device__ __forceinline__ void gelu3(const f32x4 (&z)[T], f32x4 (&h)[T], f32x4 (&a1)[T], f32x4 (&c2)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const float x = z[t][r];
+      const float one_erf = 1.0f + erf_fast(x * 0.70710678118654752440f);
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+      h[t][r] = 0.5f * x * one_erf;
+      a1[t][r] = fmaf(x, pdf, 0.5f * one_erf);  // Phi + x phi
+      c2[t][r] = pdf * (2.0f - x * x);           // 2 phi + x phi' = phi (2 - x^2)
+    }
+}
+template <int T>
+__device__ __forceinline__ void mul16(const f32x4 (&a)[T], const f32x4 (&b)[T], f32x4 (&out)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; t++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[t][r] = a[t][r] * b[t][r];
+}
+template <int T>
+__device__ __forceinline__ void to_nt_all(const f32x4 (&in)[T], f32x4 (&out)[T], float* buf, int g, int c) {
+#pragma unroll
+  for (int t = 0; t < T; t++) to_nt(in[t], out[t], buf, g, c);
+}
+
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+__global__ void __launch_bounds__(BW * 64)
+    mlp_dbl_bwd_kernel(Plan16 p, int64_t N, const float* __restrict__ X, const float* __restrict__ V,
+                       const float* __restrict__ dY, float* __restrict__ dX2, BwdPtrs a) {
+  static_assert(T3 > 0, "three hidden layers");
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int SX = 4 * TI0;
+  constexpr int WAVE_LDS = 16 * 17 + 16 + 4 * SX * 64;   // transpose buffer, dy, 2 x X tile, 2 x V tile
+  constexpr int OTS = FINAL_DOT ? 1 : OUT_T;
+  using IM = Img<TI0, T1, T2, T3, OTS, FINAL_DOT>;
+  const int img = IM::TOTAL > p.total ? IM::TOTAL : ((p.total + 3) & ~3);
+  float* tbuf = lds + img + wave * WAVE_LDS;
+  float* dyb = tbuf + 16 * 17;
+  float* xbuf = dyb + 16;
+  float* vbuf = xbuf + 2 * SX * 64;
+  {
+    const int tid = threadIdx.x, nt = BW * 64;
+    const int d0 = p.dims[0], d1 = p.dims[1], d2 = p.dims[2], d3 = p.dims[3];
+    for (int e = tid; e < T1 * TI0 * 256; e += nt) {
+      const int j = e & 3, ln = (e >> 2) & 63, gg = ln >> 4, cc = ln & 15;
+      {
+        const int pr = e >> 8, s4 = pr % TI0, to = pr / TI0;
+        lds[IM::F0 + e] = ld_w(a.W[0], d1, d0, 16 * to + cc, 4 * (4 * s4 + j) + gg);
+      }
+      {
+        const int pr = e >> 8, to = pr % T1, t = pr / T1;
+        lds[IM::B0 + e] = ld_w(a.W[0], d1, d0, 16 * to + 4 * gg + j, 16 * t + cc);
+      }
+    }
+    stage_chain(lds + IM::F1, lds + IM::B1, a.W[1], d2, d1, T2, T1, tid, nt);
+    stage_chain(lds + IM::F2, lds + IM::B2, a.W[2], d3, d2, T3, T2, tid, nt);
+    const int lfi = p.n_layers - 1;
+    if constexpr (!FINAL_DOT)
+      stage_chain(nullptr, lds + IM::BO, a.W[lfi], p.dims[lfi + 1], p.dims[lfi], OTS, IM::TL, tid, nt);
+    for (int e = tid; e < T1 * 16; e += nt) lds[IM::BIAS1 + e] = e < d1 ? a.b[0][e] : 0.f;
+    for (int e = tid; e < T2 * 16; e += nt) lds[IM::BIAS2 + e] = e < d2 ? a.b[1][e] : 0.f;
+    for (int e = tid; e < T3 * 16; e += nt) lds[IM::BIAS3 + e] = e < d3 ? a.b[2][e] : 0.f;
+    if constexpr (FINAL_DOT)
+      for (int e = tid; e < 4 * IM::TL * 16; e += nt) {
+        const int gg = e & 3, r = (e >> 2) & 3, ti = (e >> 4) % IM::TL, o = (e >> 4) / IM::TL;
+        lds[IM::WF + e] = ld_w(a.W[lfi], p.dims[lfi + 1], p.dims[lfi], o, 16 * ti + 4 * gg + r);
+      }
+  }
+  __syncthreads();
+  const int g = lane >> 4, c = lane & 15;
+  const int K0 = p.dims[0], OUT = p.dims[p.n_layers], S0 = p.steps0;
+  const int lf = p.n_layers - 1;
+
+  LayerAcc<T1, TI0> acc0;
+  LayerAcc<T2, T1> acc1;
+  LayerAcc<T3, T2> acc2;
+  LayerAcc<OTS, T3> acco;
+  float accf[4][T3];
+  acc0.zero();
+  acc1.zero();
+  acc2.zero();
+  acco.zero();
+#pragma unroll
+  for (int o = 0; o < 4; o++)
+#pragma unroll
+    for (int t = 0; t < T3; t++) accf[o][t] = 0.f;
+
+  {
+  const float* __restrict__ W = lds;
+  auto prefetch = [&](int64_t t, float* xb_, float* vb_) {
+    int64_t n = t * 16 + c;
+    n = n < N ? n : N - 1;
+    for (int s = 0; s < S0; s++) {
+      int k = 4 * s + g;
+      k = k < K0 ? k : K0 - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)k * N + n),
+                                       (__attribute__((address_space(3))) void*)(xb_ + s * 64), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(V + (int64_t)k * N + n),
+                                       (__attribute__((address_space(3))) void*)(vb_ + s * 64), 4, 0, 0);
+    }
+  };
+  // layer-0 product W0 * (operand tile staged in LDS), optional bias
+  auto layer0_fwd = [&](const float* ob, bool live, f32x4 (&z)[T1]) {
+    const int S4 = (S0 + 3) >> 2;
+    for (int s4 = 0; s4 < S4; s4++) {
+      f32x4 wv[T1];
+#pragma unroll
+      for (int to = 0; to < T1; to++)
+        wv[to] = *reinterpret_cast<const f32x4*>(W + IM::F0 + ((to * TI0 + s4) * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int sj = 4 * s4 + j;
+        if (sj < S0) {
+          const float xv = ob[sj * 64 + lane];
+          const float b = (4 * sj + g < K0 && live) ? xv : 0.f;
+#pragma unroll
+          for (int to = 0; to < T1; to++) z[to] = MFMA16(wv[to][j], b, z[to]);
+        }
+      }
+    }
+  };
+  auto staged_nt = [&](const float* ob, int64_t tile, f32x4 (&o_nt)[TI0]) {
+    const int64_t n0 = tile * 16 + 4 * g;
+#pragma unroll
+    for (int t = 0; t < TI0; t++) {
+      const int k = 16 * t + c;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ob + (4 * t + (c >> 2)) * 64 + (c & 3) * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; r++) o_nt[t][r] = (k < K0 && n0 + r < N) ? v[r] : 0.f;
+    }
+  };
+  const int64_t ntiles = (N + 15) / 16;
+  const int64_t tile0 = (int64_t)blockIdx.x * BW + wave, tstride = (int64_t)gridDim.x * BW;
+  if (tile0 < ntiles) prefetch(tile0, xbuf, vbuf);
+  int cur = 0;
+  for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* xb = xbuf + cur * (SX * 64);
+    const float* vb = vbuf + cur * (SX * 64);
+    if (tile + tstride < ntiles) prefetch(tile + tstride, xbuf + (cur ^ 1) * (SX * 64), vbuf + (cur ^ 1) * (SX * 64));
+    const int64_t n = tile * 16 + c;
+    const bool live = n < N;
+    // ---- forward: h, a = gelu', c = gelu''
+    f32x4 h1[T1], a1[T1], c1[T1], h2[T2], a2[T2], c2[T2], a3[T3], c3[T3];
+    {
+      f32x4 z[T1];
+      init_bias16<T1>(z, W + IM::BIAS1, g);
+      layer0_fwd(xb, live, z);
+      gelu3<T1>(z, h1, a1, c1);
+    }
+    {
+      f32x4 z[T2];
+      init_bias16<T2>(z, W + IM::BIAS2, g);
+      chain_fwd4<T1, T2>(h1, z, W + IM::F1, lane);
+      gelu3<T2>(z, h2, a2, c2);
+    }
+    {
+      f32x4 z[T3], h3[T3];
+      init_bias16<T3>(z, W + IM::BIAS3, g);
+      chain_fwd4<T2, T3>(h2, z, W + IM::F2, lane);
+      gelu3<T3>(z, h3, a3, c3);
+    }
+    // ---- first-order chain: q3 = W3^T gy ... u1
+    f32x4 q3[T3], q2[T2], q1[T1];
+    zero16<T3>(q3);
+    zero16<T2>(q2);
+    zero16<T1>(q1);
+    float dyo[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dyT[OTS];
+    if constexpr (FINAL_DOT) {
+      const float* __restrict__ wf = W + IM::WF;
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        if (o < OUT) {
+          dyo[o] = live ? dY[(int64_t)o * N + n] : 0.f;
+#pragma unroll
+          for (int t = 0; t < T3; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) q3[t][r] = fmaf(wf[((o * T3 + t) * 4 + r) * 4 + g], dyo[o], q3[t][r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int to = 0; to < OTS; to++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 16 * to + 4 * g + r;
+          dyT[to][r] = (row < OUT && live) ? dY[(int64_t)row * N + n] : 0.f;
+        }
+      chain_bwd4<OTS, T3>(dyT, q3, W + IM::BO, lane);
+    }
+    f32x4 u3[T3], u2[T2], u1[T1];
+    mul16<T3>(a3, q3, u3);
+    chain_bwd4<T3, T2>(u3, q2, W + IM::B2, lane);
+    mul16<T2>(a2, q2, u2);
+    chain_bwd4<T2, T1>(u2, q1, W + IM::B1, lane);
+    mul16<T1>(a1, q1, u1);
+    // ---- adjoint, forward-like sweep
+    f32x4 da1[T1], da2[T2], da3[T3];
+    {
+      f32x4 du1[T1];
+      zero16<T1>(du1);
+      layer0_fwd(vb, live, du1);                                   // du1 = W0 V
+      f32x4 u_nt[T1], v_nt[TI0];
+      to_nt_all<T1>(u1, u_nt, tbuf, g, c);
+      staged_nt(vb, tile, v_nt);
+      acc0.add_nb(u_nt, v_nt);                                     // dW0 += u1 V^T
+      f32x4 dq1[T1];
+      mul16<T1>(du1, q1, da1);
+      mul16<T1>(du1, a1, dq1);
+      f32x4 du2[T2];
+      zero16<T2>(du2);
+      chain_fwd4<T1, T2>(dq1, du2, W + IM::F1, lane);              // du2 = W1 dq1
+      f32x4 u2_nt[T2], dq1_nt[T1];
+      to_nt_all<T2>(u2, u2_nt, tbuf, g, c);
+      to_nt_all<T1>(dq1, dq1_nt, tbuf, g, c);
+      acc1.add_nb(u2_nt, dq1_nt);                                  // dW1 += u2 dq1^T
+      f32x4 dq2[T2];
+      mul16<T2>(du2, q2, da2);
+      mul16<T2>(du2, a2, dq2);
+      f32x4 du3[T3];
+      zero16<T3>(du3);
+      chain_fwd4<T2, T3>(dq2, du3, W + IM::F2, lane);              // du3 = W2 dq2
+      f32x4 u3_nt[T3], dq2_nt[T2];
+      to_nt_all<T3>(u3, u3_nt, tbuf, g, c);
+      to_nt_all<T2>(dq2, dq2_nt, tbuf, g, c);
+      acc2.add_nb(u3_nt, dq2_nt);                                  // dW2 += u3 dq2^T
+      f32x4 dq3[T3], dq3_nt[T3];
+      mul16<T3>(du3, q3, da3);
+      mul16<T3>(du3, a3, dq3);
+      to_nt_all<T3>(dq3, dq3_nt, tbuf, g, c);
+      if constexpr (FINAL_DOT) {                                   // dW3 += gy dq3^T
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+          if (o < OUT) {
+            if (g == 0) dyb[c] = dyo[o];
+            NT_FENCE();
+#pragma unroll
+            for (int t = 0; t < T3; t++) {
+              float pr = 0.f;
+#pragma unroll
+              for (int r = 0; r < 4; r++) pr = fmaf(dq3_nt[t][r], dyb[4 * g + r], pr);
+              accf[o][t] += pr;
+            }
+            NT_FENCE();
+          }
+        }
+      } else {
+        f32x4 dy_nt[OTS];
+        to_nt_all<OTS>(dyT, dy_nt, tbuf, g, c);
+        acco.add_nb(dy_nt, dq3_nt);
+      }
+    }
+    // ---- ordinary backward sweep with the injected pre-activation gradients
+    f32x4 dz3[T3];
+    mul16<T3>(da3, c3, dz3);
+    {
+      f32x4 dz_nt[T3], h_nt[T2];
+      to_nt_all<T3>(dz3, dz_nt, tbuf, g, c);
+      to_nt_all<T2>(h2, h_nt, tbuf, g, c);
+      acc2.add(dz_nt, h_nt);
+    }
+    f32x4 dz2[T2];
+    zero16<T2>(dz2);
+    chain_bwd4<T3, T2>(dz3, dz2, W + IM::B2, lane);
+#pragma unroll
+    for (int t = 0; t < T2; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) dz2[t][r] = dz2[t][r] * a2[t][r] + da2[t][r] * c2[t][r];
+    {
+      f32x4 dz_nt[T2], h_nt[T1];
+      to_nt_all<T2>(dz2, dz_nt, tbuf, g, c);
+      to_nt_all<T1>(h1, h_nt, tbuf, g, c);
+      acc1.add(dz_nt, h_nt);
+    }
+    f32x4 dz1[T1];
+    zero16<T1>(dz1);
+    chain_bwd4<T2, T1>(dz2, dz1, W + IM::B1, lane);
+#pragma unroll
+    for (int t = 0; t < T1; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) dz1[t][r] = dz1[t][r] * a1[t][r] + da1[t][r] * c1[t][r];
+    {
+      f32x4 dz_nt[T1], x_nt[TI0];
+      to_nt_all<T1>(dz1, dz_nt, tbuf, g, c);
+      staged_nt(xb, tile, x_nt);
+      acc0.add(dz_nt, x_nt);
+    }
+#pragma unroll
+    for (int t = 0; t < TI0; t++) {
+      f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int to = 0; to < T1; to++) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(W + IM::B0 + ((t * T1 + to) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dx = MFMA16(wv[r], dz1[to][r], dx);
+      }
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int k = 16 * t + 4 * g + q;
+          if (k < K0) dX2[(int64_t)k * N + n] = dx[q];
+        }
+      }
+    }
+  }
+  }
+  __syncthreads();
+  float* ACC = lds;
+  for (int e = threadIdx.x; e < p.total; e += BW * 64) ACC[e] = 0.f;
+  __syncthreads();
+  acc0.flush_layer0(ACC + p.w_off[0], ACC + p.b_off[0], S0, g, c);
+  acc1.flush_chain(ACC + p.w_off[1], ACC + p.b_off[1], g, c);
+  acc2.flush_chain(ACC + p.w_off[2], ACC + p.b_off[2], g, c);
+  if constexpr (FINAL_DOT) {
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      if (o < OUT) {
+#pragma unroll
+        for (int t = 0; t < T3; t++) {
+          float pr = accf[o][t];
+          pr += __shfl_xor(pr, 16, 64);
+          pr += __shfl_xor(pr, 32, 64);
+          if (g == 0) atomicAdd(ACC + p.w_off[lf] + ((o * T3 + t) * 4 + (c & 3)) * 4 + (c >> 2), pr);
+        }
+      }
+    }
+  } else {
+    acco.flush_chain(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c);  // its bias partials are zero (add_nb only)
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < p.total; e += BW * 64) {
+    const float v = ACC[e];
+    if (v == 0.f) continue;
+    int l, row, col;
+    bool is_bias;
+    unpack_index(p, e, l, row, col, is_bias);
+    if (is_bias) {
+      if (row < p.dims[l + 1]) atomicAdd(a.db[l] + row, v);
+    } else if (row < p.dims[l + 1] && col < p.dims[l]) {
+      atomicAdd(a.dW[l] + (int64_t)row * p.dims[l] + col, v);
+    }
+  }
+}
+
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, const float* dY, float* dX2,
+                   const BwdPtrs& a, hipStream_t st) {
+  using IM = Img<TI0, T1, T2, T3, FINAL_DOT ? 1 : OUT_T, FINAL_DOT>;
+  const int img = IM::TOTAL > p.total ? IM::TOTAL : ((p.total + 3) & ~3);
+  const size_t shmem = ((size_t)img + BW * (16 * 17 + 16 + 4 * 4 * TI0 * 64)) * sizeof(float);
+  if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
+  const int64_t ntiles = (N + 15) / 16;
+  int64_t blocks = (ntiles + BW - 1) / BW;
+  if (blocks > 256) blocks = 256;
+  auto kern = mlp_dbl_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, V, dY, dX2, a);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
 template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
 int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
   const int64_t ntiles = (N + 15) / 16;
@@ -663,6 +1049,42 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   CASE(4, 4, 4, 4, 3, false)  // 52 -> 64x3 -> 33
   CASE(3, 4, 4, 4, 3, false)  // 36 -> 64x3 -> 33
   CASE(5, 4, 4, 0, 1, true)   // 80 -> 64x2 -> 3          (background colour head, models.py:463-469)
+#undef CASE
+  return PSDF_ERR_UNSUPPORTED;
+}
+
+// Double backward (see mlp_dbl_bwd_kernel): V [dims[0], N] is the upstream gradient of the dX that psdf_mlp_backward
+// produced for the same X / parameters / dY.  dX2 [dims[0], N] receives the gradient wrt X; dW[l] / db[l] are
+// ACCUMULATED INTO.  Three hidden layers only; returns PSDF_ERR_UNSUPPORTED (-2) for widths without an instantiation.
+int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                             const float* const* biases, const float* dY, const float* V, float* dX2,
+                             float* const* dW, float* const* db, void* stream) {
+  Plan16 p;
+  int rc = make_plan16(n_layers, dims, p);
+  if (rc != PSDF_OK) return rc;
+  if (n_layers != 4) return PSDF_ERR_UNSUPPORTED;
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !X || !weights || !biases || !dY || !V || !dX2 || !dW || !db) return PSDF_ERR_ARG;
+  BwdPtrs a;
+  for (int l = 0; l < MAXL; l++) {
+    a.W[l] = l < n_layers ? weights[l] : nullptr;
+    a.b[l] = l < n_layers ? biases[l] : nullptr;
+    a.dW[l] = l < n_layers ? dW[l] : nullptr;
+    a.db[l] = l < n_layers ? db[l] : nullptr;
+    if (l < n_layers && (!a.W[l] || !a.b[l] || !a.dW[l] || !a.db[l])) return PSDF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ti0 = p.tiles[0], t1 = p.tiles[1], t2 = p.tiles[2], t3 = p.tiles[3], to = p.tiles[n_layers];
+#define CASE(I, A, B, C, O, D)                                                   \
+  if (ti0 == I && t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
+    return launch_dbl_bwd<I, A, B, C, O, D>(p, N, X, V, dY, dX2, a, st);
+  CASE(4, 2, 2, 2, 3, false)  // 52 -> 32x3 -> 33   (reference SDF net, models.py:153-161)
+  CASE(3, 2, 2, 2, 3, false)  // 36 -> 32x3 -> 33
+  CASE(4, 2, 2, 2, 1, true)   // 49..64 -> 32x3 -> 1..4
+  CASE(3, 2, 2, 2, 1, true)
+  CASE(2, 2, 2, 2, 1, true)
+  CASE(3, 4, 4, 4, 1, true)   // 36 -> 64x3 -> 1..4 (BASELINE net)
+  CASE(4, 4, 4, 4, 1, true)
 #undef CASE
   return PSDF_ERR_UNSUPPORTED;
 }

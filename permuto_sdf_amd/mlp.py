@@ -187,9 +187,35 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         return (None, None, dX.t(), None, *dWs, *dbs)
 
 
+def double_backward_supported(dims):
+    """True when csrc/mlp_bwd.hip has a fused double-backward instantiation for these widths"""
+    if len(dims) != 5:
+        return False
+    t = [(d + 15) // 16 for d in dims]
+    sig = (t[0], t[1], t[2], t[3], t[4], dims[-1] <= 4)
+    return sig in {(4, 2, 2, 2, 3, False), (3, 2, 2, 2, 3, False), (4, 2, 2, 2, 1, True), (3, 2, 2, 2, 1, True),
+                   (2, 2, 2, 2, 1, True), (3, 4, 4, 4, 1, True), (4, 4, 4, 4, 1, True)}
+
+
 def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
     """-> (dX [C,N], [dW_l], [db_l]) of <dx(x, params; gy), v>; fused kernel where one is built, torch (GPU) otherwise"""
-    return _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm)
+    if not double_backward_supported(dims):
+        return _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm)
+    N = x_fm.shape[1]
+    n_layers = len(dims) - 1
+    dev = x_fm.device
+    ws = [w.detach().contiguous() for w in weights]
+    bs = [b.detach().contiguous() for b in biases]
+    dx2 = torch.empty((dims[0], N), dtype=torch.float32, device=dev)
+    dWs = [torch.zeros((dims[l + 1], dims[l]), dtype=torch.float32, device=dev) for l in range(n_layers)]
+    dbs = [torch.zeros((dims[l + 1],), dtype=torch.float32, device=dev) for l in range(n_layers)]
+    Wp = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
+    Bp = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
+    W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
+    B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
+    L.call("psdf_mlp_double_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), Wp, Bp, L.ptr(gy_fm),
+           L.ptr(v_fm), L.ptr(dx2), W, B, L.stream())
+    return dx2, dWs, dbs
 
 
 class FusedMLP(torch.nn.Module):
