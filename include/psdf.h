@@ -85,6 +85,11 @@ int psdf_encode_mlp_forward(int64_t N, int nr_levels, int capacity, const float*
 int psdf_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float
     beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* the same update for up to 64 tensors sharing the step count, one launch (host arrays of sizes / device pointers) */
+int psdf_adamw_step_multi(int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads, float*
+    const* exp_avgs, float* const* exp_avg_sqs, float lr, float beta1, float beta2, float eps, float weight_decay, int
+    step, float grad_scale, void* stream);
+
 /* ---- sampling.hip ---- */
 /* replaces: OccupancyGrid::compute_grid_points / compute_random_sample_of_grid_points, src/OccupancyGrid.cu:88-117,179-208 */
 int psdf_grid_points(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const int*

@@ -5,12 +5,11 @@
 #include "psdf_common.h"
 
 namespace {
-__global__ void __launch_bounds__(PSDF_BLOCK)
-    adamw_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                 float* __restrict__ v, float lr, float beta1, float beta2, float eps, float weight_decay,
-                 float bias_corr1, float bias_corr2_sqrt, float grad_scale) {
-  const int64_t stride = (int64_t)gridDim.x * PSDF_BLOCK * 4;
-  for (int64_t i = ((int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x) * 4; i < n; i += stride) {
+__device__ __forceinline__ void adamw_range(int64_t n, float* __restrict__ p, const float* __restrict__ g,
+                                            float* __restrict__ m, float* __restrict__ v, float lr, float beta1,
+                                            float beta2, float eps, float weight_decay, float bias_corr1,
+                                            float bias_corr2_sqrt, float grad_scale, int64_t first, int64_t stride) {
+  for (int64_t i = first; i < n; i += stride) {
     if (i + 3 < n) {
       float4 P = *reinterpret_cast<float4*>(p + i);
       const float4 G = *reinterpret_cast<const float4*>(g + i);
@@ -47,6 +46,32 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     }
   }
 }
+
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    adamw_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                 float* __restrict__ v, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 float bias_corr1, float bias_corr2_sqrt, float grad_scale) {
+  adamw_range(n, p, g, m, v, lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, grad_scale,
+              ((int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x) * 4, (int64_t)gridDim.x * PSDF_BLOCK * 4);
+}
+
+// Many SMALL tensors in one launch (the MLP weights and biases: ~35 tensors of a few hundred to a few thousand floats
+// per step would otherwise be ~35 launches): blockIdx.y selects the tensor.
+constexpr int ADAMW_MAX_TENSORS = 64;
+struct AdamwMulti {
+  int64_t n[ADAMW_MAX_TENSORS];
+  float* p[ADAMW_MAX_TENSORS];
+  const float* g[ADAMW_MAX_TENSORS];
+  float* m[ADAMW_MAX_TENSORS];
+  float* v[ADAMW_MAX_TENSORS];
+};
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    adamw_multi_kernel(AdamwMulti a, float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1,
+                       float bias_corr2_sqrt, float grad_scale) {
+  const int t = blockIdx.y;
+  adamw_range(a.n[t], a.p[t], a.g[t], a.m[t], a.v[t], lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt,
+              grad_scale, ((int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x) * 4, (int64_t)gridDim.x * PSDF_BLOCK * 4);
+}
 }  // namespace
 
 extern "C" {
@@ -62,6 +87,37 @@ int psdf_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, 
   if (blocks > 4096u) blocks = 4096u;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, n, param, grad, exp_avg,
                      exp_avg_sq, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// The same update for up to 64 tensors that share the step count, in ONE launch (host arrays of sizes and device
+// pointers; every pointer 16-byte aligned).
+int psdf_adamw_step_multi(int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads,
+                          float* const* exp_avgs, float* const* exp_avg_sqs, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, float grad_scale, void* stream) {
+  if (n_tensors <= 0) return PSDF_OK;
+  if (n_tensors > ADAMW_MAX_TENSORS || !sizes || !params || !grads || !exp_avgs || !exp_avg_sqs || step < 1)
+    return PSDF_ERR_ARG;
+  AdamwMulti a;
+  int64_t nmax = 0;
+  for (int t = 0; t < n_tensors; t++) {
+    if (sizes[t] < 0 || !params[t] || !grads[t] || !exp_avgs[t] || !exp_avg_sqs[t]) return PSDF_ERR_ARG;
+    if ((((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avgs[t] | (uintptr_t)exp_avg_sqs[t]) & 15) != 0)
+      return PSDF_ERR_ARG;
+    a.n[t] = sizes[t];
+    a.p[t] = params[t];
+    a.g[t] = grads[t];
+    a.m[t] = exp_avgs[t];
+    a.v[t] = exp_avg_sqs[t];
+    if (sizes[t] > nmax) nmax = sizes[t];
+  }
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  unsigned blocks = psdf_blocks((nmax + 3) / 4, PSDF_BLOCK);
+  if (blocks > 64u) blocks = 64u;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks, (unsigned)n_tensors), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, a, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

@@ -9,10 +9,14 @@ class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    SMALL = 1 << 16  # tensors below this many elements are batched into one launch (64 per launch)
+
     @torch.no_grad()
     def step(self, grad_scale=1.0):
+        import ctypes
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            small = {}   # step count -> [(p, g, m, v)]
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -25,6 +29,19 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                aligned = all(t.data_ptr() % 16 == 0 for t in (p, g, st["exp_avg"], st["exp_avg_sq"]))
+                if p.numel() < self.SMALL and aligned:
+                    small.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
+                    continue
                 L.call("psdf_adamw_step", L.c_l(p.numel()), L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
                        L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]), L.c_f(group["weight_decay"]),
                        L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())
+            for step, items in small.items():
+                for i in range(0, len(items), 64):
+                    chunk = items[i:i + 64]
+                    n = len(chunk)
+                    sizes = (ctypes.c_int64 * n)(*[c[0].numel() for c in chunk])
+                    arrs = [(ctypes.c_void_p * n)(*[c[k].data_ptr() for c in chunk]) for k in range(4)]
+                    L.call("psdf_adamw_step_multi", L.c_i(n), sizes, *arrs, L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2),
+                           L.c_f(group["eps"]), L.c_f(group["weight_decay"]), L.c_i(step), L.c_f(float(grad_scale)),
+                           L.stream())
