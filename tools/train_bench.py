@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     args = ap.parse_args()
     rank, world, local = parallel.init()
+    if os.environ.get("PSDF_BENCH_SINGLE_DEVICE") == "1":
+        local = 0   # development aid (with PSDF_DIST_BACKEND=gloo): every rank on cuda:0, exercises the N>1 path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     tr = Trainer(dev)
@@ -42,6 +44,12 @@ def main():
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    if world > 1:   # replicas must have stayed identical: same parameters on every rank after the run
+        chk = torch.stack([p.detach().double().sum() for p in tr.params]).cpu()
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "replicas diverged"
     if rank == 0:
         el = float(el.item())
         print(json.dumps({"metric": "train iters/sec (cfg 4: SDF + colour + background step, synthetic reel)",
