@@ -27,11 +27,16 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
   }
   E[0] = sm;
 
+  // The frozen convention (oracle/permuto_oracle.py) divides by P+1 in double and rounds once.  When P+1 is a power of
+  // two (pos_dim 3: the SDF / colour lattices) that is an exact scaling, so the float product is bit-identical and the
+  // f64 converts and multiplies (half / quarter rate) are skipped.
+  constexpr bool POW2 = ((P + 1) & P) == 0;
   const double inv = 1.0 / (P + 1);
+  const float invf = 1.0f / (P + 1);
   int sum = 0;
 #pragma unroll
   for (int i = 0; i <= P; i++) {
-    float v = (float)((double)E[i] * inv);
+    float v = POW2 ? E[i] * invf : (float)((double)E[i] * inv);
     float up = ceilf(v) * (float)(P + 1);
     float down = floorf(v) * (float)(P + 1);
     s.rem0[i] = ((up - E[i]) < (E[i] - down)) ? (int)up : (int)down;
@@ -71,7 +76,7 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
   for (int k = 0; k <= P + 1; k++) s.bary[k] = 0.f;
 #pragma unroll
   for (int i = 0; i <= P; i++) {
-    float delta = (float)((double)(E[i] - (float)s.rem0[i]) * inv);
+    float delta = POW2 ? (E[i] - (float)s.rem0[i]) * invf : (float)((double)(E[i] - (float)s.rem0[i]) * inv);
 #pragma unroll
     for (int k = 0; k <= P + 1; k++) {
       if (k == P - s.rank[i]) s.bary[k] = s.bary[k] + delta;
@@ -91,6 +96,9 @@ __device__ __forceinline__ uint32_t vertex_row(const Simplex<P>& s, int remainde
     h += (uint32_t)k;
     h *= 2531011u;
   }
+  // `capacity` is wave-uniform (a kernel argument): a scalar branch.  A runtime 32-bit modulo is ~35 VALU
+  // instructions, times P+1 vertices per (point, level) -- a quarter of the forward kernel's instruction count.
+  if ((capacity & (capacity - 1u)) == 0u) return h & (capacity - 1u);
   return h % capacity;
 }
 
