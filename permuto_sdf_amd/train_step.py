@@ -253,6 +253,15 @@ class Trainer:
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
         self._rank_seed = parallel.rank_seed(seed + 1, parallel.rank())
 
+    # ---- checkpoints in the reference's file layout (permuto_sdf_utils.py:222-237)
+    def save_checkpoint(self, folder):
+        from . import checkpoint
+        checkpoint.save(folder, sdf=self.sdf, rgb=self.rgb, bg=self.bg, grid=self.grid)
+
+    def load_checkpoint(self, folder):
+        from . import checkpoint
+        checkpoint.load(folder, sdf=self.sdf, rgb=self.rgb, bg=self.bg, grid=self.grid, map_location=self.dev)
+
     # ---- sampling (no grad): nerf_utils.py:502-525 + sdf_utils.py:383-423
     @torch.no_grad()
     def _samples(self, o, d, it):
