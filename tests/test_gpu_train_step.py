@@ -25,3 +25,21 @@ def test_training_step_learns_constant_colour(dev):
     assert changed >= len(before) - 5
     lat = tr.sdf.encoding.lattice_values.grad
     assert lat is not None and torch.isfinite(lat).all() and float(lat.abs().max()) > 0
+
+
+def test_checkpoint_round_trip_on_device(dev, tmp_path):
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel, Trainer
+    hp = HyperParams()
+    hp.nr_rays = 128
+    hp.target_nr_of_samples = 128 * 96
+    tr = Trainer(dev, hp)
+    reel = SyntheticReel(dev, nr_images=2, height=40, width=60)
+    for _ in range(3):
+        tr.step(reel)
+    tr.save_checkpoint(str(tmp_path))
+    tr2 = Trainer(dev, hp, seed=5)
+    tr2.load_checkpoint(str(tmp_path))
+    for a, b in zip(tr.params, tr2.params):
+        assert torch.equal(a, b)
+    assert torch.equal(tr.grid.get_grid_occupancy(), tr2.grid.get_grid_occupancy())
+    assert torch.equal(tr.grid.get_grid_values(), tr2.grid.get_grid_values())
