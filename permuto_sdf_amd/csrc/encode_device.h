@@ -71,18 +71,25 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
       s.rem0[i] -= P + 1;
     }
   }
-  // recompute d after the fix-up (rem0 may have moved by +-(P+1)); same expression as the oracle
+  // recompute d after the fix-up (rem0 may have moved by +-(P+1)); same expression as the oracle.
+  // The oracle scatters: bary[P - rank_i] += delta_i; bary[P + 1 - rank_i] -= delta_i.  The ranks are a permutation,
+  // so every bary[k] receives exactly one "+" (from the element of rank P-k) and one "-" (rank P+1-k): gathering the
+  // deltas by rank first and forming bary[k] = ds[P-k] - ds[P+1-k] is the same single rounding with (P+1)^2 selects
+  // instead of 2(P+1)(P+2).
+  float ds[P + 1];
 #pragma unroll
-  for (int k = 0; k <= P + 1; k++) s.bary[k] = 0.f;
+  for (int r = 0; r <= P; r++) ds[r] = 0.f;
 #pragma unroll
   for (int i = 0; i <= P; i++) {
     float delta = POW2 ? (E[i] - (float)s.rem0[i]) * invf : (float)((double)(E[i] - (float)s.rem0[i]) * inv);
 #pragma unroll
-    for (int k = 0; k <= P + 1; k++) {
-      if (k == P - s.rank[i]) s.bary[k] = s.bary[k] + delta;
-      if (k == P + 1 - s.rank[i]) s.bary[k] = s.bary[k] - delta;
-    }
+    for (int r = 0; r <= P; r++)
+      if (s.rank[i] == r) ds[r] = delta;
   }
+  s.bary[0] = 0.f + ds[P];
+#pragma unroll
+  for (int k = 1; k <= P; k++) s.bary[k] = (0.f + ds[P - k]) - ds[P + 1 - k];
+  s.bary[P + 1] = 0.f - ds[0];
   s.bary[0] = (float)((double)s.bary[0] + (1.0 + (double)s.bary[P + 1]));
 }
 
