@@ -93,18 +93,27 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
   s.bary[0] = (float)((double)s.bary[0] + (1.0 + (double)s.bary[P + 1]));
 }
 
+// Hash of the vertex with remainder r: key_i = rem0_i + r - (P+1)*[rank_i > P - r],  h = (..((key_0)*c + key_1)*c ..)*c.
+// In the ring of 32-bit integers that is  sum_i key_i c^(P-i), so with H0 = sum_i rem0_i c^(P-i) (P multiplies, ONCE per
+// simplex) every vertex is  H0 + r*(c^P + .. + c) - sum_i [rank_i > P - r] * (P+1) c^(P-i):  adds and selects only
+// (integer multiplies are quarter rate and the direct form needs P of them per vertex).
+constexpr uint32_t HASH_C = 2531011u;
+constexpr uint32_t hash_pow(int e) { return e == 0 ? 1u : HASH_C * hash_pow(e - 1); }
+constexpr uint32_t hash_geom(int P) { return P == 0 ? 0u : hash_pow(P) + hash_geom(P - 1); }
+
 template <int P>
 __device__ __forceinline__ uint32_t vertex_row(const Simplex<P>& s, int remainder, uint32_t capacity) {
   uint32_t h = 0;
 #pragma unroll
-  for (int i = 0; i < P; i++) {
-    int k = s.rem0[i] + remainder;
-    if (s.rank[i] > P - remainder) k -= (P + 1);
-    h += (uint32_t)k;
-    h *= 2531011u;
+  for (int i = 0; i < P; i++) {   // H0; common to the P+1 vertices: the compiler keeps one copy after inlining
+    h += (uint32_t)s.rem0[i];
+    h *= HASH_C;
   }
-  // `capacity` is wave-uniform (a kernel argument): a scalar branch.  A runtime 32-bit modulo is ~35 VALU
-  // instructions, times P+1 vertices per (point, level) -- a quarter of the forward kernel's instruction count.
+  h += (uint32_t)remainder * hash_geom(P);
+#pragma unroll
+  for (int i = 0; i < P; i++)
+    if (s.rank[i] > P - remainder) h -= (uint32_t)(P + 1) * hash_pow(P - i);
+  // `capacity` is wave-uniform (a kernel argument): a scalar branch instead of a ~35-instruction runtime modulo
   if ((capacity & (capacity - 1u)) == 0u) return h & (capacity - 1u);
   return h % capacity;
 }
