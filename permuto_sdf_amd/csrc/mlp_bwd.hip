@@ -127,15 +127,21 @@ __device__ __forceinline__ void zero16(f32x4 (&a)[T]) {
 // z -> (gelu(z), gelu'(z)) with one erf and one exp; same formulas as gelu_exact / gelu_grad (mlp_device.h)
 template <int T>
 __device__ __forceinline__ void gelu_both(const f32x4 (&z)[T], f32x4 (&h)[T], f32x4 (&dg)[T]) {
+  // pairs of values in packed fp32 arithmetic (same operations and order as the scalar formulas: bit-identical)
 #pragma unroll
   for (int t = 0; t < T; t++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float x = z[t][r];
-      const float one_erf = 1.0f + erf_fast(x * 0.70710678118654752440f);
-      h[t][r] = 0.5f * x * one_erf;
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-      dg[t][r] = fmaf(x, pdf, 0.5f * one_erf);
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2 x = {z[t][r], z[t][r + 1]};
+      const f32x2 one_erf = splat2(1.0f) + erf_fast2(x * splat2(0.70710678118654752440f));
+      const f32x2 hh = (splat2(0.5f) * x) * one_erf;
+      const f32x2 e = (splat2(-0.5f) * x) * x;
+      const f32x2 pdf = splat2(0.3989422804014327f) * f32x2{__expf(e.x), __expf(e.y)};
+      const f32x2 d = pk_fma(x, pdf, splat2(0.5f) * one_erf);
+      h[t][r] = hh.x;
+      h[t][r + 1] = hh.y;
+      dg[t][r] = d.x;
+      dg[t][r + 1] = d.y;
     }
 }
 
@@ -621,13 +627,20 @@ __device__ __forceinline__ void gelu3(const f32x4 (&z)[T], f32x4 (&h)[T], f32x4 
 #pragma unroll
   for (int t = 0; t < T; t++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float x = z[t][r];
-      const float one_erf = 1.0f + erf_fast(x * 0.70710678118654752440f);
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-      h[t][r] = 0.5f * x * one_erf;
-      a1[t][r] = fmaf(x, pdf, 0.5f * one_erf);  // Phi + x phi
-      c2[t][r] = pdf * (2.0f - x * x);           // 2 phi + x phi' = phi (2 - x^2)
+    for (int r = 0; r < 4; r += 2) {
+      const f32x2 x = {z[t][r], z[t][r + 1]};
+      const f32x2 one_erf = splat2(1.0f) + erf_fast2(x * splat2(0.70710678118654752440f));
+      const f32x2 e = (splat2(-0.5f) * x) * x;
+      const f32x2 pdf = splat2(0.3989422804014327f) * f32x2{__expf(e.x), __expf(e.y)};
+      const f32x2 hh = (splat2(0.5f) * x) * one_erf;
+      const f32x2 aa = pk_fma(x, pdf, splat2(0.5f) * one_erf);   // Phi + x phi
+      const f32x2 cc = pdf * (splat2(2.0f) - x * x);              // 2 phi + x phi' = phi (2 - x^2)
+      h[t][r] = hh.x;
+      h[t][r + 1] = hh.y;
+      a1[t][r] = aa.x;
+      a1[t][r + 1] = aa.y;
+      c2[t][r] = cc.x;
+      c2[t][r + 1] = cc.y;
     }
 }
 template <int T>
