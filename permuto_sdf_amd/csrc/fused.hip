@@ -36,7 +36,7 @@ struct EncArgs {
   float points_scaling;
 };
 
-constexpr int JB = 4;  // level pairs per gather batch
+constexpr int JB = 1;  // level pairs per gather batch
 
 // features (f0,f1) of level `lv` (hashed if lv < L, scaled point if L <= lv < Lt, zero beyond) for one sample
 struct LevelLoad {
@@ -129,7 +129,7 @@ __device__ __forceinline__ void encode_layer0(const MlpPlan& p, const float* __r
 }
 
 template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
-__global__ void __launch_bounds__(PSDF_BLOCK, 2)
+__global__ void __launch_bounds__(PSDF_BLOCK, 3)
     fused_fwd_kernel(MlpPlan p, EncArgs e, int64_t N, const unsigned char* __restrict__ skip,
                      const float* __restrict__ packed, float* __restrict__ feat, float* __restrict__ Y) {
   extern __shared__ __align__(16) float lds[];
