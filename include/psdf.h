@@ -60,6 +60,14 @@ int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, c
     stream);
 
 /* ---- mlp_bwd.hip ---- */
+/* per-sample masks for fixed-shape callers (one slot per ray: the sphere tracer's converged rays): masked points /
+   fully masked 32-sample tiles are not evaluated, their outputs are left untouched */
+int psdf_encode_forward_masked(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+    const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points, float
+    points_scaling, const uint8_t* skip, float* sliced, void* stream);
+int psdf_mlp_forward_masked(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, const uint8_t*
+    skip, float* Y, void* stream);
+
 /* replaces: autograd backward of the same evaluators (dX, dW_l, db_l in one launch; forward recomputed from X).
    weights[l]/biases[l]: torch-layout parameters; dW[l]/db[l] are accumulated into (caller zero-fills) */
 int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights, const

@@ -22,9 +22,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_fwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
-                      float* __restrict__ sliced) {
+                      const unsigned char* __restrict__ skip, float* __restrict__ sliced) {
   const int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (n >= N) return;
+  if (skip && skip[n]) return;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
   const int level = blockIdx.y;
   float pos[P];
   load_pos<P>(positions, n, pos);
@@ -685,9 +686,10 @@ inline int extra_levels(int P, int F, int concat) { return concat ? (P + F - 1) 
 // ================================================================================== C ABI
 extern "C" {
 
-int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
-                        const float* lattice, const float* scale_factor, const float* shifts, const float* window,
-                        int concat_points, float points_scaling, float* sliced, void* stream) {
+static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+                               const float* lattice, const float* scale_factor, const float* shifts, const float* window,
+                               int concat_points, float points_scaling, const unsigned char* skip, float* sliced,
+                               void* stream) {
   if (N == 0) return PSDF_OK;
   if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !sliced) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -695,7 +697,7 @@ int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int 
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);
 #define FWD(P_, F_)                                                                                            \
   hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, \
-                     positions, lattice, scale_factor, shifts, window, points_scaling, sliced)
+                     positions, lattice, scale_factor, shifts, window, points_scaling, skip, sliced)
   if (pos_dim == 3 && nr_feat == 2)
     FWD(3, 2);
   else if (pos_dim == 4 && nr_feat == 2)
@@ -709,6 +711,23 @@ int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int 
 #undef FWD
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
+}
+
+int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+                        const float* lattice, const float* scale_factor, const float* shifts, const float* window,
+                        int concat_points, float points_scaling, float* sliced, void* stream) {
+  return encode_forward_impl(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts, window,
+                             concat_points, points_scaling, nullptr, sliced, stream);
+}
+
+// Same with a per-point mask: points with skip[n] != 0 are not evaluated and their columns of `sliced` are left as
+// they are (fixed-shape callers that keep one slot per ray, e.g. the sphere tracer's converged rays).
+int psdf_encode_forward_masked(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+                               const float* lattice, const float* scale_factor, const float* shifts, const float* window,
+                               int concat_points, float points_scaling, const unsigned char* skip, float* sliced,
+                               void* stream) {
+  return encode_forward_impl(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts, window,
+                             concat_points, points_scaling, skip, sliced, stream);
 }
 
 // Workspace for the binned (queue + LDS reduction) lattice-gradient path; 0 = the path does not apply (small batch,

@@ -75,7 +75,7 @@ struct Net {
 template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
 __global__ void __launch_bounds__(PSDF_BLOCK, 2)
     mlp_fwd_kernel(MlpPlan p, int64_t N, const float* __restrict__ X, const float* __restrict__ packed,
-                   float* __restrict__ Y) {
+                   const unsigned char* __restrict__ skip, float* __restrict__ Y) {
   extern __shared__ __align__(16) float lds[];
   for (int i = threadIdx.x; i < p.total; i += PSDF_BLOCK) lds[i] = packed[i];
   __syncthreads();
@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
     asm volatile("" ::: "memory");
     const int64_t n = tile * 32 + sl;
     const int64_t nc = n < N ? n : N - 1;
+    if (skip && __ballot(n < N && !skip[nc]) == 0) continue;  // every sample of the tile is masked
     // ---- layer 0: B operand from global (feature-major input)
     f32x16 h1[T1];
     init_bias<T1>(h1, lds + p.b_off[0], h);
@@ -162,7 +163,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
 }
 
 template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
-int launch_fwd(const MlpPlan& p, int64_t N, const float* X, const float* packed, float* Y, hipStream_t st) {
+int launch_fwd(const MlpPlan& p, int64_t N, const float* X, const float* packed, const unsigned char* skip, float* Y,
+               hipStream_t st) {
   const size_t shmem = (size_t)p.total * sizeof(float);
   auto kern = mlp_fwd_kernel<T1, T2, T3, OUT_T, FINAL_DOT>;
   if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
@@ -174,7 +176,7 @@ int launch_fwd(const MlpPlan& p, int64_t N, const float* X, const float* packed,
   int64_t blocks = (ntiles + 3) / 4;
   const int64_t cap = 256 * 4;  // persistent-ish: the weight staging is amortised over many tiles
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PSDF_BLOCK), shmem, st, p, N, X, packed, Y);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PSDF_BLOCK), shmem, st, p, N, X, packed, skip, Y);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -209,8 +211,8 @@ int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, co
 }
 
 // X: [dims[0], N] feature-major; Y: [dims[n_layers], N] feature-major.  GELU (erf) after every layer but the last.
-int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y,
-                     void* stream) {
+static int mlp_forward_impl(int n_layers, const int* dims, int64_t N, const float* X, const float* packed,
+                            const unsigned char* skip, float* Y, void* stream) {
   MlpPlan p;
   int rc = make_plan(n_layers, dims, p);
   if (rc != PSDF_OK) return rc;
@@ -221,7 +223,7 @@ int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, c
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
 #define CASE(A, B, C, O, D)                                          \
   if (t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
-    return launch_fwd<A, B, C, O, D>(p, N, X, packed, Y, st);
+    return launch_fwd<A, B, C, O, D>(p, N, X, packed, skip, Y, st);
   CASE(2, 2, 2, 1, true)   // 64x3 -> 1..4      (BASELINE SDF net)
   CASE(1, 1, 1, 1, true)   // 32x3 -> 1..4
   CASE(1, 1, 1, 2, false)  // 32x3 -> 33        (reference SDF net, models.py:153-161)
@@ -231,6 +233,19 @@ int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, c
   CASE(4, 4, 2, 1, true)   // 128,128,64 -> 3   (colour net, models.py:350)
 #undef CASE
   return PSDF_ERR_UNSUPPORTED;
+}
+
+
+int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y,
+                     void* stream) {
+  return mlp_forward_impl(n_layers, dims, N, X, packed, nullptr, Y, stream);
+}
+
+// Same with a per-sample mask: 32-sample tiles whose samples all have skip[n] != 0 are not evaluated (their Y entries
+// are left as they are); partially masked tiles are evaluated in full.
+int psdf_mlp_forward_masked(int n_layers, const int* dims, int64_t N, const float* X, const float* packed,
+                            const unsigned char* skip, float* Y, void* stream) {
+  return mlp_forward_impl(n_layers, dims, N, X, packed, skip, Y, stream);
 }
 
 }  // extern "C"

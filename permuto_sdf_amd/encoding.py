@@ -43,13 +43,18 @@ def _tail(cfg):
     return (L.c_i(int(cfg.concat_points)), L.c_f(cfg.points_scaling))
 
 
-def encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window):
-    """-> sliced [channels, N] (feature-major)."""
+def encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window, skip=None, out=None):
+    """-> sliced [channels, N] (feature-major).  `skip` [N] bool/uint8: masked points are not evaluated and their columns
+    of `out` (pass a persistent buffer) stay as they are."""
     L.require_cuda(positions, lattice)
     N = positions.shape[0]
-    sliced = torch.empty((cfg.channels, N), dtype=torch.float32, device=positions.device)
-    L.call("psdf_encode_forward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
-           L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(sliced), L.stream())
+    sliced = out if out is not None else torch.empty((cfg.channels, N), dtype=torch.float32, device=positions.device)
+    if skip is None:
+        L.call("psdf_encode_forward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
+               L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(sliced), L.stream())
+    else:
+        L.call("psdf_encode_forward_masked", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
+               L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(skip), L.ptr(sliced), L.stream())
     return sliced
 
 

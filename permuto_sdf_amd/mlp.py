@@ -38,12 +38,17 @@ def pack_params(dims, weights, biases):
     return packed
 
 
-def mlp_forward_raw(dims, x_fm, packed):
-    """x_fm [dims[0], N] feature-major -> y [dims[-1], N] feature-major."""
+def mlp_forward_raw(dims, x_fm, packed, skip=None, out=None):
+    """x_fm [dims[0], N] feature-major -> y [dims[-1], N] feature-major.  `skip` [N]: 32-sample tiles that are masked
+    entirely are not evaluated (their entries of `out` stay as they are)."""
     N = x_fm.shape[1]
-    y = torch.empty((dims[-1], N), dtype=torch.float32, device=x_fm.device)
-    L.call("psdf_mlp_forward", L.c_i(len(dims) - 1), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(y),
-           L.stream())
+    y = out if out is not None else torch.empty((dims[-1], N), dtype=torch.float32, device=x_fm.device)
+    if skip is None:
+        L.call("psdf_mlp_forward", L.c_i(len(dims) - 1), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(y),
+               L.stream())
+    else:
+        L.call("psdf_mlp_forward_masked", L.c_i(len(dims) - 1), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed),
+               L.ptr(skip), L.ptr(y), L.stream())
     return y
 
 

@@ -11,7 +11,6 @@ import torch
 
 from . import _lib as L
 from .encoding import _head, _tail, encode_forward_raw
-from .fused import encode_mlp_forward_raw, fused_supported
 from .mlp import mlp_backward_raw, mlp_forward_raw, pack_params
 
 
@@ -23,22 +22,15 @@ class SphereTracer:
         self._graph = None
 
     # ---- building blocks -----------------------------------------------------------------------------------
-    def _sdf(self, pts, dims, packed, skip=None, out=None, want_feat=False):
-        """SDF channel of the net at `pts` -> (feat [C,N] or None, sdf [1,N]).  Fused single launch when the encoding
-        is 3-D with 2 features per level (every reference model), otherwise encode + MLP."""
+    def _sdf(self, pts, dims, packed, skip=None, out=None, feat_buf=None):
+        """SDF channel of the net at `pts` -> (feat [C,N], sdf [1,N]).  Two launches: the level-major encode kernel keeps
+        one 2-MiB table at a time in every XCD's L2 and runs at full occupancy, which beats the single fused launch
+        (csrc/fused.hip, whose 24 tables thrash the L2) even more clearly at 24 levels; both honour the per-ray mask
+        (converged rays: no gathers, fully converged 32-ray tiles: no MLP)."""
         e = self.enc
-        args = (e.cfg, pts, e.lattice_values.detach(), e.scale_factor, e.random_shift_per_level.detach(), self.window)
-        if skip is not None and fused_supported(e.cfg, dims):
-            # single launch with the per-ray mask: tiles of converged rays cost nothing.  (Without a mask the two
-            # level-major/occupancy-friendly launches below are faster, tools/fused_bench.py.)
-            y, feat = encode_mlp_forward_raw(*args, dims, packed, skip=skip, want_feat=want_feat, out=out)
-            return feat, y
-        feat = encode_forward_raw(*args)
-        y = mlp_forward_raw(dims, feat, packed)
-        if out is not None:
-            out.copy_(y)
-            y = out
-        return feat, y
+        feat = encode_forward_raw(e.cfg, pts, e.lattice_values.detach(), e.scale_factor,
+                                  e.random_shift_per_level.detach(), self.window, skip=skip, out=feat_buf)
+        return feat, mlp_forward_raw(dims, feat, packed, skip=skip, out=out)
 
     def _grid_args(self):
         g = self.grid
@@ -65,11 +57,12 @@ class SphereTracer:
         dims = list(self.mlp.dims[:-1]) + [1]
         packed = pack_params(dims, ws, bs)
         sdf = torch.zeros((1, R), dtype=torch.float32, device=dev)
+        feat_buf = torch.zeros((self.enc.cfg.channels, R), dtype=torch.float32, device=dev)
         for _ in range(nr_sphere_traces):
-            self._sdf(pts, dims, packed, skip=conv.view(-1), out=sdf)     # tiles of converged rays are skipped
+            self._sdf(pts, dims, packed, skip=conv.view(-1), out=sdf, feat_buf=feat_buf)   # converged rays are skipped
             L.call("psdf_sphere_trace_step", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf),
                    L.c_f(sdf_multiplier), L.c_f(sdf_converged_tresh), L.ptr(pts), L.ptr(conv), L.stream())
-        feat, sdf = self._sdf(pts, dims, packed, want_feat=return_gradients)
+        feat, sdf = self._sdf(pts, dims, packed)
         grads = None
         if return_gradients:
             # analytic normal: d sdf / d x = encode_backward_positions( mlp_backward_dX( 1 ) )
