@@ -69,7 +69,8 @@ int psdf_mlp_forward_masked(int n_layers, const int* dims, int64_t N, const floa
     skip, float* Y, void* stream);
 
 /* replaces: autograd backward of the same evaluators (dX, dW_l, db_l in one launch; forward recomputed from X).
-   weights[l]/biases[l]: torch-layout parameters; dW[l]/db[l] are accumulated into (caller zero-fills) */
+   weights[l]/biases[l]: torch-layout parameters; dW[l]/db[l] are accumulated into (caller zero-fills); dW = db = NULL:
+   data gradient only (lighter kernel: analytic normals at inference) */
 int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights, const
     float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 

@@ -308,7 +308,8 @@ __device__ __forceinline__ void chain_bwd4(const f32x4 (&dz)[TO], f32x4 (&dh)[TI
 
 constexpr int BW = 4;  // waves per workgroup (one per SIMD: the kernel wants the whole 512-register file)
 
-template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool NEED_DX>
+// NEED_DW = false: data gradient only (dX of a fixed net: analytic normals at inference); no accumulators, no transposes
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool NEED_DX, bool NEED_DW = true>
 __global__ void __launch_bounds__(BW * 64)
     mlp_bwd_kernel(Plan16 p, int64_t N, const float* __restrict__ X, const float* __restrict__ dY,
                    float* __restrict__ dX, BwdPtrs a) {
@@ -445,12 +446,14 @@ __global__ void __launch_bounds__(BW * 64)
     zero16<TL>(dhl);
     {
       f32x4 hl_nt[TL];
+      if constexpr (NEED_DW) {
 #pragma unroll
-      for (int t = 0; t < TL; t++) {
-        if constexpr (T3 > 0)
-          to_nt(h3[t], hl_nt[t], tbuf, g, c);
-        else
-          to_nt(h2[t], hl_nt[t], tbuf, g, c);
+        for (int t = 0; t < TL; t++) {
+          if constexpr (T3 > 0)
+            to_nt(h3[t], hl_nt[t], tbuf, g, c);
+          else
+            to_nt(h2[t], hl_nt[t], tbuf, g, c);
+        }
       }
       if constexpr (FINAL_DOT) {
         const float* __restrict__ wf = W + IM::WF;
@@ -462,17 +465,19 @@ __global__ void __launch_bounds__(BW * 64)
             for (int t = 0; t < TL; t++)
 #pragma unroll
               for (int r = 0; r < 4; r++) dhl[t][r] = fmaf(wf[((o * TL + t) * 4 + r) * 4 + g], dy, dhl[t][r]);
-            if (g == 0) dyb[c] = dy;
-            NT_FENCE();
+            if constexpr (NEED_DW) {
+              if (g == 0) dyb[c] = dy;
+              NT_FENCE();
 #pragma unroll
-            for (int t = 0; t < TL; t++) {
-              float pr = 0.f;
+              for (int t = 0; t < TL; t++) {
+                float pr = 0.f;
 #pragma unroll
-              for (int r = 0; r < 4; r++) pr = fmaf(hl_nt[t][r], dyb[4 * g + r], pr);
-              accf[o][t] += pr;
+                for (int r = 0; r < 4; r++) pr = fmaf(hl_nt[t][r], dyb[4 * g + r], pr);
+                accf[o][t] += pr;
+              }
+              accfb[o] += (g == 0) ? dy : 0.f;
+              NT_FENCE();
             }
-            accfb[o] += (g == 0) ? dy : 0.f;
-            NT_FENCE();
           }
         }
       } else {
@@ -485,10 +490,12 @@ __global__ void __launch_bounds__(BW * 64)
             dyT[to][r] = (row < OUT && live) ? dY[(int64_t)row * N + n] : 0.f;
           }
         chain_bwd4<OTS, TL>(dyT, dhl, W + IM::BO, lane);
-        f32x4 dy_nt[OTS];
+        if constexpr (NEED_DW) {
+          f32x4 dy_nt[OTS];
 #pragma unroll
-        for (int to = 0; to < OTS; to++) to_nt(dyT[to], dy_nt[to], tbuf, g, c);
-        acco.add(dy_nt, hl_nt);
+          for (int to = 0; to < OTS; to++) to_nt(dyT[to], dy_nt[to], tbuf, g, c);
+          acco.add(dy_nt, hl_nt);
+        }
       }
     }
     // ---------------------------------------------------------------- hidden layers, last to first
@@ -498,7 +505,7 @@ __global__ void __launch_bounds__(BW * 64)
       for (int t = 0; t < T3S; t++)
 #pragma unroll
         for (int r = 0; r < 4; r++) dhl[t][r] = dhl[t][r] * d3[t][r];  // dZ3
-      {
+      if constexpr (NEED_DW) {
         f32x4 dz_nt[T3S], hin_nt[T2];
 #pragma unroll
         for (int t = 0; t < T3S; t++) to_nt(dhl[t], dz_nt[t], tbuf, g, c);
@@ -516,7 +523,7 @@ __global__ void __launch_bounds__(BW * 64)
     for (int t = 0; t < T2; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) dh2[t][r] = dh2[t][r] * d2[t][r];  // dZ2
-    {
+    if constexpr (NEED_DW) {
       f32x4 dz_nt[T2], hin_nt[T1];
 #pragma unroll
       for (int t = 0; t < T2; t++) to_nt(dh2[t], dz_nt[t], tbuf, g, c);
@@ -531,7 +538,7 @@ __global__ void __launch_bounds__(BW * 64)
     for (int t = 0; t < T1; t++)
 #pragma unroll
       for (int r = 0; r < 4; r++) dh1[t][r] = dh1[t][r] * d1[t][r];  // dZ1
-    {
+    if constexpr (NEED_DW) {
       // dW0[out][k] = sum_s dZ1[out][s] X[k][s]:  A = dZ1 NT, B = X NT = transposed read of the staged tile
       // (lane (g, c): feature k = 16t+c lives at k-step 4t + c>>2, row c&3; its samples 4g..4g+3 are contiguous)
       f32x4 dz_nt[T1], x_nt[TI0];
@@ -568,6 +575,7 @@ __global__ void __launch_bounds__(BW * 64)
     }
   }
   }  // ---- end of the weight image scope
+  if constexpr (!NEED_DW) return;
   // ---------------------------------------------------------------- wave accumulators -> workgroup image -> global
   // (the weight image is dead once every wave has left the tile loop: the gradient image takes its place)
   __syncthreads();
@@ -1011,6 +1019,17 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
     if (e != hipSuccess) return (int)e;                                                                            \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, dY, dX, a);                  \
   } while (0)
+  if (!a.dW[0]) {  // data gradient only: no accumulators -> more waves per CU, more workgroups
+    if (!dX) return PSDF_OK;
+    auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, true, false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return (int)e;
+    int64_t nb = (ntiles + BW - 1) / BW;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(BW * 64), shmem, st, p, N, X, dY, dX, a);
+    PSDF_LAUNCH_CHECK();
+    return PSDF_OK;
+  }
   if (dX)
     GO(true);
   else
@@ -1026,7 +1045,7 @@ extern "C" {
 
 // Backward of psdf_mlp_forward.  weights[l] / biases[l]: the torch-layout parameters (W_l [dims[l+1], dims[l]]);
 // X [dims[0], N], dY [dims[n_layers], N] and dX [dims[0], N] (or NULL) are feature-major; dW[l] (torch layout) and
-// db[l] are ACCUMULATED INTO (caller zero-fills).
+// db[l] are ACCUMULATED INTO (caller zero-fills); pass dW = db = NULL for the data gradient only (a lighter kernel).
 int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
                       const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
                       void* stream) {
@@ -1034,15 +1053,15 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   int rc = make_plan16(n_layers, dims, p);
   if (rc != PSDF_OK) return rc;
   if (N == 0) return PSDF_OK;
-  if (N < 0 || !X || !weights || !biases || !dY || !dW || !db) return PSDF_ERR_ARG;
+  if (N < 0 || !X || !weights || !biases || !dY || ((dW == nullptr) != (db == nullptr))) return PSDF_ERR_ARG;
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
   BwdPtrs a;
   for (int l = 0; l < MAXL; l++) {
     a.W[l] = l < n_layers ? weights[l] : nullptr;
     a.b[l] = l < n_layers ? biases[l] : nullptr;
-    a.dW[l] = l < n_layers ? dW[l] : nullptr;
-    a.db[l] = l < n_layers ? db[l] : nullptr;
-    if (l < n_layers && (!a.W[l] || !a.b[l] || !a.dW[l] || !a.db[l])) return PSDF_ERR_ARG;
+    a.dW[l] = (dW && l < n_layers) ? dW[l] : nullptr;
+    a.db[l] = (db && l < n_layers) ? db[l] : nullptr;
+    if (l < n_layers && (!a.W[l] || !a.b[l] || (dW && (!a.dW[l] || !a.db[l])))) return PSDF_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;
   const int ti0 = p.tiles[0], t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0,

@@ -67,20 +67,23 @@ def _zero_grads(dims, dev):
     return dWs, dbs
 
 
-def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True):
+def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True, need_dw=True):
     """weights/biases: the torch-layout parameters (the backward kernel builds its own LDS image from them)
-    -> (dx_fm [dims[0], N] or None, [dW_l], [db_l])"""
+    -> (dx_fm [dims[0], N] or None, [dW_l], [db_l]); need_dw=False: data gradient only (lighter kernel, empty lists)"""
     N = x_fm.shape[1]
     n_layers = len(dims) - 1
     dev = x_fm.device
     ws = [w.detach().contiguous() for w in weights]
     bs = [b.detach().contiguous() for b in biases]
     dx = torch.empty((dims[0], N), dtype=torch.float32, device=dev) if need_dx else None
-    dWs, dbs = _zero_grads(dims, dev)
     Wp = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
     Bp = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
-    W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
-    B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
+    if need_dw:
+        dWs, dbs = _zero_grads(dims, dev)
+        W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
+        B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
+    else:
+        dWs, dbs, W, B = [], [], None, None
     L.call("psdf_mlp_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), Wp, Bp, L.ptr(gy_fm),
            L.ptr(dx), W, B, L.stream())
     return dx, dWs, dbs

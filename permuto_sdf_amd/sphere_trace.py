@@ -67,7 +67,7 @@ class SphereTracer:
         if return_gradients:
             # analytic normal: d sdf / d x = encode_backward_positions( mlp_backward_dX( 1 ) )
             gy = torch.ones_like(sdf)
-            d_feat, _, _ = mlp_backward_raw(dims, feat, ws, bs, gy, need_dx=True)
+            d_feat, _, _ = mlp_backward_raw(dims, feat, ws, bs, gy, need_dx=True, need_dw=False)
             grads = torch.zeros((R, 3), dtype=torch.float32, device=dev)
             cfg = self.enc.cfg
             L.call("psdf_encode_backward", *_head(cfg, R), L.ptr(pts), L.ptr(self.enc.lattice_values.detach()),

@@ -157,3 +157,19 @@ def test_double_backward_through_input_gradient(dev, dims):
     for a, b in zip(m.layers, lin64):
         assert (a.weight.grad.cpu().double() - b.weight.grad).abs().max() <= 2e-4 * sc(b.weight.grad)
         assert (a.bias.grad.cpu().double() - b.bias.grad).abs().max() <= 2e-4 * sc(b.bias.grad)
+
+
+@pytest.mark.parametrize("dims", [[52, 32, 32, 32, 1], [36, 64, 64, 64, 1], [52, 32, 32, 32, 33]])
+def test_data_gradient_only_variant(dev, dims):
+    """psdf_mlp_backward with dW = db = NULL (analytic normals at inference): same dX as the full backward"""
+    from permuto_sdf_amd import FusedMLP
+    from permuto_sdf_amd.mlp import mlp_backward_raw
+    torch.manual_seed(1)
+    m = FusedMLP(dims).to(dev)
+    x = torch.randn(dims[0], 3001, device=dev)
+    gy = torch.randn(dims[-1], 3001, device=dev)
+    ws, bs = [l.weight for l in m.layers], [l.bias for l in m.layers]
+    dx_full, dWs, _ = mlp_backward_raw(dims, x, ws, bs, gy)
+    dx_only, none_w, none_b = mlp_backward_raw(dims, x, ws, bs, gy, need_dw=False)
+    assert none_w == [] and none_b == [] and len(dWs) == len(dims) - 1
+    assert torch.equal(dx_full, dx_only)
