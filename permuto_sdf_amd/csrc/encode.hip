@@ -506,6 +506,88 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   if (LATTICE && !(QUEUE && !use_cache)) sc.flush(grad_lattice + tbase);
 }
 
+// Position gradient ONLY (no lattice gradient: inference normals, sphere_trace.py; the reference gets them from
+// autograd, models.py:236-251).  Same level-major launch shape as the forward, but a thread handles POS_LPB consecutive
+// levels and sums their contributions in registers before it touches grad_positions: a quarter of the atomics of the
+// general kernel (which also carries the scatter-cache / queue machinery of the lattice gradient) while the 4 tables
+// of a group (8 MiB) still mostly live in the L2s.
+constexpr int POS_LPB = 4;
+template <int P, int F>
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, const float* __restrict__ positions,
+                          const float* __restrict__ lattice, const float* __restrict__ scale_factor,
+                          const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
+                          const float* __restrict__ grad_sliced, float* __restrict__ grad_positions) {
+  const int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (n >= N) return;
+  float pos[P];
+  load_pos<P>(positions, n, pos);
+  float gp[P];
+#pragma unroll
+  for (int i = 0; i < P; i++) gp[i] = 0.f;
+#pragma unroll
+  for (int li = 0; li < POS_LPB; li++) {
+    const int level = blockIdx.y * POS_LPB + li;
+    if (level >= Lt) break;
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) g[f] = grad_sliced[((int64_t)level * F + f) * N + n];
+    if (level >= L) {  // pseudo-levels: the concatenated, scaled point
+      const int e = level - L;
+#pragma unroll
+      for (int f = 0; f < F; f++) {
+        const int d = e * F + f;
+#pragma unroll
+        for (int i = 0; i < P; i++)
+          if (i == d) gp[i] = gp[i] + g[f] * points_scaling;
+      }
+      continue;
+    }
+    float sfl[P], shl[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      sfl[i] = scale_factor[level * P + i];
+      shl[i] = shifts[level * P + i];
+    }
+    const float w = window[level];
+    const int64_t tbase = (int64_t)level * capacity * F;
+    Simplex<P> s;
+    compute_simplex<P>(pos, shl, sfl, s);
+    float dbary[P + 2];
+#pragma unroll
+    for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
+#pragma unroll
+    for (int r = 0; r <= P; r++) {
+      const uint32_t row = vertex_row<P>(s, r, capacity);
+#pragma unroll
+      for (int f = 0; f < F; f++) dbary[r] = dbary[r] + lattice[tbase + (int64_t)row * F + f] * w * g[f];
+    }
+    dbary[P + 1] = dbary[P + 1] + dbary[0];  // adjoint of bary[0] += 1 + bary[P+1]
+    float dE[P + 1];
+    const float invp = 1.0f / (P + 1);
+#pragma unroll
+    for (int i = 0; i <= P; i++) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int k = 0; k <= P + 1; k++) {
+        if (k == P - s.rank[i]) a = dbary[k];
+        if (k == P + 1 - s.rank[i]) b = dbary[k];
+      }
+      dE[i] = (a - b) * invp;
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j <= i; j++) acc = acc + dE[j];
+      acc = acc - dE[i + 1] * (float)(i + 1);
+      gp[i] = gp[i] + acc * sfl[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < P; i++) atomicAdd(grad_positions + n * P + i, gp[i]);
+}
+
 // One workgroup per (partition, level): fold the queue into an LDS image of the partition's table slice (64-bit
 // compare-and-swap per feature pair, lds_add_pair), then add the slice to the gradient table (plain read-modify-write:
 // this workgroup is the only writer of these rows after the binning kernel has finished).
@@ -805,7 +887,9 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     else if (grad_lattice)                                                                                       \
       BWD(P_, F_, true, false, false);                                                                           \
     else                                                                                                         \
-      BWD(P_, F_, false, true, false);                                                                           \
+      hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, \
+                         st, N, nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, \
+                         points_scaling, grad_sliced, grad_positions);                                           \
     if (use_queue) {                                                                                             \
       const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                          \
       hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                              \
