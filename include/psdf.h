@@ -59,7 +59,7 @@ int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, co
 int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y, void*
     stream);
 
-/* ---- mlp_bwd.hip ---- */
+/* ---- encode.hip / mlp.hip: masked forward ---- */
 /* per-sample masks for fixed-shape callers (one slot per ray: the sphere tracer's converged rays): masked points /
    fully masked 32-sample tiles are not evaluated, their outputs are left untouched */
 int psdf_encode_forward_masked(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
@@ -68,6 +68,7 @@ int psdf_encode_forward_masked(int pos_dim, int nr_feat, int64_t N, int nr_level
 int psdf_mlp_forward_masked(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, const uint8_t*
     skip, float* Y, void* stream);
 
+/* ---- mlp_bwd.hip ---- */
 /* replaces: autograd backward of the same evaluators (dX, dW_l, db_l in one launch; forward recomputed from X).
    weights[l]/biases[l]: torch-layout parameters; dW[l]/db[l] are accumulated into (caller zero-fills); dW = db = NULL:
    data gradient only (lighter kernel: analytic normals at inference) */
