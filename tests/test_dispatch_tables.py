@@ -1,0 +1,40 @@
+"""Host-side dispatch predicates (permuto_sdf_amd/mlp.py) must list exactly the template instantiations the C ABI
+dispatches to (csrc/mlp_bwd.hip CASE tables): a mismatch would surface only at run time as status -2 or as a needless
+torch fallback."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cases(src, func):
+    body = src[src.index("int %s(" % func):]
+    body = body[:body.index("return PSDF_ERR_UNSUPPORTED;\n}")]
+    out = set()
+    for m in re.finditer(r"^\s*CASE\((\d+), (\d+), (\d+), (\d+), (\d+), (true|false)\)", body, re.M):
+        out.add(tuple(int(x) for x in m.groups()[:5]) + (m.group(6) == "true",))
+    return out
+
+
+def _python_set(func_name):
+    import ast
+    src = open(os.path.join(ROOT, "permuto_sdf_amd", "mlp.py")).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == func_name][0]
+    sets = [n for n in ast.walk(fn) if isinstance(n, ast.Set)]
+    return set(ast.literal_eval(ast.unparse(sets[0])))
+
+
+def test_backward_and_double_backward_tables_match():
+    src = open(os.path.join(ROOT, "permuto_sdf_amd", "csrc", "mlp_bwd.hip")).read()
+    assert _cases(src, "psdf_mlp_backward") == _python_set("backward_supported")
+    assert _cases(src, "psdf_mlp_double_backward") == _python_set("double_backward_supported")
+
+
+def test_predicates_on_the_nets_of_the_reference():
+    from permuto_sdf_amd.mlp import backward_supported, double_backward_supported
+    assert backward_supported([52, 32, 32, 32, 33]) and double_backward_supported([52, 32, 32, 32, 33])   # SDF net
+    assert backward_supported([36, 64, 64, 64, 1]) and double_backward_supported([36, 64, 64, 64, 1])     # BASELINE net
+    assert backward_supported([52, 64, 64, 64, 65]) and backward_supported([80, 64, 64, 3])               # background nets
+    assert not backward_supported([112, 128, 128, 64, 3])                                                 # colour net: torch (GPU)
+    assert not double_backward_supported([80, 64, 64, 3])
