@@ -309,8 +309,10 @@ __device__ __forceinline__ void chain_bwd4(const f32x4 (&dz)[TO], f32x4 (&dh)[TI
 constexpr int BW = 4;  // waves per workgroup (one per SIMD: the kernel wants the whole 512-register file)
 
 // NEED_DW = false: data gradient only (dX of a fixed net: analytic normals at inference); no accumulators, no transposes
-template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool NEED_DX, bool NEED_DW = true>
-__global__ void __launch_bounds__(BW * 64)
+// NW = waves per workgroup: 4 (one per SIMD, the whole register file) for 64-wide nets, 8 for 32-wide nets whose
+// accumulators + state fit 256 registers -- two waves per SIMD cover each other's GELU / LDS / MFMA shadows.
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool NEED_DX, bool NEED_DW = true, int NW = BW>
+__global__ void __launch_bounds__(NW * 64)
     mlp_bwd_kernel(Plan16 p, int64_t N, const float* __restrict__ X, const float* __restrict__ dY,
                    float* __restrict__ dX, BwdPtrs a) {
   extern __shared__ __align__(16) float lds[];
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(BW * 64)
   float* dyb = tbuf + 16 * 17;                      // 16 floats
   float* xbuf = dyb + 16;                           // 2 x [SX][64]: layer-0 operand tiles landed by LDS-DMA
   {
-    const int tid = threadIdx.x, nt = BW * 64;
+    const int tid = threadIdx.x, nt = NW * 64;
     const int d0 = p.dims[0], d1 = p.dims[1], d2 = p.dims[2], d3 = p.dims[3];
     for (int e = tid; e < T1 * TI0 * 256; e += nt) {  // layer 0: forward (k-steps by four) and transposed (dX)
       const int j = e & 3, ln = (e >> 2) & 63, gg = ln >> 4, cc = ln & 15;
@@ -394,7 +396,7 @@ __global__ void __launch_bounds__(BW * 64)
     }
   };
   const int64_t ntiles = (N + 15) / 16;
-  const int64_t tile0 = (int64_t)blockIdx.x * BW + wave, tstride = (int64_t)gridDim.x * BW;
+  const int64_t tile0 = (int64_t)blockIdx.x * NW + wave, tstride = (int64_t)gridDim.x * NW;
   if (tile0 < ntiles) prefetch(tile0, xbuf);
   int cur = 0;
   for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
@@ -580,7 +582,7 @@ __global__ void __launch_bounds__(BW * 64)
   // (the weight image is dead once every wave has left the tile loop: the gradient image takes its place)
   __syncthreads();
   float* ACC = lds;
-  for (int e = threadIdx.x; e < p.total; e += BW * 64) ACC[e] = 0.f;
+  for (int e = threadIdx.x; e < p.total; e += NW * 64) ACC[e] = 0.f;
   __syncthreads();
   acc0.flush_layer0(ACC + p.w_off[0], ACC + p.b_off[0], S0, g, c);
   acc1.flush_chain(ACC + p.w_off[1], ACC + p.b_off[1], g, c);
@@ -605,7 +607,7 @@ __global__ void __launch_bounds__(BW * 64)
     acco.flush_chain(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < p.total; e += BW * 64) {
+  for (int e = threadIdx.x; e < p.total; e += NW * 64) {
     const float v = ACC[e];
     if (v == 0.f) continue;
     int l, row, col;
@@ -1005,23 +1007,17 @@ int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, c
 
 template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
 int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
+  constexpr int NW = (T1 <= 2 && T2 <= 2 && T3 <= 2) ? 8 : BW;   // 32-wide nets: two waves per SIMD
   const int64_t ntiles = (N + 15) / 16;
-  int64_t blocks = (ntiles + BW - 1) / BW;
-  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave (pair) walks many tiles
+  int64_t blocks = (ntiles + NW - 1) / NW;
+  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
   using IM = Img<TI0, T1, T2, T3, FINAL_DOT ? 1 : OUT_T, FINAL_DOT>;
   const int img = IM::TOTAL > p.total ? IM::TOTAL : ((p.total + 3) & ~3);
-  const size_t shmem = ((size_t)img + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
-  if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
-#define GO(DX)                                                                                                     \
-  do {                                                                                                             \
-    auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, DX>;                                              \
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
-    if (e != hipSuccess) return (int)e;                                                                            \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, dY, dX, a);                  \
-  } while (0)
   if (!a.dW[0]) {  // data gradient only: no accumulators -> more waves per CU, more workgroups
     if (!dX) return PSDF_OK;
-    auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, true, false>;
+    const size_t shmem = ((size_t)img + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
+    if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
+    auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, true, false, BW>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return (int)e;
     int64_t nb = (ntiles + BW - 1) / BW;
@@ -1030,6 +1026,15 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
     PSDF_LAUNCH_CHECK();
     return PSDF_OK;
   }
+  const size_t shmem = ((size_t)img + NW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
+  if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
+#define GO(DX)                                                                                                     \
+  do {                                                                                                             \
+    auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, DX, true, NW>;                                    \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
+    if (e != hipSuccess) return (int)e;                                                                            \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), shmem, st, p, N, X, dY, dX, a);                  \
+  } while (0)
   if (dX)
     GO(true);
   else
