@@ -351,8 +351,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   float t = 0.f;
   int steps = 0;
   bool inside = true;
-  const double limit = (double)g.n * sqrt(3.0);
-  while (inside && (double)steps < limit) {
+  // reference bound: steps < n*sqrt(3) in double (an irrational number: same as the integer bound floor(..)+1)
+  const int limit = (int)((double)g.n * sqrt(3.0)) + 1;
+  while (inside && steps < limit) {
     const v3 pos = along(org, t, dir);
     const int vox = g.pos_to_idx(pos);
     if (!g.in_range(vox)) {
@@ -430,8 +431,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   int steps = 0;
   bool inside = true;
   v3 out = p;
-  const double limit = (double)g.n * sqrt(3.0);
-  while (inside && (double)steps < limit) {
+  // reference bound: steps < n*sqrt(3) in double (an irrational number: same as the integer bound floor(..)+1)
+  const int limit = (int)((double)g.n * sqrt(3.0)) + 1;
+  while (inside && steps < limit) {
     const v3 q = along(p, t, dir);
     const int vox = g.pos_to_idx(q);
     if (!g.in_range(vox)) {
