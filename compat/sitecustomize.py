@@ -7,6 +7,22 @@ import sys
 import types
 
 
+def _accept_verbose_argument():
+    """The reference's MultiStepLR passes `verbose` positionally to the scheduler base class
+    (permuto_sdf_py/schedulers/multisteplr.py:48); PyTorch >= 2.7 removed that parameter.  Called when `torch._six` is
+    requested, i.e. exactly by the modules that need it (torch is imported by then)."""
+    import torch.optim.lr_scheduler as lrs
+    base = lrs.LRScheduler
+    if getattr(base.__init__, "_psdf_compat", False):
+        return
+    orig = base.__init__
+
+    def __init__(self, optimizer, last_epoch=-1, verbose=None, *args, **kwargs):
+        orig(self, optimizer, last_epoch)
+    __init__._psdf_compat = True
+    base.__init__ = __init__
+
+
 class _TorchSix(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, fullname, path, target=None):
         if fullname == "torch._six":
@@ -31,6 +47,7 @@ class _TorchSix(importlib.abc.MetaPathFinder, importlib.abc.Loader):
                     return lambda *a, **k: None
             m.SummaryWriter = SummaryWriter
             return m
+        _accept_verbose_argument()
         m = types.ModuleType(spec.name)
         m.inf = float("inf")
         m.nan = float("nan")

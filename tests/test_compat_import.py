@@ -28,6 +28,15 @@ sdf = SDF(3, None, 32, 10000)
 assert sdf.encoding.output_dims() == sdf.mlp_sdf[0].in_features
 names = dict(sdf.named_parameters())
 assert any("lattice_values" in k for k in names)            # models.py:408-420 looks parameters up by this name
+# LR schedulers of the reference (pass `verbose` positionally: needs the compat shim on PyTorch >= 2.7)
+from permuto_sdf_py.schedulers.multisteplr import MultiStepLR
+from permuto_sdf_py.schedulers.warmup import GradualWarmupScheduler
+p = torch.nn.Parameter(torch.zeros(3))
+opt = torch.optim.AdamW([p], lr=1e-3)
+sched = GradualWarmupScheduler(opt, multiplier=1, total_epoch=3, after_scheduler=MultiStepLR(opt, milestones=[5, 10], gamma=0.3))
+for _ in range(12):
+    opt.step(); sched.step()
+assert 0 < opt.param_groups[0]["lr"] < 1e-3
 # the training script itself: everything up to the first CUDA call at module level must import
 try:
     importlib.import_module("permuto_sdf_py.train_permuto_sdf")
