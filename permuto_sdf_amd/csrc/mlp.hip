@@ -117,16 +117,27 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
         }
       }
     }
+#ifdef PSDF_GELU_INCHAIN
+    f32x16 h2[T2];
+    init_bias<T2>(h2, lds + p.b_off[1], h);
+    dense_chain_gelu<T1, T2>(h1, h2, lds + p.w_off[1], lane);
+    if constexpr (T3 == 0) apply_gelu<T2>(h2);
+#else
     apply_gelu<T1>(h1);
     f32x16 h2[T2];
     init_bias<T2>(h2, lds + p.b_off[1], h);
     dense_chain<T1, T2>(h1, h2, lds + p.w_off[1], lane);
     apply_gelu<T2>(h2);
+#endif
     constexpr int TL = (T3 > 0) ? T3 : T2;
     f32x16 hl[TL];
     if constexpr (T3 > 0) {
       init_bias<T3>(hl, lds + p.b_off[2], h);
+#ifdef PSDF_GELU_INCHAIN
+      dense_chain_gelu<T2, T3>(h2, hl, lds + p.w_off[2], lane);
+#else
       dense_chain<T2, T3>(h2, hl, lds + p.w_off[2], lane);
+#endif
       apply_gelu<T3>(hl);
     } else {
 #pragma unroll

@@ -131,11 +131,15 @@ __device__ __forceinline__ void apply_gelu(f32x16 (&acc)[T]) {
 #pragma unroll
   for (int to = 0; to < T; to++)
 #pragma unroll
+#ifdef PSDF_GELU_SCALAR
+    for (int r = 0; r < 16; r++) acc[to][r] = gelu_exact(acc[to][r]);
+#else
     for (int r = 0; r < 16; r += 2) {
       const f32x2 y = gelu_exact2(f32x2{acc[to][r], acc[to][r + 1]});
       acc[to][r] = y.x;
       acc[to][r + 1] = y.y;
     }
+#endif
 }
 
 // out^T = W * in^T for register-resident activations (chained layout, see header).
@@ -156,6 +160,28 @@ __device__ __forceinline__ void dense_chain(const f32x16 (&in)[TI], f32x16 (&out
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const float b = in[ti][4 * rq + j];
+#pragma unroll
+        for (int to = 0; to < TO; to++) out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[to][j], b, out[to], 0, 0, 0);
+      }
+    }
+}
+
+// Same chain with the activation of the INPUT applied per k-step, right before the MFMAs that consume that row
+// (k-step r of the chain only needs gelu(in[.][r])): the VALU work sits in the shadow of the matrix pipe.
+template <int TI, int TO>
+__device__ __forceinline__ void dense_chain_gelu(const f32x16 (&in)[TI], f32x16 (&out)[TO],
+                                                 const float* __restrict__ w_lds, int lane) {
+#pragma unroll
+  for (int ti = 0; ti < TI; ti++)
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      f32x4w a[TO];
+#pragma unroll
+      for (int to = 0; to < TO; to++)
+        a[to] = *reinterpret_cast<const f32x4w*>(w_lds + (((to * TI + ti) * 4 + rq) * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float b = gelu_exact(in[ti][4 * rq + j]);
 #pragma unroll
         for (int to = 0; to < TO; to++) out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[to][j], b, out[to], 0, 0, 0);
       }
