@@ -64,6 +64,56 @@ __global__ void mlp_pack_kernel(PackArgs a, float* __restrict__ packed) {
   packed[e] = v;
 }
 
+// Split-bf16 image (mlp_device.h): one thread per 32-bit word = two bf16 of one piece of one lane record, or one float
+// of the tail.
+__global__ void mlp_pack_split_kernel(PackArgs a, SplitPlan sp, float* __restrict__ packed) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  const MlpPlan& p = a.plan;
+  if (w >= sp.total_rec * 4) return;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(packed + sp.base);
+  const int nl = p.n_layers;
+  const int rec = w >> 2;
+  if (rec >= sp.tail_rec) {
+    const int f = w - sp.tail_rec * 4;
+    float v = 0.f;
+    for (int l = 0; l < nl; l++) {
+      const bool dot = (l == nl - 1) && p.final_dot;
+      const int nb = dot ? 4 : p.tiles[l + 1] * 32;
+      if (f >= sp.b_off[l] && f < sp.b_off[l] + nb) {
+        const int row = f - sp.b_off[l];
+        if (row < p.dims[l + 1]) v = a.b[l][row];
+      }
+      if (dot && f >= sp.wf_off && f < sp.wf_off + p.dims[nl] * p.tiles[l] * 32) {
+        const int q = f - sp.wf_off;  // [o][ti][r][h]
+        const int h = q & 1, r = (q >> 1) & 15, ti = (q >> 5) % p.tiles[l], o = (q >> 5) / p.tiles[l];
+        const int col = 32 * ti + row_of(r, h);
+        if (col < p.dims[l]) v = a.W[l][(int64_t)o * p.dims[l] + col];
+      }
+    }
+    dst[w] = __float_as_uint(v);
+    return;
+  }
+  int l = 0;
+  for (int i = 1; i < nl; i++) {
+    const bool dot = (i == nl - 1) && p.final_dot;
+    if (!dot && rec >= sp.w_rec[i]) l = i;
+  }
+  const int local = rec - sp.w_rec[l];
+  const int lane = local & 63, piece = (local >> 6) % 3, s = (local / 192) % sp.ns[l], to = (local / 192) / sp.ns[l];
+  const int row = 32 * to + (lane & 31), hh = lane >> 5;
+  uint32_t out = 0;
+  for (int e = 0; e < 2; e++) {
+    const int j = 2 * (w & 3) + e;
+    const int col = l == 0 ? 16 * s + 8 * hh + j : 32 * (s >> 1) + row_of(8 * (s & 1) + j, hh);
+    float v = 0.f;
+    if (row < p.dims[l + 1] && col < p.dims[l]) v = a.W[l][(int64_t)row * p.dims[l] + col];
+    uint32_t pc[3];
+    split3(v, pc);
+    out |= pc[piece] << (16 * e);
+  }
+  dst[w] = out;
+}
+
 // Forward of the whole net for one 32-sample tile; fills the hidden pre-activation free result in `hid`.
 // T1,T2,T3: hidden widths in tiles of 32 (T3 == 0: only two hidden layers).
 template <int T1, int T2, int T3>
@@ -117,27 +167,16 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
         }
       }
     }
-#ifdef PSDF_GELU_INCHAIN
-    f32x16 h2[T2];
-    init_bias<T2>(h2, lds + p.b_off[1], h);
-    dense_chain_gelu<T1, T2>(h1, h2, lds + p.w_off[1], lane);
-    if constexpr (T3 == 0) apply_gelu<T2>(h2);
-#else
     apply_gelu<T1>(h1);
     f32x16 h2[T2];
     init_bias<T2>(h2, lds + p.b_off[1], h);
     dense_chain<T1, T2>(h1, h2, lds + p.w_off[1], lane);
     apply_gelu<T2>(h2);
-#endif
     constexpr int TL = (T3 > 0) ? T3 : T2;
     f32x16 hl[TL];
     if constexpr (T3 > 0) {
       init_bias<T3>(hl, lds + p.b_off[2], h);
-#ifdef PSDF_GELU_INCHAIN
-      dense_chain_gelu<T2, T3>(h2, hl, lds + p.w_off[2], lane);
-#else
       dense_chain<T2, T3>(h2, hl, lds + p.w_off[2], lane);
-#endif
       apply_gelu<T3>(hl);
     } else {
 #pragma unroll
@@ -173,6 +212,137 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
   }
 }
 
+// The same evaluator on the bf16 matrix pipe with split fp32 operands (mlp_device.h, "split-bf16 operand path").
+// CH: k-steps of layer 0 whose loads are issued together (= all of them when the input has <= 64 features).
+template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, int CH>
+__global__ void __launch_bounds__(PSDF_BLOCK, 2)
+    mlp_fwd_split_kernel(MlpPlan p, SplitPlan sp, int64_t N, const float* __restrict__ X,
+                         const float* __restrict__ packed, const unsigned char* __restrict__ skip,
+                         float* __restrict__ Y) {
+  extern __shared__ __align__(16) u32x4 simg[];
+  {
+    const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(packed + sp.base);
+    for (int i = threadIdx.x; i < sp.total_rec; i += PSDF_BLOCK) simg[i] = src[i];
+  }
+  __syncthreads();
+  const float* tail = reinterpret_cast<const float*>(simg + sp.tail_rec);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, sl = lane & 31;
+  const int K0 = p.dims[0];
+  const int OUT = p.dims[p.n_layers];
+  const int ns0 = sp.ns[0];
+  const int64_t ntiles = (N + 31) / 32;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    asm volatile("" ::: "memory");  // keeps the loop-invariant LDS reads inside the tile loop (see mlp_fwd_kernel)
+    const int64_t n = tile * 32 + sl;
+    const int64_t nc = n < N ? n : N - 1;
+    if (skip && __ballot(n < N && !skip[nc]) == 0) continue;
+    // ---- layer 0: lane (n, h) reads features 16 s + 8 h + j; CH k-steps of loads in flight before their MFMAs
+    f32x16 h1[T1];
+    init_bias4<T1>(h1, tail + sp.b_off[0], h);
+    const float* __restrict__ xl = X + nc + (h ? (int64_t)8 * N : (int64_t)0);  // this lane's column, rows 8 h + ...
+    for (int s0 = 0; s0 < ns0; s0 += CH) {
+      float xs[CH][8];
+#pragma unroll
+      for (int i = 0; i < CH; i++) {
+        const int sb = 16 * (s0 + i);  // wave-uniform
+        if (sb + 16 <= K0) {           // whole k-step inside the input: row offsets are scalar, no guards
+#pragma unroll
+          for (int j = 0; j < 8; j++) xs[i][j] = xl[(int64_t)(sb + j) * N];
+        } else if (sb < K0) {          // the partial last k-step: clamped address + select (no exec-mask branch per load)
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const int k = sb + 8 * h + j;
+            const float v = X[(int64_t)(k < K0 ? k : K0 - 1) * N + nc];
+            xs[i][j] = k < K0 ? v : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; j++) xs[i][j] = 0.f;
+        }
+      }
+      // branch-free: a k-step past the end multiplies zeros with the (finite) last weight record -- a guarded MFMA would
+      // make the accumulators live across control flow (32 register copies per branch)
+#pragma unroll
+      for (int i = 0; i < CH; i++) {
+        const int s = s0 + i < ns0 ? s0 + i : ns0 - 1;
+        split_mac<T1>(h1, xs[i], simg + sp.w_rec[0] + s * 192, ns0, lane);
+      }
+    }
+    apply_gelu_scalar<T1>(h1);
+    f32x16 h2[T2];
+    init_bias4<T2>(h2, tail + sp.b_off[1], h);
+    split_chain<T1, T2>(h1, h2, simg + sp.w_rec[1], lane);
+    apply_gelu_scalar<T2>(h2);
+    constexpr int TL = (T3 > 0) ? T3 : T2;
+    f32x16 hl[TL];
+    if constexpr (T3 > 0) {
+      init_bias4<T3>(hl, tail + sp.b_off[2], h);
+      split_chain<T2, T3>(h2, hl, simg + sp.w_rec[2], lane);
+      apply_gelu_scalar<T3>(hl);
+    } else {
+#pragma unroll
+      for (int t = 0; t < T2; t++) hl[t] = h2[t];
+    }
+    const int lf = p.n_layers - 1;
+    if constexpr (FINAL_DOT) {
+      const float* __restrict__ wf = tail + sp.wf_off;
+      for (int o = 0; o < OUT; o++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < TL; ti++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc = fmaf(wf[((o * TL + ti) * 16 + r) * 2 + h], hl[ti][r], acc);
+        acc += __shfl_xor(acc, 32, 64);
+        acc += tail[sp.b_off[lf] + o];
+        if (h == 0 && n < N) Y[(int64_t)o * N + n] = acc;
+      }
+    } else {
+      f32x16 y[OUT_T];
+      init_bias4<OUT_T>(y, tail + sp.b_off[lf], h);
+      split_chain<TL, OUT_T>(hl, y, simg + sp.w_rec[lf], lane);
+      if (n < N) {
+#pragma unroll
+        for (int to = 0; to < OUT_T; to++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = 32 * to + row_of(r, h);
+            if (row < OUT) Y[(int64_t)row * N + n] = y[to][r];
+          }
+      }
+    }
+  }
+}
+
+template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, int CH>
+int launch_fwd_split_ch(const MlpPlan& p, const SplitPlan& sp, int64_t N, const float* X, const float* packed,
+                     const unsigned char* skip, float* Y, hipStream_t st) {
+  const size_t shmem = (size_t)sp.total_rec * 16;
+  auto kern = mlp_fwd_split_kernel<T1, T2, T3, OUT_T, FINAL_DOT, CH>;
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t ntiles = (N + 31) / 32;
+  int64_t blocks = (ntiles + 3) / 4;
+  const int64_t cap = 256 * 4;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PSDF_BLOCK), shmem, st, p, sp, N, X, packed, skip, Y);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+int launch_fwd_split(const MlpPlan& p, const SplitPlan& sp, int64_t N, const float* X, const float* packed,
+                     const unsigned char* skip, float* Y, hipStream_t st) {
+  switch (sp.ns[0]) {  // up to 64 input features: one chunk, no padded k-step
+    case 1: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 1>(p, sp, N, X, packed, skip, Y, st);
+    case 2: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 2>(p, sp, N, X, packed, skip, Y, st);
+    case 3: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 3>(p, sp, N, X, packed, skip, Y, st);
+    default: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 4>(p, sp, N, X, packed, skip, Y, st);
+  }
+}
+
 template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
 int launch_fwd(const MlpPlan& p, int64_t N, const float* X, const float* packed, const unsigned char* skip, float* Y,
                hipStream_t st) {
@@ -202,7 +372,9 @@ extern "C" {
 int64_t psdf_mlp_packed_size(int n_layers, const int* dims) {
   MlpPlan p;
   if (make_plan(n_layers, dims, p) != PSDF_OK) return PSDF_ERR_ARG;
-  return p.total;
+  SplitPlan sp;
+  make_split_plan(p, sp);
+  return sp.ok ? (int64_t)sp.base + (int64_t)sp.total_rec * 4 : (int64_t)p.total;
 }
 
 // weights[l]: device pointer to torch-layout W_l [dims[l+1], dims[l]]; biases[l]: [dims[l+1]].
@@ -218,6 +390,13 @@ int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, co
   hipLaunchKernelGGL(mlp_pack_kernel, dim3(psdf_blocks(a.plan.total, 256)), dim3(256), 0, (hipStream_t)stream, a,
                      packed);
   PSDF_LAUNCH_CHECK();
+  SplitPlan sp;
+  make_split_plan(a.plan, sp);
+  if (sp.ok) {  // second image of the same parameters: bf16 pieces in the operand order of mlp_fwd_split_kernel
+    hipLaunchKernelGGL(mlp_pack_split_kernel, dim3(psdf_blocks(sp.total_rec * 4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, a, sp, packed);
+    PSDF_LAUNCH_CHECK();
+  }
   return PSDF_OK;
 }
 
@@ -232,16 +411,23 @@ static int mlp_forward_impl(int n_layers, const int* dims, int64_t N, const floa
   hipStream_t st = (hipStream_t)stream;
   const int t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0, to = p.tiles[n_layers];
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
-#define CASE(A, B, C, O, D)                                          \
-  if (t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
-    return launch_fwd<A, B, C, O, D>(p, N, X, packed, skip, Y, st);
-  CASE(2, 2, 2, 1, true)   // 64x3 -> 1..4      (BASELINE SDF net)
-  CASE(1, 1, 1, 1, true)   // 32x3 -> 1..4
-  CASE(1, 1, 1, 2, false)  // 32x3 -> 33        (reference SDF net, models.py:153-161)
-  CASE(2, 2, 2, 3, false)  // 64x3 -> 65        (background density+feature net, models.py:451-459)
-  CASE(2, 2, 2, 2, false)  // 64x3 -> 33
-  CASE(2, 2, 0, 1, true)   // 64x2 -> 3         (background colour head, models.py:463-469)
-  CASE(4, 4, 2, 1, true)   // 128,128,64 -> 3   (colour net, models.py:350)
+  SplitPlan sp;
+  make_split_plan(p, sp);
+  // S: shapes whose split-bf16 image can fit SPLIT_LDS_MAX (the wider nets never do, so that kernel is not built for them)
+#define CASE(A, B, C, O, D, S)                                                   \
+  if (t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) {           \
+    if constexpr (S) {                                                          \
+      if (sp.ok) return launch_fwd_split<A, B, C, O, D>(p, sp, N, X, packed, skip, Y, st); \
+    }                                                                           \
+    return launch_fwd<A, B, C, O, D>(p, N, X, packed, skip, Y, st);             \
+  }
+  CASE(2, 2, 2, 1, true, true)    // 64x3 -> 1..4      (BASELINE SDF net)
+  CASE(1, 1, 1, 1, true, true)    // 32x3 -> 1..4
+  CASE(1, 1, 1, 2, false, true)   // 32x3 -> 33        (reference SDF net, models.py:153-161)
+  CASE(2, 2, 2, 3, false, false)  // 64x3 -> 65        (background density+feature net, models.py:451-459)
+  CASE(2, 2, 2, 2, false, false)  // 64x3 -> 33
+  CASE(2, 2, 0, 1, true, true)    // 64x2 -> 3         (background colour head, models.py:463-469)
+  CASE(4, 4, 2, 1, true, false)   // 128,128,64 -> 3   (colour net, models.py:350)
 #undef CASE
   return PSDF_ERR_UNSUPPORTED;
 }

@@ -131,15 +131,21 @@ __device__ __forceinline__ void apply_gelu(f32x16 (&acc)[T]) {
 #pragma unroll
   for (int to = 0; to < T; to++)
 #pragma unroll
-#ifdef PSDF_GELU_SCALAR
-    for (int r = 0; r < 16; r++) acc[to][r] = gelu_exact(acc[to][r]);
-#else
     for (int r = 0; r < 16; r += 2) {
       const f32x2 y = gelu_exact2(f32x2{acc[to][r], acc[to][r + 1]});
       acc[to][r] = y.x;
       acc[to][r + 1] = y.y;
     }
-#endif
+}
+
+// One element per instruction: the form to use beside bf16 MFMAs (packed fp32 arithmetic does not hide in the shadow of
+// the matrix pipe, plain VALU does: tools/mfma_valu_overlap.hip).  Same operations as the packed form, same bits.
+template <int T>
+__device__ __forceinline__ void apply_gelu_scalar(f32x16 (&acc)[T]) {
+#pragma unroll
+  for (int to = 0; to < T; to++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[to][r] = gelu_exact(acc[to][r]);
 }
 
 // out^T = W * in^T for register-resident activations (chained layout, see header).
@@ -166,26 +172,144 @@ __device__ __forceinline__ void dense_chain(const f32x16 (&in)[TI], f32x16 (&out
     }
 }
 
-// Same chain with the activation of the INPUT applied per k-step, right before the MFMAs that consume that row
-// (k-step r of the chain only needs gelu(in[.][r])): the VALU work sits in the shadow of the matrix pipe.
-template <int TI, int TO>
-__device__ __forceinline__ void dense_chain_gelu(const f32x16 (&in)[TI], f32x16 (&out)[TO],
-                                                 const float* __restrict__ w_lds, int lane) {
+// ------------------------------------------------------------------------------ split-bf16 operand path
+// fp32 MFMAs and VALU work do not overlap on gfx950 (their times add), bf16 MFMAs do and are 16x faster per k
+// (tools/mfma_valu_overlap.hip, profiles/r01_mfma_valu_overlap.txt).  So the forward evaluator multiplies fp32
+// operands as three bf16 pieces each, a = a1 + a2 + a3 (8 mantissa bits per piece, by truncation, so the sum is
+// exact), and keeps the six products down to 2^-16 relative size:
+//     a b ~= a3 b1 + a2 b2 + a1 b3 + a2 b1 + a1 b2 + a1 b1          (error ~2^-22 |a b|, fp32 accumulation)
+// on v_mfma_f32_32x32x16_bf16: 6/16 of the fp32 matrix time, hidden under the GELU.  Same chained-register design:
+// D tile of layer l = B operand of layer l+1.  Lane (sample n = lane & 31, half h = lane >> 5) supplies, for k-step s
+// of input tile ti = s >> 1, its registers r = 8 (s & 1) + j, j = 0..7, i.e. the neurons 32 ti + row_of(r, h); the
+// weight image is permuted to match.  Layer 0 reads features k = 16 s + 8 h + j of the feature-major input.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SPLIT_LDS_MAX = 80 * 1024;  // two workgroups per CU
+
+struct SplitPlan {
+  int ok;            // the image fits SPLIT_LDS_MAX (else the fp32 MFMA kernel is used)
+  int base;          // float offset of the split image inside the packed buffer (multiple of 4: 16-byte records)
+  int ns[MAXL];      // k-steps (16 inputs each) of layer l
+  int w_rec[MAXL];   // record offset of layer l's weight image [to][s][piece][lane] (8 bf16 per record)
+  int tail_rec;      // record offset of the fp32 tail (biases, final dot weights)
+  int b_off[MAXL];   // float offsets inside the tail
+  int wf_off;        // final dot weights [o][ti][r][h] (final_dot nets)
+  int total_rec;
+};
+
+static void make_split_plan(const MlpPlan& p, SplitPlan& sp) {
+  sp.base = (p.total + 3) & ~3;
+  int rec = 0;
+  const int nl = p.n_layers;
+  for (int l = 0; l < MAXL; l++) sp.ns[l] = sp.w_rec[l] = sp.b_off[l] = 0;
+  for (int l = 0; l < nl; l++) {
+    const bool dot = (l == nl - 1) && p.final_dot;
+    sp.ns[l] = l == 0 ? (p.dims[0] + 15) / 16 : 2 * p.tiles[l];
+    sp.w_rec[l] = rec;
+    if (!dot) rec += p.tiles[l + 1] * sp.ns[l] * 3 * 64;
+  }
+  sp.tail_rec = rec;
+  int f = 0;
+  for (int l = 0; l < nl; l++) {
+    const bool dot = (l == nl - 1) && p.final_dot;
+    if (dot) {
+      sp.wf_off = f;
+      f += p.dims[nl] * p.tiles[l] * 32;
+    }
+    sp.b_off[l] = f;
+    f += dot ? 4 : p.tiles[l + 1] * 32;
+  }
+  if (!p.final_dot) sp.wf_off = 0;
+  sp.total_rec = rec + (f + 3) / 4;
+  sp.ok = (nl == 3 || nl == 4) && (size_t)sp.total_rec * 16 <= (size_t)SPLIT_LDS_MAX;
+}
+
+// three bf16 pieces of a float (top 16 bits of the running remainder); host + device, used by the pack kernel
+__host__ __device__ inline void split3(float x, uint32_t (&piece)[3]) {
+  float r = x;
 #pragma unroll
-  for (int ti = 0; ti < TI; ti++)
+  for (int i = 0; i < 3; i++) {
+    uint32_t u;
+    __builtin_memcpy(&u, &r, 4);
+    piece[i] = u >> 16;
+    const uint32_t t = u & 0xFFFF0000u;
+    float tf;
+    __builtin_memcpy(&tf, &t, 4);
+    r -= tf;
+  }
+}
+
+// eight fp32 registers -> three bf16x8 B operands
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+  uint32_t a[8], b[8], c[8];
 #pragma unroll
-    for (int rq = 0; rq < 4; rq++) {
-      f32x4w a[TO];
+  for (int j = 0; j < 8; j++) {
+    a[j] = __float_as_uint(x[j]);
+    const float r1 = x[j] - __uint_as_float(a[j] & 0xFFFF0000u);
+    b[j] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(b[j] & 0xFFFF0000u);
+    c[j] = __float_as_uint(r2);
+  }
+  u32x4 q1, q2, q3;
 #pragma unroll
-      for (int to = 0; to < TO; to++)
-        a[to] = *reinterpret_cast<const f32x4w*>(w_lds + (((to * TI + ti) * 4 + rq) * 64 + lane) * 4);
+  for (int i = 0; i < 4; i++) {  // v_perm_b32: {high half of odd element, high half of even element}
+    q1[i] = __builtin_amdgcn_perm(a[2 * i + 1], a[2 * i], 0x07060302u);
+    q2[i] = __builtin_amdgcn_perm(b[2 * i + 1], b[2 * i], 0x07060302u);
+    q3[i] = __builtin_amdgcn_perm(c[2 * i + 1], c[2 * i], 0x07060302u);
+  }
+  p1 = __builtin_bit_cast(bf16x8, q1);
+  p2 = __builtin_bit_cast(bf16x8, q2);
+  p3 = __builtin_bit_cast(bf16x8, q3);
+}
+
+// bias rows of a D tile: registers 4q..4q+3 of lane half h are the consecutive rows 8q + 4h .. +3 -> one 128-bit read
+// (every bias block of the split image starts on a 16-byte boundary)
+template <int T>
+__device__ __forceinline__ void init_bias4(f32x16 (&acc)[T], const float* __restrict__ bias_lds, int h) {
+  const f32x4w* __restrict__ b4 = reinterpret_cast<const f32x4w*>(bias_lds);
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float b = gelu_exact(in[ti][4 * rq + j]);
+  for (int to = 0; to < T; to++)
 #pragma unroll
-        for (int to = 0; to < TO; to++) out[to] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[to][j], b, out[to], 0, 0, 0);
-      }
+    for (int q = 0; q < 4; q++) {
+      const f32x4w v = b4[8 * to + 2 * q + h];
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc[to][4 * q + c] = v[c];
     }
 }
+
+// one k-step (16 inputs) into TO output tiles.  w_s -> record [to = 0][s][piece 0][lane 0]; `to` stride = ns*192 records.
+template <int TO>
+__device__ __forceinline__ void split_mac(f32x16 (&out)[TO], const float (&x)[8], const u32x4* __restrict__ w_s, int ns,
+                                          int lane) {
+  bf16x8 b1, b2, b3;
+  split8(x, b1, b2, b3);
+#pragma unroll
+  for (int to = 0; to < TO; to++) {
+    const u32x4* wt = w_s + to * ns * 192 + lane;
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, wt[0]);
+    const bf16x8 a2 = __builtin_bit_cast(bf16x8, wt[64]);
+    const bf16x8 a3 = __builtin_bit_cast(bf16x8, wt[128]);
+    out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, out[to], 0, 0, 0);  // smallest terms first
+    out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, out[to], 0, 0, 0);
+    out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, out[to], 0, 0, 0);
+    out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, out[to], 0, 0, 0);
+    out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, out[to], 0, 0, 0);
+    out[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, out[to], 0, 0, 0);
+  }
+}
+
+template <int TI, int TO>
+__device__ __forceinline__ void split_chain(const f32x16 (&in)[TI], f32x16 (&out)[TO], const u32x4* __restrict__ w,
+                                            int lane) {
+#pragma unroll
+  for (int s = 0; s < 2 * TI; s++) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = in[s >> 1][8 * (s & 1) + j];
+    split_mac<TO>(out, x, w + s * 192, 2 * TI, lane);
+  }
+}
+
 
 }  // namespace

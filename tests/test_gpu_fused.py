@@ -1,5 +1,7 @@
-"""GPU: fused encode->MLP launch (csrc/fused.hip) == the unfused pair psdf_encode_forward + psdf_mlp_forward, BIT FOR BIT
-(same expressions in the same order, same MFMA k order), for every built net; skip-mask and by-product feature tensor."""
+"""GPU: fused encode->MLP launch (csrc/fused.hip) vs the unfused pair psdf_encode_forward + psdf_mlp_forward.  The
+encoding by-product is BIT-identical (same expressions in the same order).  The network output is bit-identical where
+both launches use the fp32 matrix pipe; nets that psdf_mlp_forward evaluates with split-bf16 operands (mlp_device.h)
+agree to fp32 rounding level (different summation order).  Skip-mask and by-product feature tensor."""
 import numpy as np
 import pytest
 import torch
@@ -29,6 +31,13 @@ def _setup(dev, levels, concat, net, seed=0):
     return enc, mlp, packed, win
 
 
+def _same_output(net, yf, y):
+    if net == [64, 64, 64, 33]:      # too wide for the split-bf16 image: both launches are the fp32 MFMA evaluator
+        assert torch.equal(yf, y)
+    else:
+        assert (yf - y).abs().max() <= 3e-6 * max(1.0, y.abs().max().item())
+
+
 @pytest.mark.parametrize("levels,concat,net", CASES)
 @pytest.mark.parametrize("N", [1, 33, 10007])
 def test_fused_equals_unfused_bitwise(dev, levels, concat, net, N):
@@ -42,9 +51,9 @@ def test_fused_equals_unfused_bitwise(dev, levels, concat, net, N):
     y = mlp_forward_raw(mlp.dims, feat, packed)
     yf, ff = encode_mlp_forward_raw(*args, mlp.dims, packed, want_feat=True)
     assert torch.equal(ff, feat)
-    assert torch.equal(yf, y)
+    _same_output(net, yf, y)
     yf2, none = encode_mlp_forward_raw(*args, mlp.dims, packed)
-    assert none is None and torch.equal(yf2, y)
+    assert none is None and torch.equal(yf2, yf)
 
 
 def test_skip_mask_leaves_fully_masked_tiles_untouched(dev):

@@ -59,6 +59,54 @@ def test_forward_asymmetric_weights(dev):
     assert (y - y_ref).abs().max() <= 2e-5 * max(1.0, y_ref.abs().max().item())
 
 
+SPLIT_NETS = [[36, 64, 64, 64, 1], [52, 64, 64, 64, 1], [52, 32, 32, 32, 33], [80, 64, 64, 3], [7, 32, 32, 32, 2],
+              [100, 64, 64, 64, 4]]
+
+
+@pytest.mark.parametrize("dims", SPLIT_NETS)
+def test_split_bf16_forward_keeps_fp32_accuracy(dev, dims):
+    """The nets whose split-bf16 image fits the LDS run on the bf16 matrix pipe with each fp32 operand as three bf16
+    pieces (six products kept).  Against a float64 evaluation the error must stay at the level of an fp32 evaluation
+    (torch fp32 on the CPU, same weights), not at bf16 level (1e-2) nor at three-product level (1e-4)."""
+    from permuto_sdf_amd import FusedMLP
+    torch.manual_seed(dims[0])
+    ref = _ref_net(dims)
+    x = torch.randn(20000, dims[0]) * 2.0
+    y64 = ref.double()(x.double()).detach()
+    y32 = ref.float()(x).detach().double()
+    m = FusedMLP.from_sequential(ref.float()).to(dev)
+    with torch.no_grad():
+        y = m(x.to(dev)).cpu().double()
+    scale = y64.abs().max().item()
+    err_hip, err_t32 = (y - y64).abs().max().item(), (y32 - y64).abs().max().item()
+    assert err_hip <= max(4.0 * err_t32, 2e-6 * scale), (err_hip, err_t32, scale)
+
+
+def test_split_bf16_forward_input_ranges(dev):
+    """Pieces are taken by truncation of the running remainder, so tiny, huge and exactly-representable inputs all
+    reconstruct exactly: zeros, denormal-range values, 1e4-scale inputs, mixed signs."""
+    from permuto_sdf_amd import FusedMLP
+    dims = [36, 64, 64, 64, 1]
+    torch.manual_seed(3)
+    ref = _ref_net(dims)
+    m = FusedMLP.from_sequential(ref).to(dev)
+    g = torch.Generator().manual_seed(4)
+    cases = {
+        "zeros": torch.zeros(100, 36),
+        "tiny": torch.randn(100, 36, generator=g) * 1e-30,
+        "large": torch.randn(100, 36, generator=g) * 1e4,
+        "mixed": torch.randn(100, 36, generator=g) * torch.logspace(-20, 3, 36)[None, :],
+        "powers_of_two": torch.full((100, 36), 0.5),
+    }
+    for name, x in cases.items():
+        y64 = ref.double()(x.double()).detach()
+        ref.float()
+        with torch.no_grad():
+            y = m(x.to(dev)).cpu().double()
+        assert torch.isfinite(y).all(), name
+        assert (y - y64).abs().max() <= 3e-6 * max(1.0, y64.abs().max().item()), name
+
+
 BWD_NETS = [[52, 64, 64, 64, 1], [36, 64, 64, 64, 1], [52, 32, 32, 32, 33], [52, 64, 64, 64, 65], [80, 64, 64, 3],
             [51, 32, 32, 32, 1], [20, 64, 64, 64, 1], [20, 32, 32, 32, 1]]
 
