@@ -231,6 +231,9 @@ def main():
             "config": {"workload": "cfg2+composite: 16-level permutohedral encode fwd/bwd + 64x3 SDF MLP fwd/bwd + NeuS "
                                    "compositing fwd/bwd + AdamW, %d rays x %d samples = %d samples per GPU" % (NR_RAYS, SAMPLES_PER_RAY, N),
                        "pos_dim": 3, "nr_levels": NR_LEVELS, "capacity": Tcap, "feat_per_level": F, "mlp": "36-64-64-64-1 GELU",
+                       "mlp_forward_arithmetic": "fp32 operands multiplied as 3 bf16 pieces each, 6 products kept, fp32 accumulation "
+                                                 "(error at fp32 rounding level: tests/test_gpu_mlp.py::test_split_bf16_forward_keeps_fp32_accuracy); "
+                                                 "backward: fp32 MFMA",
                        "parallelism": "ray-sharded dp%d, RCCL grad all-reduce" % world if world > 1 else "single GPU"},
             "roofline": roof,
             "roofline_other": other,
