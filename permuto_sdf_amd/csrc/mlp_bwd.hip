@@ -105,7 +105,86 @@ struct BwdPtrs {
   const float* b[MAXL];
   float* dW[MAXL];
   float* db[MAXL];
+  float* partial;  // [gridDim.x][p.total] workgroup gradient images (summed by mlp_grad_reduce_kernel), or NULL: atomics
 };
+
+// Workgroup gradient image -> global.  With a scratch buffer every workgroup stores its image (coalesced, no atomics:
+// 256 workgroups adding into the same ~11 K addresses serialise in the L2) and a small second launch sums them.
+template <int NTHREADS>
+__device__ __forceinline__ void flush_image(const Plan16& p, const BwdPtrs& a, const float* __restrict__ ACC) {
+  if (a.partial) {
+    float* __restrict__ dst = a.partial + (size_t)blockIdx.x * p.total;
+    for (int e = threadIdx.x; e < p.total; e += NTHREADS) dst[e] = ACC[e];
+    return;
+  }
+  for (int e = threadIdx.x; e < p.total; e += NTHREADS) {
+    const float v = ACC[e];
+    if (v == 0.f) continue;
+    int l, row, col;
+    bool is_bias;
+    unpack_index(p, e, l, row, col, is_bias);
+    if (is_bias) {
+      if (row < p.dims[l + 1]) atomicAdd(a.db[l] + row, v);
+    } else if (row < p.dims[l + 1] && col < p.dims[l]) {
+      atomicAdd(a.dW[l] + (int64_t)row * p.dims[l] + col, v);
+    }
+  }
+}
+
+// 64 image entries per workgroup; wave w sums the workgroup images w, w+4, ... (coalesced), LDS combines the four.
+__global__ void __launch_bounds__(256) mlp_grad_reduce_kernel(Plan16 p, BwdPtrs a, int nimages) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (e < p.total)
+    for (int b = wave; b < nimages; b += 4) s += a.partial[(size_t)b * p.total + e];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0 || e >= p.total) return;
+  const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  if (v == 0.f) return;
+  int l, row, col;
+  bool is_bias;
+  unpack_index(p, e, l, row, col, is_bias);
+  if (is_bias) {
+    if (row < p.dims[l + 1]) a.db[l][row] += v;
+  } else if (row < p.dims[l + 1] && col < p.dims[l]) {
+    a.dW[l][(int64_t)row * p.dims[l] + col] += v;
+  }
+}
+
+// Stream-ordered scratch for the workgroup images; NULL (-> atomics) while the stream is being captured or when the
+// allocation fails.
+static float* grad_scratch_alloc(size_t floats, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  static bool pool_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !pool_set[dev]) {
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+      uint64_t keep = ~(uint64_t)0;  // keep freed blocks in the pool: the same size is asked for every step
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    pool_set[dev] = true;
+  }
+  void* ptr = nullptr;
+  if (hipMallocAsync(&ptr, floats * sizeof(float), st) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return (float*)ptr;
+}
+
+static void grad_scratch_reduce_and_free(const Plan16& p, const BwdPtrs& a, int nimages, hipStream_t st) {
+  if (!a.partial) return;
+  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((unsigned)((p.total + 63) / 64)), dim3(256), 0, st, p, a, nimages);
+  (void)hipFreeAsync(a.partial, st);
+}
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -607,18 +686,7 @@ __global__ void __launch_bounds__(NW * 64)
     acco.flush_chain(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < p.total; e += NW * 64) {
-    const float v = ACC[e];
-    if (v == 0.f) continue;
-    int l, row, col;
-    bool is_bias;
-    unpack_index(p, e, l, row, col, is_bias);
-    if (is_bias) {
-      if (row < p.dims[l + 1]) atomicAdd(a.db[l] + row, v);
-    } else if (row < p.dims[l + 1] && col < p.dims[l]) {
-      atomicAdd(a.dW[l] + (int64_t)row * p.dims[l] + col, v);
-    }
-  }
+  flush_image<NW * 64>(p, a, ACC);
 }
 
 // ======================================================================================================
@@ -973,18 +1041,7 @@ __global__ void __launch_bounds__(BW * 64)
     acco.flush_chain(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c);  // its bias partials are zero (add_nb only)
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < p.total; e += BW * 64) {
-    const float v = ACC[e];
-    if (v == 0.f) continue;
-    int l, row, col;
-    bool is_bias;
-    unpack_index(p, e, l, row, col, is_bias);
-    if (is_bias) {
-      if (row < p.dims[l + 1]) atomicAdd(a.db[l] + row, v);
-    } else if (row < p.dims[l + 1] && col < p.dims[l]) {
-      atomicAdd(a.dW[l] + (int64_t)row * p.dims[l] + col, v);
-    }
-  }
+  flush_image<BW * 64>(p, a, ACC);
 }
 
 template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
@@ -1000,7 +1057,10 @@ int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, c
   auto kern = mlp_dbl_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, V, dY, dX2, a);
+  BwdPtrs ap = a;
+  ap.partial = grad_scratch_alloc((size_t)blocks * p.total, st);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, V, dY, dX2, ap);
+  grad_scratch_reduce_and_free(p, ap, (int)blocks, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1033,13 +1093,16 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
     auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, DX, true, NW>;                                    \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
     if (e != hipSuccess) return (int)e;                                                                            \
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), shmem, st, p, N, X, dY, dX, a);                  \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), shmem, st, p, N, X, dY, dX, ap);                 \
   } while (0)
+  BwdPtrs ap = a;
+  ap.partial = grad_scratch_alloc((size_t)blocks * p.total, st);
   if (dX)
     GO(true);
   else
     GO(false);
 #undef GO
+  grad_scratch_reduce_and_free(p, ap, (int)blocks, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1061,6 +1124,7 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   if (N < 0 || !X || !weights || !biases || !dY || ((dW == nullptr) != (db == nullptr))) return PSDF_ERR_ARG;
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
   BwdPtrs a;
+  a.partial = nullptr;
   for (int l = 0; l < MAXL; l++) {
     a.W[l] = l < n_layers ? weights[l] : nullptr;
     a.b[l] = l < n_layers ? biases[l] : nullptr;
@@ -1103,6 +1167,7 @@ int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const flo
   if (N == 0) return PSDF_OK;
   if (N < 0 || !X || !weights || !biases || !dY || !V || !dX2 || !dW || !db) return PSDF_ERR_ARG;
   BwdPtrs a;
+  a.partial = nullptr;
   for (int l = 0; l < MAXL; l++) {
     a.W[l] = l < n_layers ? weights[l] : nullptr;
     a.b[l] = l < n_layers ? biases[l] : nullptr;
