@@ -51,7 +51,10 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
 /* replaces: torch.nn.Sequential(Linear,GELU,...) evaluators, permuto_sdf_py/models/models.py:153-161,451-470 */
 int64_t psdf_mlp_packed_size(int n_layers, const int* dims);
 
-/* replaces: same evaluators (parameter re-ordering for the MFMA kernels) */
+/* replaces: same evaluators (parameter re-ordering for the MFMA kernels).  `packed` holds psdf_mlp_packed_size floats:
+   the fp32 operand image and, for nets whose image fits 80 KB of LDS, a second image of the same parameters as three
+   bf16 pieces per weight (16-byte aligned, after the first) that psdf_mlp_forward multiplies on the bf16 matrix pipe
+   with six products kept per fp32 multiply (fp32-level accuracy; no range restriction on inputs or weights). */
 int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, const float* const* biases, float*
     packed, void* stream);
 

@@ -176,7 +176,7 @@ __device__ __forceinline__ void dense_chain(const f32x16 (&in)[TI], f32x16 (&out
 // fp32 MFMAs and VALU work do not overlap on gfx950 (their times add), bf16 MFMAs do and are 16x faster per k
 // (tools/mfma_valu_overlap.hip, profiles/r01_mfma_valu_overlap.txt).  So the forward evaluator multiplies fp32
 // operands as three bf16 pieces each, a = a1 + a2 + a3 (8 mantissa bits per piece, by truncation, so the sum is
-// exact), and keeps the six products down to 2^-16 relative size:
+// exact for |a| >= 2^-100 and within 2^-132 below: tests/test_split_bf16_numerics.py), and keeps the six products down to 2^-16 relative size:
 //     a b ~= a3 b1 + a2 b2 + a1 b3 + a2 b1 + a1 b2 + a1 b1          (error ~2^-22 |a b|, fp32 accumulation)
 // on v_mfma_f32_32x32x16_bf16: 6/16 of the fp32 matrix time, hidden under the GELU.  Same chained-register design:
 // D tile of layer l = B operand of layer l+1.  Lane (sample n = lane & 31, half h = lane >> 5) supplies, for k-step s
