@@ -26,3 +26,9 @@ for _ in range(10):
 e.record()
 torch.cuda.synchronize()
 print("mlp_bwd %s: %.3f ms" % (dims, s.elapsed_time(e) / 10))
+s.record()
+for _ in range(10):
+    mlp_backward_raw(dims, x, ws, bs, gy, need_dx=True, need_dw=False)
+e.record()
+torch.cuda.synchronize()
+print("mlp_bwd %s, data gradient only: %.3f ms" % (dims, s.elapsed_time(e) / 10))
