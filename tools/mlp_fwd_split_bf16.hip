@@ -49,7 +49,25 @@ __device__ __forceinline__ float erf_fast(float a) {
   const float lo = fmaf(q, a, a);
   return t > 0.927734375f ? hi : lo;
 }
+#ifdef GELU_EXP2_POLY
+// gelu(x) = max(x, 0) - t Phi(-t), t = min(|x|, 5.75), Phi(-t) = exp2(P8(t)): 12 instructions; fit and error report in
+// tools/gelu_fit.py (max error / |x| 8.6e-8 against float64, the fp32 erf formula itself has 1.06e-7)
+__device__ __forceinline__ float gelu(float x) {
+  const float t = fminf(fabsf(x), 5.75f);
+  float p = -2.772052994e-06f;
+  p = fmaf(p, t, 3.862077210e-05f);
+  p = fmaf(p, t, -1.825476502e-04f);
+  p = fmaf(p, t, -1.458701736e-04f);
+  p = fmaf(p, t, 7.075471804e-03f);
+  p = fmaf(p, t, -5.250502750e-02f);
+  p = fmaf(p, t, -4.592049122e-01f);
+  p = fmaf(p, t, -1.151105762e+00f);
+  p = fmaf(p, t, -1.000000000e+00f);
+  return fmaf(-t, __builtin_amdgcn_exp2f(p), fmaxf(x, 0.f));
+}
+#else
 __device__ __forceinline__ float gelu(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+#endif
 
 // eight fp32 -> three bf16x8 pieces by truncation (each piece = the top 16 bits of the running remainder)
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
