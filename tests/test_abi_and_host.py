@@ -49,6 +49,48 @@ def test_argument_errors_and_empty_inputs_without_gpu(lib):
                                ctypes.c_float(.99), ctypes.c_float(1e-15), ctypes.c_float(0), 1, ctypes.c_float(1), None) == -1
 
 
+def _packed_floats(dims):
+    """Python restatement of make_plan + make_split_plan (csrc/mlp_device.h): size of the packed parameter buffer"""
+    nl = len(dims) - 1
+    tiles = [(d + 31) // 32 for d in dims]
+    final_dot = dims[-1] <= 4
+    off = 0
+    for l in range(nl):
+        last = l == nl - 1
+        if l == 0:
+            off += tiles[1] * ((dims[0] + 1) // 2) * 65
+        elif last and final_dot:
+            off += dims[nl] * tiles[l] * 32
+        else:
+            off += tiles[l + 1] * tiles[l] * 16 * 64
+        off += 4 if (last and final_dot) else tiles[l + 1] * 32
+    fp32_total = off
+    rec, tail = 0, 0
+    for l in range(nl):
+        dot = (l == nl - 1) and final_dot
+        ns = (dims[0] + 15) // 16 if l == 0 else 2 * tiles[l]
+        if dot:
+            tail += dims[nl] * tiles[l] * 32 + 4
+        else:
+            rec += tiles[l + 1] * ns * 3 * 64
+            tail += tiles[l + 1] * 32
+    total_rec = rec + (tail + 3) // 4
+    fits = nl in (3, 4) and total_rec * 16 <= 80 * 1024
+    return fp32_total, (((fp32_total + 3) & ~3) + total_rec * 4) if fits else fp32_total
+
+
+def test_packed_buffer_holds_the_split_bf16_image_only_when_it_fits(lib):
+    """psdf_mlp_packed_size = fp32 operand image (+ 16-byte aligned split-bf16 image when that fits 80 KB of LDS)"""
+    lib.psdf_mlp_packed_size.restype = ctypes.c_int64
+    for dims, split in [((36, 64, 64, 64, 1), True), ((52, 64, 64, 64, 1), True), ((52, 32, 32, 32, 33), True),
+                        ((80, 64, 64, 3), True), ((52, 64, 64, 64, 65), False), ((52, 64, 64, 64, 33), False),
+                        ((51, 128, 128, 64, 3), False), ((36, 64, 1), False)]:
+        fp32_total, want = _packed_floats(list(dims))
+        got = lib.psdf_mlp_packed_size(len(dims) - 1, (ctypes.c_int * len(dims))(*dims))
+        assert got == want, (dims, got, want)
+        assert (got > fp32_total) == split, dims
+
+
 def test_pcg32_host_copy_matches_oracle():
     from oracle import oracle as O
     from permuto_sdf_amd.bridge import Pcg32
