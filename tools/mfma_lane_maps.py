@@ -6,7 +6,9 @@ Checks (all exact):
   1. chaining: the D tile of one product is the B operand of the next when k-step s' of a tile takes registers 8 s' .. + 7
      and the A operand is permuted to k <-> row_of(8 s' + j, hh);
   2. transpose by a 0/1 operand: D = H I puts feature f of sample row_of(r, h) in register r of lane (f, h);
-  3. dW from two such feature-lane tiles, k-step ks = registers 8 ks .. + 7 of both.
+  3. dW from two such feature-lane tiles, k-step ks = registers 8 ks .. + 7 of both;
+  4. the same 0/1-operand product applied to a forward WEIGHT tile yields the A operand of the dH chain (lane = input
+     row, k-step s' = output neurons row_of(8 s' + j, hh)): transposed weight images need not be stored.
 usage: python tools/mfma_lane_maps.py"""
 import numpy as np
 
@@ -88,7 +90,24 @@ def main():
         for r in range(16):
             want[lane, r] = ref[row_of(r, h), fi]
     assert np.array_equal(acc, want), "dW"
-    print("lane-map checks passed: chaining, transpose by 0/1 operand, dW from feature-lane tiles")
+    # 4. transposed weight tile from the forward A operands: dH^T = W^T dZ^T with A taken from registers 8 s' .. of D = W_A I
+    W, dZ = rng.integers(-3, 4, (32, 32)).astype(float), rng.integers(-3, 4, (32, 32)).astype(float)  # W[out][in], dZ[out][sample]
+    wt = np.zeros((64, 16))
+    for sp in range(2):
+        A = np.zeros((64, 8))
+        ident = np.zeros((64, 8))
+        for lane in range(64):
+            m, hh = lane & 31, lane >> 5
+            for j in range(8):
+                A[lane, j] = W[m, row_of(8 * sp + j, hh)]                      # forward image, k-step sp
+                ident[lane, j] = 1.0 if m == row_of(8 * sp + j, hh) else 0.0
+        wt = mfma_32x32x16(A, ident, wt)                                       # lane = input neuron, registers = outputs
+    t = d_layout(dZ)
+    acc = np.zeros((64, 16))
+    for sp in range(2):
+        acc = mfma_32x32x16(wt[:, 8 * sp:8 * sp + 8], t[:, 8 * sp:8 * sp + 8], acc)
+    assert np.array_equal(acc, d_layout(W.T @ dZ)), "weight transpose"
+    print("lane-map checks passed: chaining, transpose by 0/1 operand, dW from feature-lane tiles, transposed weights")
 
 
 if __name__ == "__main__":
