@@ -9,7 +9,10 @@
 // k-step (one per 16-feature tile); a feature-lane tile holds samples 4 g + r, which fill k-slots (g, 0..3) of a dW operand.
 // The tile loop is emulated lane by lane in numpy (tools/emulate_bwd_v3.py: all nine gradients match float64 to 4e-7).
 // *** NOT YET RUN ON THE GPU (the round's GPU budget was spent): treat every number it prints as unverified. ***
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/mlp_bwd_split_bf16_v3.hip -o tools/mlp_bwd_split_bf16_v3
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 tools/mlp_bwd_split_bf16_v3.hip \
+//         -o tools/mlp_bwd_split_bf16_v3
+// (by default every MFMA writes AGPRs and each chain / transpose result is copied out with v_accvgpr_read: 948 copies and
+//  80 spilled dwords per tile; with the VGPR form allowed the compiler keeps only accumulators in AGPRs: 583 and 24)
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
