@@ -56,6 +56,14 @@ def rank_seed(base_seed, rank):
     return int(base_seed) * 1000003 + int(rank) + 1
 
 
+def step_seed(base_seed, rank, iteration, world=None):
+    """Seed of (rank, iteration): injective in both (`rank_seed + iteration` made rank r+1 at step t-1 replay
+    rank r's batch of step t).  Iterations are spaced `world` apart and the rank fills the gap."""
+    world = world_size() if world is None else int(world)
+    assert 0 <= int(rank) < world
+    return (int(base_seed) * 1000003 + int(iteration)) * world + int(rank)
+
+
 class GradientBuckets:
     """Async sum all-reduce of gradient tensors, bucket by bucket; `finish()` waits for all of them."""
 

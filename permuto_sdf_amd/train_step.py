@@ -251,7 +251,7 @@ class Trainer:
         self.iter = 0
         self.last = {}
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
-        self._rank_seed = parallel.rank_seed(seed + 1, parallel.rank())
+        self._seed = seed + 1
 
     # ---- checkpoints in the reference's file layout (permuto_sdf_utils.py:222-237)
     def save_checkpoint(self, folder):
@@ -264,13 +264,13 @@ class Trainer:
 
     # ---- sampling (no grad): nerf_utils.py:502-525 + sdf_utils.py:383-423
     @torch.no_grad()
-    def _samples(self, o, d, it):
+    def _samples(self, o, d, it, jitter=True):
         hp = self.hp
         _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
         fg = self.grid.compute_samples_in_occupied_regions(o, d, te, tx, hp.min_dist_between_samples,
-                                                           hp.max_nr_samples_per_ray, True).compact_to_valid_samples()
+                                                           hp.max_nr_samples_per_ray, jitter).compact_to_valid_samples()
         bg = RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius, self.sphere.m_center_tensor,
-                                           True, False)
+                                           jitter, False)
         if fg.samples_pos.shape[0] == 0:
             return fg, bg
         fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it))
@@ -280,7 +280,7 @@ class Trainer:
             w = alpha * T
             _, per_sample = VolumeRendering.sum_over_each_ray(fg, w)
             cdf = VolumeRendering.compute_cdf(fg, w / torch.clamp(per_sample, min=1e-6))
-            imp = VolumeRendering.importance_sample(o, d, fg, cdf, hp.nr_samples_imp_sampling, True)
+            imp = VolumeRendering.importance_sample(o, d, fg, cdf, hp.nr_samples_imp_sampling, jitter)
             if rnd == 0:
                 imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it))
             else:
@@ -289,8 +289,9 @@ class Trainer:
         return fg, bg
 
     # ---- run_net: train_permuto_sdf.py:111-169
-    def _render(self, o, d, it, cos_anneal_ratio, forced_variance):
-        fg, bg = self._samples(o, d, it)
+    def _render(self, o, d, it, cos_anneal_ratio, forced_variance, jitter=True):
+        """`jitter` = the reference's `model.training` flag (nerf_utils.py:507, sdf_utils.py:401): False in eval mode"""
+        fg, bg = self._samples(o, d, it, jitter)
         R = o.shape[0]
         if fg.samples_pos.shape[0] == 0:
             pred = torch.zeros(R, 3, device=self.dev)
@@ -307,7 +308,7 @@ class Trainer:
     def step(self, reel):
         """one optimisation step; returns the loss (device tensor, no sync)"""
         hp, it = self.hp, self.iter
-        torch.manual_seed(self._rank_seed + it)  # this rank's rays / jitter
+        torch.manual_seed(parallel.step_seed(self._seed, parallel.rank(), it))  # this rank's rays / jitter
         cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
         forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
         with torch.no_grad():

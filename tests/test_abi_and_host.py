@@ -176,3 +176,11 @@ def test_ray_sharding_helpers():
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
     assert len({parallel.rank_seed(7, r) for r in range(8)}) == 8
+
+
+def test_step_seeds_are_injective_in_rank_and_iteration():
+    """seeds must differ for every (rank, iteration) pair, or neighbouring ranks replay each other's ray batches"""
+    from permuto_sdf_amd import parallel
+    for world in (1, 2, 8):
+        seeds = {parallel.step_seed(5, r, it, world) for r in range(world) for it in range(64)}
+        assert len(seeds) == world * 64
