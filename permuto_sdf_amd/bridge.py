@@ -94,12 +94,21 @@ class RaySamplesPacked:
             self.ray_fixed_dt = torch.empty((R, 1), **f)
             self.ray_start_end_idx = torch.empty((R, 2), dtype=torch.int32, device=dev)
 
+    def __setattr__(self, name, value):
+        """Python may overwrite any attribute (the reference does: sdf_utils.py:216 assigns samples_pos).  A container whose
+        ray ranges or sample count were re-assigned from outside is no longer known to be densely packed: the `_exact`
+        shortcut of compact_to_valid_samples / compute_exact_nr_samples is dropped and the generic path recounts.
+        Producers set `_exact = True` AFTER filling the container."""
+        if name in ("ray_start_end_idx", "cur_nr_samples"):
+            object.__setattr__(self, "_exact", False)
+        object.__setattr__(self, name, value)
+
     # -- ray-index arguments shared by every per-ray kernel
     def _ri(self):
         se = self.ray_start_end_idx
         if se.dtype != torch.int32 or not se.is_contiguous():
             se = se.to(torch.int32).contiguous()
-            self.ray_start_end_idx = se
+            object.__setattr__(self, "ray_start_end_idx", se)   # same values: packing knowledge is unchanged
         return (L.c_i(se.shape[0]), L.ptr(se), L.c_i(int(self.rays_have_equal_nr_of_samples)),
                 L.c_i(int(self.fixed_nr_of_samples_per_ray)), L.c_i(int(self.max_nr_samples)))
 

@@ -62,12 +62,55 @@ __device__ __forceinline__ float erf_fast(float a) {
   return t > 0.927734375f ? hi : lo;
 }
 // gelu and its derivative Phi(z) + z phi(z) from one erf and one exp
+#if !defined(GELU_EXP2_POLY)
 __device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
   const float cdf = fmaf(0.5f, erf_fast(z * 0.70710678118654752440f), 0.5f);
   const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
   hval = z * cdf;
   gprime = fmaf(z, pdf, cdf);
 }
+#else
+// tools/gelu_fit.py: e = Phi(-t) = exp2(P8(t)), t = min(|z|, 5.75); gelu = max(z, 0) - t e; gelu' = (z < 0 ? e : 1 - e) + zc phi(t)
+__device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
+  const float t = fminf(fabsf(z), 5.75f);
+  float p = -2.772052994e-06f;
+  p = fmaf(p, t, 3.862077210e-05f);
+  p = fmaf(p, t, -1.825476502e-04f);
+  p = fmaf(p, t, -1.458701736e-04f);
+  p = fmaf(p, t, 7.075471804e-03f);
+  p = fmaf(p, t, -5.250502750e-02f);
+  p = fmaf(p, t, -4.592049122e-01f);
+  p = fmaf(p, t, -1.151105762e+00f);
+  p = fmaf(p, t, -1.000000000e+00f);
+  const float e = __builtin_amdgcn_exp2f(p);
+  hval = fmaf(-t, e, fmaxf(z, 0.f));
+  const float cdf = z < 0.f ? e : 1.0f - e;
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(t * t * -0.72134752044448170368f);
+  gprime = fmaf(copysignf(t, z), pdf, cdf);
+}
+#endif
+#if defined(GELU_PACKED)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void gelu_both2(f32x2 z, f32x2& hval, f32x2& gprime) {
+  const f32x2 t = {fminf(fabsf(z.x), 5.75f), fminf(fabsf(z.y), 5.75f)};
+  f32x2 p = {-2.772052994e-06f, -2.772052994e-06f};
+  p = pkfma(p, t, f32x2{3.862077210e-05f, 3.862077210e-05f});
+  p = pkfma(p, t, f32x2{-1.825476502e-04f, -1.825476502e-04f});
+  p = pkfma(p, t, f32x2{-1.458701736e-04f, -1.458701736e-04f});
+  p = pkfma(p, t, f32x2{7.075471804e-03f, 7.075471804e-03f});
+  p = pkfma(p, t, f32x2{-5.250502750e-02f, -5.250502750e-02f});
+  p = pkfma(p, t, f32x2{-4.592049122e-01f, -4.592049122e-01f});
+  p = pkfma(p, t, f32x2{-1.151105762e+00f, -1.151105762e+00f});
+  p = pkfma(p, t, f32x2{-1.000000000e+00f, -1.000000000e+00f});
+  const f32x2 e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+  hval = pkfma(-t, e, f32x2{fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)});
+  const f32x2 cdf = {z.x < 0.f ? e.x : 1.0f - e.x, z.y < 0.f ? e.y : 1.0f - e.y};
+  const f32x2 q = t * t * f32x2{-0.72134752044448170368f, -0.72134752044448170368f};
+  const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)} * f32x2{0.3989422804014327f, 0.3989422804014327f};
+  gprime = pkfma(f32x2{copysignf(t.x, z.x), copysignf(t.y, z.y)}, pdf, cdf);
+}
+#endif
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -197,7 +240,16 @@ __device__ __forceinline__ void zero_init(f32x4 (&acc)[NTILE]) {
 // in place: acc <- gelu(acc), gp <- gelu'(acc)
 __device__ __forceinline__ void act_both(f32x4 (&acc)[NT], f32x4 (&gp)[NT]) {
 #pragma unroll
-  for (int t = 0; t < NT; t++)
+  for (int t = 0; t < NT; t++) {
+#if defined(GELU_PACKED)
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      f32x2 hv, d;
+      gelu_both2(f32x2{acc[t][r], acc[t][r + 1]}, hv, d);
+      acc[t][r] = hv.x; acc[t][r + 1] = hv.y;
+      gp[t][r] = d.x; gp[t][r + 1] = d.y;
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float hv, d;
@@ -205,6 +257,8 @@ __device__ __forceinline__ void act_both(f32x4 (&acc)[NT], f32x4 (&gp)[NT]) {
       acc[t][r] = hv;
       gp[t][r] = d;
     }
+#endif
+  }
 }
 // chain layer over the two k-steps of `in`; per_step(s, pieces) sees the operand pieces of each k-step
 template <int NTILE, typename F>

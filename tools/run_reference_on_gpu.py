@@ -167,7 +167,8 @@ def main():
     num = (pred2.detach() - pred_rgb.detach()).abs()
     log["run_net_vs_trainer_render"] = {
         "max_abs": float(num.max()), "max_rel_to_max": float(num.max() / pred_rgb.abs().max()),
-        "mean_abs": float(num.mean()), "fg_samples_reference_python": int(fg.samples_pos.shape[0]),
+        "mean_abs": float(num.mean()), "quantile_0.9999_abs": float(torch.quantile(num.view(-1), 0.9999)),
+        "values_above_1e-4": int((num > 1e-4).sum()), "values": int(num.numel()), "fg_samples_reference_python": int(fg.samples_pos.shape[0]),
         "fg_samples_trainer": int(fg2.samples_pos.shape[0]),
         "same_sample_count": int(fg.samples_pos.shape[0]) == int(fg2.samples_pos.shape[0])}
     print("[run_net vs Trainer._render]", log["run_net_vs_trainer_render"], flush=True)
