@@ -23,6 +23,14 @@ extern "C" {
 #endif
 
 /* ---- encode.hip ---- */
+/* The frozen conventions of the encoding (upstream source absent, PARITY UNPINNED) are the #defines of
+   permuto_sdf_amd/csrc/encode_conventions.h; `concat_points` below is one of PSDF_ENC_CONCAT_NONE (0),
+   PSDF_ENC_CONCAT_PSEUDO_LEVELS (1: F*(L + ceil(P/F)) channels, zero padded) or PSDF_ENC_CONCAT_APPEND (2: F*L + P channels,
+   `cat([sliced, scaling * points])`, what permuto_sdf_py/models/models.py:149,154 consumes through output_dims()).
+   psdf_encode_convention(i) returns the compiled-in value of convention i (0 hash multiplier, 1 rank tie rule, 2 sqrt term
+   of scale_factor, 3 inverse-std-dev term, 4 default concatenation layout); host only. */
+int64_t psdf_encode_convention(int which);
+
 /* replaces: permutohedral_encoding CUDA op `forward_gpu` (un-vendored; call sites permuto_sdf_py/models/models.py:186,370,500,542) */
 int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
     const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,

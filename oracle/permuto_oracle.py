@@ -17,7 +17,13 @@ sites force (``permuto_sdf_py/models/models.py:143-149,186,408-420``) and freeze
 * rank tie-break: ``E_i - rem0_i <  E_j - rem0_j`` -> ``rank[i]++`` else ``rank[j]++``
 * hash: ``h = 0; for i < P: h += (uint32) key[i]; h *= 2531011``; ``idx = h % T``
 * output channel order ``[N, l*F + f]``; when ``concat_points`` the scaled points are appended as
-  ``ceil(P/F)`` extra pseudo-levels, zero padded (so P=3,F=2 gives 4 extra channels, the last one 0).
+  ``ceil(P/F)`` extra pseudo-levels, zero padded (so P=3,F=2 gives 4 extra channels, the last one 0) -- layout 1 --
+  or as exactly P channels (SURVEY.md App. A.3 ``cat([sliced, scaling*points])``, 51 channels) -- layout 2.
+
+The VALUES of these conventions are not written in this file: they are parsed from the one header the HIP kernels
+include, ``permuto_sdf_amd/csrc/encode_conventions.h`` (a data file: nothing of the product is imported or executed),
+so that a change of convention there is followed by kernels, host code and oracle together
+(``tests/test_encoding_conventions.py``).  ``CONV`` may be replaced by a test to evaluate a flipped convention.
 
 All float arithmetic is fp32 with one rounding per operation (no FMA contraction) in the order written
 below; the HIP kernels are compiled contraction-free for the same expressions, so forward parity is
@@ -33,8 +39,38 @@ import math
 import numpy as np
 import torch
 
-HASH_MULT = 2531011
+import os
+import re
+
 U32 = 0xFFFFFFFF
+CONVENTIONS_HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "permuto_sdf_amd", "csrc",
+                                  "encode_conventions.h")
+
+
+def parse_conventions(path=CONVENTIONS_HEADER):
+    out = {}
+    for m in re.finditer(r"^#define\s+(PSDF_ENC_[A-Z0-9_]+)\s+([-+0-9.eE]+)\s*$", open(path).read(), re.M):
+        v = m.group(2)
+        out[m.group(1)] = float(v) if any(ch in v for ch in ".eE") else int(v)
+    return out
+
+
+CONV = parse_conventions()
+
+
+def _hash_mult():
+    return int(CONV["PSDF_ENC_HASH_MULTIPLIER"])
+
+
+def _tie_later():
+    return bool(CONV["PSDF_ENC_RANK_TIE_RAISES_LATER"])
+
+
+def concat_layout(concat_points, layout=None):
+    """-> 0 none, 1 padded pseudo-levels, 2 exactly P appended channels"""
+    if not concat_points:
+        return 0
+    return int(CONV["PSDF_ENC_CONCAT_DEFAULT_LAYOUT"]) if layout is None else int(layout)
 
 
 def scale_factors(scale_list, pos_dim):
@@ -42,7 +78,10 @@ def scale_factors(scale_list, pos_dim):
     scale_list = np.asarray(scale_list, dtype=np.float64)
     sf = np.empty((len(scale_list), pos_dim), dtype=np.float64)
     for i in range(pos_dim):
-        sf[:, i] = 1.0 / (math.sqrt((i + 1) * (i + 2)) * scale_list)
+        term = math.sqrt((i + 1) * (i + 2)) if CONV["PSDF_ENC_SCALE_SQRT_TERM"] else 1.0
+        if CONV["PSDF_ENC_SCALE_INV_STDDEV"]:
+            term /= (pos_dim + 1) * math.sqrt(2.0 / 3.0)
+        sf[:, i] = 1.0 / (term * scale_list)
     return torch.from_numpy(sf.astype(np.float32))
 
 
@@ -50,8 +89,13 @@ def nr_extra_levels(pos_dim, nr_feat, concat_points):
     return int(math.ceil(pos_dim / nr_feat)) if concat_points else 0
 
 
-def output_dims(pos_dim, nr_levels, nr_feat, concat_points):
-    return nr_feat * (nr_levels + nr_extra_levels(pos_dim, nr_feat, concat_points))
+def nr_point_channels(pos_dim, nr_feat, concat_points, layout=None):
+    mode = concat_layout(concat_points, layout)
+    return {0: 0, 1: nr_feat * nr_extra_levels(pos_dim, nr_feat, True), 2: pos_dim}[mode]
+
+
+def output_dims(pos_dim, nr_levels, nr_feat, concat_points, layout=None):
+    return nr_feat * nr_levels + nr_point_channels(pos_dim, nr_feat, concat_points, layout)
 
 
 def coarse2fine_window(t, nr_levels):
@@ -97,7 +141,8 @@ def simplex_scalar(pos, shift, sf):
     for i in range(P):
         di = _f32(E[i] - _f32(rem0[i]))
         for j in range(i + 1, P + 1):
-            if di < _f32(E[j] - _f32(rem0[j])):
+            dj = _f32(E[j] - _f32(rem0[j]))
+            if (di < dj) if _tie_later() else (di <= dj):
                 rank[i] += 1
             else:
                 rank[j] += 1
@@ -125,11 +170,11 @@ def vertex_index_scalar(rem0, rank, remainder, P, capacity):
         if rank[i] > P - remainder:
             k -= P + 1
         h = (h + (k & U32)) & U32
-        h = (h * HASH_MULT) & U32
+        h = (h * _hash_mult()) & U32
     return h % capacity
 
 
-def encode_scalar(points, lattice_values, scale_list, shifts, window, concat_points=False, points_scaling=1.0):
+def encode_scalar(points, lattice_values, scale_list, shifts, window, concat_points=False, points_scaling=1.0, layout=None):
     """Pure-Python loop, literal restatement of SURVEY.md App. A.3.  O(N*L) Python: keep N small."""
     pts = points.detach().cpu().numpy().astype(np.float32)
     lat = lattice_values.detach().cpu().numpy().astype(np.float32)
@@ -139,7 +184,8 @@ def encode_scalar(points, lattice_values, scale_list, shifts, window, concat_poi
     sh = shifts.detach().cpu().numpy().astype(np.float32)
     win = window.detach().cpu().numpy().astype(np.float32)
     extra = nr_extra_levels(P, F, concat_points)
-    out = np.zeros((N, (L + extra) * F), dtype=np.float32)
+    C = output_dims(P, L, F, concat_points, layout)
+    out = np.zeros((N, C), dtype=np.float32)
     for n in range(N):
         for l in range(L):
             rem0, rank, bary, _ = simplex_scalar(pts[n], sh[l], sf[l])
@@ -154,7 +200,8 @@ def encode_scalar(points, lattice_values, scale_list, shifts, window, concat_poi
         for e in range(extra):
             for f in range(F):
                 d = e * F + f
-                out[n, (L + e) * F + f] = _f32(pts[n, d] * _f32(points_scaling)) if d < P else 0.0
+                if L * F + d < C:       # channels beyond P exist only in the padded layout
+                    out[n, L * F + d] = _f32(pts[n, d] * _f32(points_scaling)) if d < P else 0.0
     return torch.from_numpy(out)
 
 
@@ -186,7 +233,7 @@ def simplex(points, shift, sf):
         rank = torch.zeros(N, P + 1, dtype=torch.int64)
         for i in range(P):
             for j in range(i + 1, P + 1):
-                lt = d[:, i] < d[:, j]
+                lt = (d[:, i] < d[:, j]) if _tie_later() else (d[:, i] <= d[:, j])
                 rank[:, i] += lt
                 rank[:, j] += ~lt
         rank = rank + s[:, None]
@@ -218,12 +265,12 @@ def vertex_indices(rem0, rank, capacity):
         for i in range(P):
             k = rem0[:, i] + r - (rank[:, i] > (P - r)).to(torch.int64) * (P + 1)
             h = (h + (k & U32)) & U32
-            h = (h * HASH_MULT) & U32
+            h = (h * _hash_mult()) & U32
         idx.append(h % capacity)
     return torch.stack(idx, dim=1)
 
 
-def encode(points, lattice_values, scale_list, shifts, window, concat_points=False, points_scaling=1.0):
+def encode(points, lattice_values, scale_list, shifts, window, concat_points=False, points_scaling=1.0, layout=None):
     """points [N,P], lattice_values [L,T,F], shifts [L,P], window [L]  ->  [N, F*(L+extra)].
     Differentiable wrt points and lattice_values (rank / rem0 are piecewise constant)."""
     N, P = points.shape
@@ -239,19 +286,21 @@ def encode(points, lattice_values, scale_list, shifts, window, concat_points=Fal
             bw = bary[:, r] * window[l]
             acc = acc + fv * bw[:, None]
         outs.append(acc)
-    extra = nr_extra_levels(P, F, concat_points)
-    if extra:
-        pad = torch.zeros(N, extra * F - P, dtype=points.dtype)
+    npc = nr_point_channels(P, F, concat_points, layout)
+    if npc:
+        pad = torch.zeros(N, npc - P, dtype=points.dtype)
         outs.append(torch.cat([points * float(points_scaling), pad], dim=1))
     return torch.cat(outs, dim=1)
 
 
-def make_params(pos_dim, capacity, nr_levels, nr_feat, seed=0, init_scale=1e-5, random_shift=True):
+def make_params(pos_dim, capacity, nr_levels, nr_feat, seed=0, init_scale=None, random_shift=True):
     """Seeded parameter construction following SURVEY.md App. A.2."""
+    if init_scale is None:
+        init_scale = CONV["PSDF_ENC_LATTICE_INIT_SCALE"]
     g = torch.Generator().manual_seed(seed)
     lattice = (torch.randn(capacity, nr_levels, nr_feat, generator=g) * init_scale).permute(1, 0, 2).contiguous()
     if random_shift:
-        shifts = torch.randn(nr_levels, pos_dim, generator=g) * 10
+        shifts = torch.randn(nr_levels, pos_dim, generator=g) * CONV["PSDF_ENC_RANDOM_SHIFT_SCALE"]
     else:
         shifts = torch.zeros(nr_levels, pos_dim)
     return lattice, shifts

@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_fwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
-                      const unsigned char* __restrict__ skip, float* __restrict__ sliced) {
+                      int pad_points, const unsigned char* __restrict__ skip, float* __restrict__ sliced) {
   const int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (n >= N) return;
   if (skip && skip[n]) return;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 #pragma unroll
       for (int i = 0; i < P; i++)
         if (i == d) v = pos[i] * points_scaling;
-      sliced[((int64_t)level * F + f) * N + n] = v;
+      // channel L*F + d; d >= P exists only in the zero-padded pseudo-level layout (encode_conventions.h)
+      if (d < P || pad_points) sliced[((int64_t)level * F + f) * N + n] = v;
     }
     return;
   }
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, const float* __restrict__ positions,
                           const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                           const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
-                          const float* __restrict__ grad_sliced, float* __restrict__ grad_positions) {
+                          int pad_points, const float* __restrict__ grad_sliced, float* __restrict__ grad_positions) {
   const int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (n >= N) return;
   float pos[P];
@@ -531,7 +532,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     if (level >= Lt) break;
     float g[F];
 #pragma unroll
-    for (int f = 0; f < F; f++) g[f] = grad_sliced[((int64_t)level * F + f) * N + n];
+    for (int f = 0; f < F; f++)   // rows beyond L*F + P exist only in the padded layout
+      g[f] = (level < L || (level - L) * F + f < P || pad_points) ? grad_sliced[((int64_t)level * F + f) * N + n] : 0.f;
     if (level >= L) {  // pseudo-levels: the concatenated, scaled point
       const int e = level - L;
 #pragma unroll
@@ -653,7 +655,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_dbl_bwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
                           const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                           const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
-                          const float* __restrict__ dd_positions, const float* __restrict__ grad_sliced,
+                          int pad_points, const float* __restrict__ dd_positions, const float* __restrict__ grad_sliced,
                           float* __restrict__ grad_lattice, float* __restrict__ grad_grad_sliced) {
   extern __shared__ __align__(16) float lds[];
   const int level = blockIdx.y;
@@ -672,7 +674,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 #pragma unroll
         for (int i = 0; i < P; i++)
           if (i == d) v = u[i] * points_scaling;
-        grad_grad_sliced[((int64_t)level * F + f) * N + n] = v;
+        if (d < P || pad_points) grad_grad_sliced[((int64_t)level * F + f) * N + n] = v;
       }
     }
     return;
@@ -761,25 +763,43 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   if (LATTICE) sc.flush(grad_lattice + tbase);
 }
 
+// `concat` = PSDF_ENC_CONCAT_* (encode_conventions.h): both concatenation layouts sweep ceil(P/F) pseudo-levels; the padded
+// one also owns the channels L*F + d with d >= P (zeros), the appended one does not have them.
 inline int extra_levels(int P, int F, int concat) { return concat ? (P + F - 1) / F : 0; }
+inline int pad_points(int concat) { return concat == PSDF_ENC_CONCAT_PSEUDO_LEVELS; }
+inline bool concat_ok(int concat) { return concat >= PSDF_ENC_CONCAT_NONE && concat <= PSDF_ENC_CONCAT_APPEND; }
 
 }  // namespace
 
 // ================================================================================== C ABI
 extern "C" {
 
+// The conventions this library was COMPILED with (encode_conventions.h), by index: 0 hash multiplier, 1 rank tie rule,
+// 2 sqrt term in scale_factor, 3 inverse-std-dev term, 4 default concatenation layout.  Host only (no device needed).
+int64_t psdf_encode_convention(int which) {
+  switch (which) {
+    case 0: return (int64_t)PSDF_ENC_HASH_MULTIPLIER;
+    case 1: return PSDF_ENC_RANK_TIE_RAISES_LATER;
+    case 2: return PSDF_ENC_SCALE_SQRT_TERM;
+    case 3: return PSDF_ENC_SCALE_INV_STDDEV;
+    case 4: return PSDF_ENC_CONCAT_DEFAULT_LAYOUT;
+    default: return -1;
+  }
+}
+
 static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
                                const float* lattice, const float* scale_factor, const float* shifts, const float* window,
                                int concat_points, float points_scaling, const unsigned char* skip, float* sliced,
                                void* stream) {
   if (N == 0) return PSDF_OK;
-  if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !sliced) return PSDF_ERR_ARG;
+  if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !sliced || !concat_ok(concat_points))
+    return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);
 #define FWD(P_, F_)                                                                                            \
   hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, \
-                     positions, lattice, scale_factor, shifts, window, points_scaling, skip, sliced)
+                     positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced)
   if (pos_dim == 3 && nr_feat == 2)
     FWD(3, 2);
   else if (pos_dim == 4 && nr_feat == 2)
@@ -856,7 +876,8 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
                             int concat_points, float points_scaling, const float* grad_sliced, float* grad_lattice,
                             float* grad_positions, void* workspace, int64_t workspace_bytes, void* stream) {
   if (N == 0 || (!grad_lattice && !grad_positions)) return PSDF_OK;
-  if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !grad_sliced) return PSDF_ERR_ARG;
+  if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !grad_sliced || !concat_ok(concat_points))
+    return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + ((grad_positions != nullptr) ? extra_levels(pos_dim, nr_feat, concat_points) : 0);
   const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
@@ -889,7 +910,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     else                                                                                                         \
       hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, \
                          st, N, nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, \
-                         points_scaling, grad_sliced, grad_positions);                                           \
+                         points_scaling, pad_points(concat_points), grad_sliced, grad_positions);                \
     if (use_queue) {                                                                                             \
       const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                          \
       hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                              \
@@ -932,7 +953,7 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
                                 float* grad_grad_sliced, void* stream) {
   if (N == 0) return PSDF_OK;
   if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !dd_positions || !grad_sliced ||
-      !grad_grad_sliced)
+      !grad_grad_sliced || !concat_ok(concat_points))
     return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
@@ -943,11 +964,12 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     if (grad_lattice)                                                                                            \
       hipLaunchKernelGGL((encode_dbl_bwd_kernel<P_, F_, true>), grid, dim3(PSDF_BLOCK), ScatterCache<F_>::bytes(), \
                          st, N, nr_levels, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window,   \
-                         points_scaling, dd_positions, grad_sliced, grad_lattice, grad_grad_sliced);               \
+                         points_scaling, pad_points(concat_points), dd_positions, grad_sliced, grad_lattice,       \
+                         grad_grad_sliced);                                                                        \
     else                                                                                                         \
       hipLaunchKernelGGL((encode_dbl_bwd_kernel<P_, F_, false>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels,      \
                          (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling,     \
-                         dd_positions, grad_sliced, grad_lattice, grad_grad_sliced);                               \
+                         pad_points(concat_points), dd_positions, grad_sliced, grad_lattice, grad_grad_sliced);    \
   } while (0)
   if (pos_dim == 3 && nr_feat == 2)
     DBL(3, 2);

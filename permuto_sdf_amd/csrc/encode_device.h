@@ -1,6 +1,7 @@
 // Device-side simplex location / hashing of the permutohedral encoding (shared by encode.hip and fused.hip).
 // Conventions: SURVEY.md App. A / oracle/permuto_oracle.py.
 #pragma once
+#include "encode_conventions.h"
 #include "psdf_common.h"
 
 namespace {
@@ -54,7 +55,7 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
   for (int i = 0; i < P; i++) {
 #pragma unroll
     for (int j = i + 1; j <= P; j++) {
-      if (d[i] < d[j])
+      if (PSDF_ENC_RANK_TIE_RAISES_LATER ? (d[i] < d[j]) : (d[i] <= d[j]))   // encode_conventions.h
         s.rank[i]++;
       else
         s.rank[j]++;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
 // In the ring of 32-bit integers that is  sum_i key_i c^(P-i), so with H0 = sum_i rem0_i c^(P-i) (P multiplies, ONCE per
 // simplex) every vertex is  H0 + r*(c^P + .. + c) - sum_i [rank_i > P - r] * (P+1) c^(P-i):  adds and selects only
 // (integer multiplies are quarter rate and the direct form needs P of them per vertex).
-constexpr uint32_t HASH_C = 2531011u;
+constexpr uint32_t HASH_C = (uint32_t)PSDF_ENC_HASH_MULTIPLIER;   // encode_conventions.h
 constexpr uint32_t hash_pow(int e) { return e == 0 ? 1u : HASH_C * hash_pow(e - 1); }
 constexpr uint32_t hash_geom(int P) { return P == 0 ? 0u : hash_pow(P) + hash_geom(P - 1); }
 

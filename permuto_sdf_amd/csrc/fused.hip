@@ -34,6 +34,7 @@ struct EncArgs {
   const float* shifts;        // [L,3]
   const float* window;        // [L]
   float points_scaling;
+  int C;               // rows of `feat`: 2*Lt (padded pseudo-levels) or 2*L + 3 (appended points), encode_conventions.h
 };
 
 constexpr int JB = 1;  // level pairs per gather batch
@@ -108,7 +109,7 @@ __device__ __forceinline__ void encode_layer0(const MlpPlan& p, const float* __r
         const float2 f = level_finish(e, pos, lv, ld[jj]);
         if (feat && n_ok && lv < e.Lt) {
           feat[(int64_t)(2 * lv) * N + n] = f.x;
-          feat[(int64_t)(2 * lv + 1) * N + n] = f.y;
+          if (2 * lv + 1 < e.C) feat[(int64_t)(2 * lv + 1) * N + n] = f.y;
         }
         const float give = h ? f.x : f.y;
         const float got = __shfl_xor(give, 32, 64);
@@ -221,7 +222,8 @@ int launch_fused(const MlpPlan& p, const EncArgs& e, int64_t N, const unsigned c
 extern "C" {
 
 // Y[dims[n_layers], N] = MLP(encode(positions)) in one launch (pos_dim 3, 2 features per level only).
-//   dims[0] must equal 2*(nr_levels + (concat_points ? 2 : 0)); `packed` comes from psdf_mlp_pack.
+//   dims[0] must equal the encoding's channel count: 2*(nr_levels + 2) for padded pseudo-levels (concat_points = 1),
+//   2*nr_levels + 3 for appended points (2), 2*nr_levels without; `packed` comes from psdf_mlp_pack.
 //   skip    optional [N] bytes: samples with skip != 0 may be left unevaluated (their Y entries are then untouched)
 //   feat    optional [dims[0], N] feature-major: receives the encoding as a by-product (what psdf_encode_forward
 //           would have written; rows of fully skipped tiles are untouched)
@@ -234,11 +236,12 @@ int psdf_encode_mlp_forward(int64_t N, int nr_levels, int capacity, const float*
   if (rc != PSDF_OK) return rc;
   if (nr_levels <= 0 || capacity <= 0) return PSDF_ERR_ARG;
   const int Lt = nr_levels + (concat_points ? 2 : 0);
-  if (dims[0] != 2 * Lt) return PSDF_ERR_ARG;
+  const int C = concat_points == PSDF_ENC_CONCAT_APPEND ? 2 * nr_levels + 3 : 2 * Lt;   // the net's first layer has C inputs
+  if (dims[0] != C || concat_points < 0 || concat_points > PSDF_ENC_CONCAT_APPEND) return PSDF_ERR_ARG;
   if (N == 0) return PSDF_OK;
   if (N < 0 || !positions || !lattice || !scale_factor || !shifts || !window || !packed || !Y) return PSDF_ERR_ARG;
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
-  EncArgs e{nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling};
+  EncArgs e{nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling, C};
   hipStream_t st = (hipStream_t)stream;
   const int t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0, to = p.tiles[n_layers];
 #define CASE(A, B, C, O, D)                                          \

@@ -15,24 +15,27 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import conventions as CV
 
 
 def scale_factor_tensor(scale_list, pos_dim):
     scale_list = np.asarray(scale_list, dtype=np.float64)
     sf = np.empty((len(scale_list), pos_dim), dtype=np.float64)
     for i in range(pos_dim):
-        sf[:, i] = 1.0 / (math.sqrt((i + 1) * (i + 2)) * scale_list)
+        sf[:, i] = 1.0 / (CV.scale_term(i, pos_dim) * scale_list)        # csrc/encode_conventions.h
     return torch.from_numpy(sf.astype(np.float32))
 
 
 class _Cfg:
     """Fixed (non-tensor) parameters of one encoding instance."""
 
-    def __init__(self, pos_dim, capacity, nr_levels, nr_feat, concat_points, points_scaling):
+    def __init__(self, pos_dim, capacity, nr_levels, nr_feat, concat_points, points_scaling, concat_layout=None):
         self.pos_dim, self.capacity, self.nr_levels, self.nr_feat = pos_dim, capacity, nr_levels, nr_feat
         self.concat_points, self.points_scaling = bool(concat_points), float(points_scaling)
+        # PSDF_ENC_CONCAT_*: padded pseudo-levels (52 channels for L=24, P=3, F=2) or exactly P appended channels (51)
+        self.concat_mode = CV.concat_mode(concat_points, concat_layout)
         self.extra = int(math.ceil(pos_dim / nr_feat)) if concat_points else 0
-        self.channels = nr_feat * (nr_levels + self.extra)
+        self.channels = CV.channels(pos_dim, nr_levels, nr_feat, self.concat_mode)
 
 
 def _head(cfg, N):
@@ -40,7 +43,7 @@ def _head(cfg, N):
 
 
 def _tail(cfg):
-    return (L.c_i(int(cfg.concat_points)), L.c_f(cfg.points_scaling))
+    return (L.c_i(int(cfg.concat_mode)), L.c_f(cfg.points_scaling))
 
 
 def encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window, skip=None, out=None):
@@ -142,7 +145,7 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
 class PermutoEncoding(torch.nn.Module):
     def __init__(self, pos_dim, capacity, nr_levels, nr_feat_per_level, scale_per_level,
                  appply_random_shift_per_level=True, concat_points=False, concat_points_scaling=1.0,
-                 init_scale=1e-5, apply_random_shift_per_level=None):
+                 init_scale=None, apply_random_shift_per_level=None, concat_layout=None):
         super().__init__()
         if apply_random_shift_per_level is not None:  # accept the correctly spelled keyword as well
             appply_random_shift_per_level = apply_random_shift_per_level
@@ -155,12 +158,15 @@ class PermutoEncoding(torch.nn.Module):
         self.pos_dim, self.capacity, self.nr_levels, self.nr_feat_per_level = pos_dim, int(capacity), nr_levels, nr_feat_per_level
         self.scale_per_level = scale_per_level
         self.concat_points, self.concat_points_scaling = concat_points, concat_points_scaling
-        self.cfg = _Cfg(pos_dim, int(capacity), nr_levels, nr_feat_per_level, concat_points, concat_points_scaling)
-
+        # `concat_layout`: None = the default of csrc/encode_conventions.h; "pseudo_levels" | "append" to pick explicitly
+        self.cfg = _Cfg(pos_dim, int(capacity), nr_levels, nr_feat_per_level, concat_points, concat_points_scaling,
+                        concat_layout)
+        if init_scale is None:
+            init_scale = CV.C["PSDF_ENC_LATTICE_INIT_SCALE"]
         lattice_values = torch.randn(int(capacity), nr_levels, nr_feat_per_level) * init_scale
         self.lattice_values = torch.nn.Parameter(lattice_values.permute(1, 0, 2).contiguous())
         if appply_random_shift_per_level:
-            shift = torch.randn(nr_levels, pos_dim) * 10
+            shift = torch.randn(nr_levels, pos_dim) * CV.C["PSDF_ENC_RANDOM_SHIFT_SCALE"]
         else:
             shift = torch.zeros(nr_levels, pos_dim)
         # fixed (saved with the checkpoint, never trained)

@@ -6,8 +6,7 @@ from .mlp import _dims_array
 
 
 def fused_supported(cfg, dims):
-    extra = 2 if cfg.concat_points else 0
-    return cfg.pos_dim == 3 and cfg.nr_feat == 2 and dims[0] == 2 * (cfg.nr_levels + extra)
+    return cfg.pos_dim == 3 and cfg.nr_feat == 2 and dims[0] == cfg.channels
 
 
 def encode_mlp_forward_raw(cfg, positions, lattice, scale_factor, shifts, window, dims, packed, skip=None,
@@ -22,6 +21,6 @@ def encode_mlp_forward_raw(cfg, positions, lattice, scale_factor, shifts, window
     Y = out if out is not None else torch.empty((dims[-1], N), dtype=torch.float32, device=positions.device)
     feat = torch.empty((dims[0], N), dtype=torch.float32, device=positions.device) if want_feat else None
     L.call("psdf_encode_mlp_forward", L.c_l(N), L.c_i(cfg.nr_levels), L.c_i(cfg.capacity), L.ptr(positions), L.ptr(lattice),
-           L.ptr(scale_factor), L.ptr(shifts), L.ptr(window), L.c_i(int(cfg.concat_points)), L.c_f(cfg.points_scaling),
+           L.ptr(scale_factor), L.ptr(shifts), L.ptr(window), L.c_i(int(cfg.concat_mode)), L.c_f(cfg.points_scaling),
            L.c_i(len(dims) - 1), _dims_array(dims), L.ptr(packed), L.ptr(skip), L.ptr(feat), L.ptr(Y), L.stream())
     return Y, feat

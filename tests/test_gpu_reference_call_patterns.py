@@ -144,7 +144,8 @@ def test_non_contiguous_inputs_equal_contiguous(world, dev):
         enc(pts).backward(g)
         outs.append((enc.lattice_values.grad.clone(), pts.grad.clone()))
     # same kernels on the same values: the scatter order of the lattice gradient may differ between launches
-    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
 
 
 def test_attribute_overwrite_invalidates_packed_shortcut(world, dev):
@@ -221,10 +222,8 @@ def test_sphere_trace_loop_pattern_against_oracle(world, port, dev):
     # oracle side
     gridnp = (world["n"], 1.0, [0, 0, 0], world["occ"])
     _, te_n, _, tx_n, _ = port.sphere_intersect(0.5, [0, 0, 0], world["o"], world["d"])
-    fh = port.first_hit(gridnp, world["o"], world["d"], te_n, tx_n)
-    keep = (fh.start_end[:, 1] - fh.start_end[:, 0]) > 0
-    pos_n = fh.pos[:int(fh.cur)] if hasattr(fh, "cur") else fh.pos[:int(keep.sum())]
-    dirs_n = fh.dirs[:pos_n.shape[0]]
+    fh = port.compact(port.first_hit_samples(world["o"], world["d"], te_n, tx_n, 1 << 21, gridnp))
+    pos_n, dirs_n = fh.pos, fh.dirs
     assert np.array_equal(rs.samples_pos.cpu().numpy(), pos_n)
     pts_n = (pos_n + dirs_n * np.float32(voxel) * np.float32(0.5)).astype(np.float32)
     assert np.array_equal(pts.cpu().numpy(), pts_n)
@@ -255,7 +254,7 @@ def test_sphere_trace_loop_pattern_against_oracle(world, port, dev):
         sn = sdf_t(pun)
         pun = (pun + dun * sn * 0.9).numpy()
         newly = (sn.abs() < 2e-4).numpy()[:, 0]
-        adv, inbn = port.advance_samples(gridnp, dun.numpy(), pun)
+        adv, inbn = port.advance_samples(dun.numpy(), pun, gridnp)
         conv_n[seln, 0] |= newly | ~inbn.reshape(-1).astype(bool)
         pts_n[seln] = adv
         # the analytic sdf goes through device vs host sqrt (both correctly rounded) and identical fp32 arithmetic

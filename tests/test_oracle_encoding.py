@@ -62,7 +62,7 @@ def test_window_and_output_dims():
 
 def test_hash_known_answers():
     # key (0,0,0) hashes to row 0; key (1,0,0): ((1*M)*M)*M mod 2^32 mod T
-    M = po.HASH_MULT
+    M = po._hash_mult()
     rem0 = torch.tensor([[0, 0, 0, 0]])
     rank = torch.tensor([[0, 1, 2, 3]])
     idx = po.vertex_indices(rem0, rank, 2 ** 18)

@@ -37,7 +37,13 @@ static constexpr int TAIL_FLOATS = 3 * HID + HID + 1;  // biases of the three hi
 static constexpr size_t IMG_BYTES = (size_t)OFF_F32 * 16 + TAIL_FLOATS * 4;
 static constexpr int NWAVES = 4;
 static constexpr size_t IMG_ALIGNED = (IMG_BYTES + 15) / 16 * 16;
+// per-wave staging of the next tile's inputs (LDS-DMA, double buffered): X rows [K0][16 samples] + 64 floats of dY
+static constexpr int STAGE_FLOATS = K0 * 16 + 64;
+#ifdef PREFETCH_LDS
+static constexpr size_t LDS_BYTES = IMG_ALIGNED + (size_t)NWAVES * 2 * STAGE_FLOATS * 4;
+#else
 static constexpr size_t LDS_BYTES = IMG_ALIGNED;
+#endif
 // gradient image (floats): dW1 [64][64 (36 used)], dW2 [64][64], dW3 [64][64], db1, db2, db3 [64], dW4 [64], db4
 static constexpr int G_W1 = 0, G_W2 = 4096, G_W3 = 8192, G_B1 = 12288, G_B2 = 12352, G_B3 = 12416, G_W4 = 12480, G_B4 = 12544,
                      G_TOTAL = 12545;
@@ -278,6 +284,22 @@ __device__ __forceinline__ void chain(const f32x4 (&in)[NT], f32x4 (&out)[NTILE]
 template <int NTO, int NTI>
 __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO], const u32x4* __restrict__ wT, int lane,
                                           const bf16x8 (&id)[2], const f32x4 (&hT)[NTI], f32x4 (&dW)[NT][NTI], float (&db)[NT]) {
+#ifdef DW_PER_STEP
+  // the transposed pieces of a k-step's two dZ tiles are consumed at once (24 registers live instead of 48); the price is
+  // that the pieces of H are cut twice
+  chain<NTO>(dz, dh, wT, lane, [&](int s, const BP& b) {
+    BP A0, A1;
+    transpose_pieces(b, id[0], A0, db[2 * s]);
+    transpose_pieces(b, id[1], A1, db[2 * s + 1]);
+#pragma unroll
+    for (int ti = 0; ti < NTI; ti++) {
+      BP B;
+      split4(hT[ti], B);
+      dW[2 * s][ti] = dw_mac(dW[2 * s][ti], A0, B);
+      dW[2 * s + 1][ti] = dw_mac(dW[2 * s + 1][ti], A1, B);
+    }
+  });
+#else
   BP A[NT];
   chain<NTO>(dz, dh, wT, lane, [&](int s, const BP& b) {
     transpose_pieces(b, id[0], A[2 * s], db[2 * s]);
@@ -290,6 +312,7 @@ __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO
 #pragma unroll
     for (int to = 0; to < NT; to++) dW[to][ti] = dw_mac(dW[to][ti], A[to], B);
   }
+#endif
 }
 
 __global__ void __launch_bounds__(NWAVES * 64, 1)
@@ -301,6 +324,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   __syncthreads();
   const float* tail = reinterpret_cast<const float*>(lds + OFF_F32);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int lane_k = lane;
   const bf16x8 id[2] = {ident_op(0, lane), ident_op(1, lane)};
   f32x4 dW1[NT][NT0], dW2[NT][NT], dW3[NT][NT];
 #pragma unroll
@@ -313,8 +337,43 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   float db1[NT] = {0.f, 0.f, 0.f, 0.f}, db2[NT] = {0.f, 0.f, 0.f, 0.f}, db3[NT] = {0.f, 0.f, 0.f, 0.f},
         dw4[NT] = {0.f, 0.f, 0.f, 0.f}, db4 = 0.f;
   const int64_t ntiles = N / 16;  // prototype: N is a multiple of 16
+#ifdef PREFETCH_LDS
+  // One wave per SIMD: nothing hides an HBM round trip (SQ counters of the version without this: 39 % of the wave's time
+  // in s_waitcnt).  The inputs of the NEXT tile are requested at the top of the current one with global_load_lds.
+  float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED) + wave * 2 * STAGE_FLOATS;
+  auto prefetch = [&](int64_t t, float* buf) {
+    const int64_t nn = t * 16 + c;
+#pragma unroll
+    for (int i = 0; i < K0 / 4; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)(4 * i + g) * N + nn),
+                                       (__attribute__((address_space(3))) void*)(buf + i * 64), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + nn),
+                                     (__attribute__((address_space(3))) void*)(buf + K0 * 16), 4, 0, 0);
+  };
+  const int64_t tile0 = (int64_t)blockIdx.x * NWAVES + wave, tstride = (int64_t)gridDim.x * NWAVES;
+  if (tile0 < ntiles) prefetch(tile0, stage);
+  int cur = 0;
+  for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA completion is not tracked by the compiler
+    const float* xb = stage + cur * STAGE_FLOATS;
+#ifndef PREFETCH_POS
+#define PREFETCH_POS 0
+#endif
+#define ISSUE_PREFETCH() if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * STAGE_FLOATS)
+    if (PREFETCH_POS == 0) ISSUE_PREFETCH();
+#else
+#define PREFETCH_POS -1
+#define ISSUE_PREFETCH()
   for (int64_t tile = (int64_t)blockIdx.x * NWAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * NWAVES) {
     asm volatile("" ::: "memory");
+#endif
+#ifdef REMAT_LANE
+    // loop-invariant lane arithmetic (addresses, masks) is cheap to redo and expensive to keep: hoisted out of the loop it
+    // ends up in scratch, and every scratch reload waits (vmcnt) for the LDS-DMA prefetch in flight
+    int lane_l = lane_k;
+    asm volatile("" : "+v"(lane_l));
+    const int lane = lane_l, c = lane & 15, g = lane >> 4;
+#endif
     const int64_t n0 = tile * 16, n = n0 + c;
     // ---------------- forward recompute; h1, h2 leave the sweep as fp32 feature-lane tiles
     f32x4 a[NT], g1[NT], b[NT], g2[NT], h1T[NT], h2T[NT];
@@ -326,7 +385,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           const int k = 32 * s + 8 * g + j;  // layer 0: natural k order (the image is packed to match)
+#ifdef PREFETCH_LDS
+          xs[s][j] = k < K0 ? xb[k * 16 + c] : 0.f;
+#else
           xs[s][j] = k < K0 ? X[(int64_t)k * N + n] : 0.f;
+#endif
         }
 #pragma unroll
       for (int s = 0; s < 2; s++) {
@@ -351,7 +414,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     act_both(a, dz);  // a = h3, dz = gelu'(z3) for now
     // ---------------- output layer: dW4 = sum dy h3, db4 = sum dy, dZ3 = w4 dy gelu'(z3)
     {
+#ifdef PREFETCH_LDS
+      const f32x4 dyT = *reinterpret_cast<const f32x4*>(xb + K0 * 16 + 4 * g);  // samples 4 g + r
+#else
       const f32x4 dyT = *reinterpret_cast<const f32x4*>(dY + n0 + 4 * g);  // samples 4 g + r
+#endif
       db4 += (dyT[0] + dyT[1]) + (dyT[2] + dyT[3]);
 #pragma unroll
       for (int s = 0; s < 2; s++) {
@@ -366,7 +433,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
         }
       }
     }
+#ifdef PREFETCH_LDS
+    const float dy = xb[K0 * 16 + c];
+#else
     const float dy = dY[n];
+#endif
     const float* wf = tail + 3 * HID;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -375,22 +446,29 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       for (int r = 0; r < 4; r++) dz[t][r] *= w4[r] * dy;
     }
     // ---------------- layer 3
+    if (PREFETCH_POS == 1) ISSUE_PREFETCH();
     zero_init<NT>(a);
     layer_bwd<NT, NT>(dz, a, lds + OFF_T2, lane, id, h2T, dW3, db3);  // a = dH2^T
 #pragma unroll
     for (int t = 0; t < NT; t++) a[t] *= g2[t];                       // dZ2^T
     // ---------------- layer 2
+    if (PREFETCH_POS == 2) ISSUE_PREFETCH();
     zero_init<NT>(dz);
     layer_bwd<NT, NT>(a, dz, lds + OFF_T1, lane, id, h1T, dW2, db2);  // dz = dH1^T
 #pragma unroll
     for (int t = 0; t < NT; t++) dz[t] *= g1[t];                      // dZ1^T
     // ---------------- layer 1: H = X, read in feature-lane order straight from the feature-major rows
+    if (PREFETCH_POS == 3) ISSUE_PREFETCH();
     f32x4 xT[NT0], dx[NT0];
 #pragma unroll
     for (int u = 0; u < NT0; u++) {
       const int feat = 16 * u + c;
       xT[u] = zero4();
+#ifdef PREFETCH_LDS
+      if (feat < K0) xT[u] = *reinterpret_cast<const f32x4*>(xb + feat * 16 + 4 * g);
+#else
       if (feat < K0) xT[u] = *reinterpret_cast<const f32x4*>(X + (int64_t)feat * N + n0 + 4 * g);
+#endif
     }
     zero_init<NT0>(dx);
     layer_bwd<NT0, NT0>(dz, dx, lds + OFF_T0, lane, id, xT, dW1, db1);  // dx = dX^T
