@@ -6,10 +6,10 @@
 
 Workload (BASELINE.json configs[1] + the compositing of configs[2]'s chunk size): per GPU 16 384 rays x 128 samples
 = 2 097 152 synthetic ray samples inside the radius-0.5 bounding sphere, already resident in HBM.  One step =
-  forward : 16-level permutohedral encode (T=2^18, F=2, +points) -> fused 64x3 SDF MLP (fp32 MFMA) -> sdf2alpha ->
-            transmittance cumprod -> weights -> per-ray weight sum -> radiance integration
-  backward: integrate_backward -> cumprod backward (incl. per-ray inverse cumsum) -> fused MLP backward (dX, dW, db)
-            -> encode backward (lattice gradient)   [dL/dsdf = ones: the reference has no native sdf->alpha backward]
+  forward : 16-level permutohedral encode (T=2^18, F=2, +points) -> fused 64x3 SDF MLP -> NeuS section-point opacity
+            (volume_rendering_modules.py:129-172) -> transmittance cumprod -> weights -> radiance integration -> L1 loss
+  backward: a TRUE gradient of that loss: L1 -> integrate_backward -> cumprod backward (incl. per-ray inverse cumsum) ->
+            opacity backward (dL/dsdf) -> fused MLP backward (dX, dW, db) -> encode backward (lattice gradient)
   N > 1   : RCCL sum all-reduce of MLP + lattice gradients (bucketed, overlapped with the encode backward)
   update  : fused AdamW on lattice + MLP parameters
 value = ray samples through that whole step per second, summed over ranks (weak scaling: per-GPU work is fixed).
@@ -58,13 +58,18 @@ def make_batch(dev, seed, nr_rays=NR_RAYS, per_ray=SAMPLES_PER_RAY):
     rs.cur_nr_samples.fill_(nr_rays * n)
     rs._exact = True
     rgb = torch.rand(nr_rays * n, 3, generator=g).to(dev)
-    return rs, rgb, (o, d, te, tx)
+    # direction of the SDF gradient at the samples (an input of the first-order path): the analytic normal of a centred
+    # sphere; and the ground-truth radiance of every ray for the L1 loss
+    normals = torch.nn.functional.normalize(rs.samples_pos, dim=1).contiguous()
+    gt = torch.rand(nr_rays, 3, generator=g).to(dev)
+    return rs, rgb, (o, d, te, tx, normals, gt)
 
 
 def cpu_baseline(cores):
-    """The CPU oracle timed on a bounded sample of the same workload: torch-vectorised encode restatement + the
-    unmodified torch.nn MLP (fwd + autograd bwd) + the C compositing oracle (fwd + bwd), fp32, `cores` threads."""
-    from oracle import oracle as O
+    """The CPU oracle timed on a bounded sample of the same step: torch-vectorised encode restatement + the unmodified
+    torch.nn MLP + the torch restatement of the NeuS opacity / compositing / L1 loss (oracle/neus_oracle.py), forward and
+    autograd backward, fp32, `cores` threads."""
+    from oracle import neus_oracle as no
     from oracle import permuto_oracle as po
     torch.set_num_threads(cores)
     rays, per_ray = 256, SAMPLES_PER_RAY
@@ -78,29 +83,21 @@ def cpu_baseline(cores):
     C = po.output_dims(3, NR_LEVELS, 2, True)
     mlp = torch.nn.Sequential(torch.nn.Linear(C, 64), torch.nn.GELU(), torch.nn.Linear(64, 64), torch.nn.GELU(),
                               torch.nn.Linear(64, 64), torch.nn.GELU(), torch.nn.Linear(64, 1))
-    port = O.Oracle("port")
-    s = O.Samples(rays, N)
-    s.equal, s.fixed = True, per_ray
-    s.dt[:] = 1.0 / per_ray / 2
-    s.fixed_dt[:] = 1.0 / per_ray / 2
-    rgb = np.random.default_rng(0).uniform(size=(N, 3)).astype(np.float32)
+    dirs = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=1)
+    normals = torch.nn.functional.normalize(pos, dim=1)
+    dt = torch.full((N, 1), 1.0 / per_ray / 2)
+    rgb = torch.rand(N, 3, generator=g)
+    gt = torch.rand(rays, 3, generator=g)
+    inv_s = torch.exp(torch.tensor(5.0))
     win = torch.ones(NR_LEVELS)
 
     def one():
         feat = po.encode(pos, lat, sl, shifts, win, True, 1e-3)
         sdf = mlp(feat)
-        sdf_np = sdf.detach().numpy()
-        alpha = port.sdf2alpha(s, sdf_np, 512.0, True, 1.0)
-        om = (1 - alpha + 1e-7).astype(np.float32)
-        T, bg = port.cumprod(s, om)
-        w = alpha * T
-        port.sum_over_each_ray(s, w)
-        pred = port.integrate(s, rgb, w)
-        g_rgb, g_w = port.integrate_backward(s, np.ones_like(pred), rgb, w)
-        gT = (g_w * alpha).astype(np.float32)
-        cs = port.cumsum(s, (gT * T).astype(np.float32), True)
-        port.cumprod_backward(s, gT, np.zeros_like(bg), om, T, bg, cs)
-        sdf.backward(torch.ones_like(sdf))
+        alpha, om = no.neus_alpha(sdf, dirs, normals, dt, inv_s, 1.0)
+        pred, _, _ = no.composite_equal(alpha, om, rgb, rays, per_ray)
+        loss = no.rgb_loss(gt, pred, torch.ones(rays, 1))
+        loss.backward()
         lat.grad = None
         mlp.zero_grad()
 
@@ -112,10 +109,11 @@ def cpu_baseline(cores):
         reps += 1
         if time.perf_counter() - t0 > 30.0:
             break
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": N / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d rays x %d samples (%d samples) of the same step: torch-CPU encode restatement fwd+bwd, torch.nn "
-                      "64x3 MLP fwd+bwd, C compositing oracle fwd+bwd; %d repetitions, %.2f s each" % (rays, per_ray, N, reps, dt)}
+    dt_s = (time.perf_counter() - t0) / reps
+    return {"value": N / dt_s, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d rays x %d samples (%d samples) of the same step: torch-CPU encode restatement, torch.nn 64x3 MLP, "
+                      "torch restatement of NeuS opacity + compositing + L1 loss, forward + autograd backward; %d repetitions, "
+                      "%.2f s each" % (rays, per_ray, N, reps, dt_s)}
 
 
 def main():
@@ -143,9 +141,10 @@ def main():
     dev = torch.device("cuda", local)
 
     hp = SdfHotPath(nr_levels=NR_LEVELS, hidden=64, out_channels=1, device=dev, seed=0)   # replicated parameters
-    rs, rgb, _ = make_batch(dev, parallel.rank_seed(7, rank))                               # per-rank rays
+    rs, rgb, aux = make_batch(dev, parallel.rank_seed(7, rank))                             # per-rank rays
+    normals, gt = aux[4], aux[5]
     N = rs.samples_pos.shape[0]
-    grad_pred = torch.ones(NR_RAYS, 3, device=dev)
+    from permuto_sdf_amd.neus import l1_loss_raw
 
     def barrier():
         torch.cuda.synchronize()
@@ -154,7 +153,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        hp.step(rs, rgb, grad_pred)
+        hp.step(rs, rgb, normals, gt)
     # per-kernel HIP events on the launch stream (torch's current stream == the stream the kernels are launched on)
     K = args.steps
     ev = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
@@ -164,9 +163,10 @@ def main():
     for i in range(K):
         hp.events = {"enc_bwd": ev["enc_bwd"][i], "mlp_bwd": ev["mlp_bwd"][i]}
         ev["fwd"][i][0].record()
-        pred, saved = hp.forward(rs, rgb)
+        pred, saved = hp.forward(rs, rgb, normals)
         ev["fwd"][i][1].record()
-        hp.backward(rs, rgb, saved, grad_pred)
+        loss, g_pred = l1_loss_raw(pred, gt)
+        hp.backward(rs, rgb, saved, g_pred)
     barrier()
     elapsed = time.perf_counter() - t0
     hp.events = None
@@ -229,7 +229,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "cfg2+composite: 16-level permutohedral encode fwd/bwd + 64x3 SDF MLP fwd/bwd + NeuS "
-                                   "compositing fwd/bwd + AdamW, %d rays x %d samples = %d samples per GPU" % (NR_RAYS, SAMPLES_PER_RAY, N),
+                                   "compositing fwd/bwd (true gradient of an L1 radiance loss) + AdamW, %d rays x %d samples = %d "
+                                   "samples per GPU" % (NR_RAYS, SAMPLES_PER_RAY, N),
                        "pos_dim": 3, "nr_levels": NR_LEVELS, "capacity": Tcap, "feat_per_level": F, "mlp": "36-64-64-64-1 GELU",
                        "mlp_forward_arithmetic": "fp32 operands multiplied as 3 bf16 pieces each, 6 products kept, fp32 accumulation "
                                                  "(error at fp32 rounding level: tests/test_gpu_mlp.py::test_split_bf16_forward_keeps_fp32_accuracy); "

@@ -55,6 +55,25 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced, float* grad_lattice,
     float* grad_grad_sliced, void* stream);
 
+/* ---- neus.hip ---- */
+/* replaces: the torch elementwise chain of VolumeRenderingNeus.compute_weights, permuto_sdf_py/volume_rendering/
+   volume_rendering_modules.py:129-172 (cos anneal, section-point SDFs, two sigmoids, (p+1e-5)/(c+1e-5) clipped to [0,1]);
+   inv_s is a DEVICE pointer to one float (the clipped exp(10*variance) of SingleVarianceNetwork, :96-115), samples are the
+   packed [N,1]/[N,3] tensors of RaySamplesPacked; one_minus_alpha (optional) = 1 - alpha + 1e-7, the transmittance input */
+int psdf_neus_alpha_forward(int64_t N, const float* sdf, const float* dirs, const float* gradients, const float* dt,
+    const float* inv_s, float cos_anneal_ratio, float* alpha, float* one_minus_alpha, void* stream);
+/* replaces: torch autograd of the same chain.  grad_gradients [N,3] and grad_inv_s [1] are optional; grad_inv_s is
+   ACCUMULATED into (zero it first) */
+int psdf_neus_alpha_backward(int64_t N, const float* grad_alpha, const float* sdf, const float* dirs, const float*
+    gradients, const float* dt, const float* inv_s, float cos_anneal_ratio, float* grad_sdf, float* grad_gradients,
+    float* grad_inv_s, void* stream);
+/* replaces: rgb_loss, permuto_sdf_py/utils/permuto_sdf_utils.py:43-47: loss[0] += scale * sum |gt - pred| * mask[ray]
+   (mask: optional [R] bytes), grad_pred (optional) = scale * sign(pred - gt) * mask */
+int psdf_l1_loss(int64_t R, int C, const float* pred, const float* gt, const unsigned char* mask, float scale,
+    float* loss, float* grad_pred, void* stream);
+/* replaces: eikonal_loss, permuto_sdf_utils.py:49-51: loss[0] += scale * sum (|g| - 1)^2, grad (optional) [N,3] */
+int psdf_eikonal_loss(int64_t N, const float* gradients, float scale, float* loss, float* grad_gradients, void* stream);
+
 /* ---- mlp.hip ---- */
 /* replaces: torch.nn.Sequential(Linear,GELU,...) evaluators, permuto_sdf_py/models/models.py:153-161,451-470 */
 int64_t psdf_mlp_packed_size(int n_layers, const int* dims);

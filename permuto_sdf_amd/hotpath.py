@@ -1,10 +1,12 @@
 """The data-parallel hot path as ONE object: encode -> fused SDF MLP -> NeuS compositing, forward and backward, over a
 packed batch of ray samples, entirely on the feature-major ([C, N]) fast path of the kernels (no autograd graph,
-no transposes).  It strings together exactly the operators the reference's Python strings together in
-permuto_sdf_py/utils/sdf_utils.py:383-423 (importance sampling: SDF eval -> sdf2alpha -> cumprod -> weights -> sum)
-and permuto_sdf_py/train_permuto_sdf.py:111-169 (run_net: SDF eval -> weights -> integrate), with their backward
-kernels.  bench.py times this object; the drop-in API (permuto_sdf / permutohedral_encoding) exposes the same kernels
-one by one for the reference's unmodified Python.
+no transposes).  It strings together the operators the reference's Python strings together in
+permuto_sdf_py/train_permuto_sdf.py:111-169 (run_net: SDF eval -> NeuS weights -> integrate) and
+permuto_sdf_py/volume_rendering/volume_rendering_modules.py:129-172 (section-point opacity -> transmittance -> weights),
+with their backward kernels, and it is a TRUE gradient: dL/d(radiance) flows through integrate -> weights -> transmittance
+-> opacity (csrc/neus.hip) -> dL/d(sdf) -> fused MLP backward -> encoding backward.  bench.py times this object; the
+drop-in API (permuto_sdf / permutohedral_encoding) exposes the same kernels one by one for the reference's unmodified
+Python.
 """
 import torch
 
@@ -13,6 +15,7 @@ from . import parallel
 from .bridge import VolumeRendering as VR
 from .encoding import PermutoEncoding, encode_backward_raw, encode_forward_raw
 from .mlp import FusedMLP, mlp_backward_raw, mlp_forward_raw, pack_params
+from .neus import neus_alpha_backward_raw, neus_alpha_forward_raw
 
 
 class SdfHotPath:
@@ -28,18 +31,22 @@ class SdfHotPath:
         with torch.no_grad():  # sphere-ish start so that alphas are neither all 0 nor all 1
             self.mlp.layers[-1].bias.fill_(0.05)
         self.window = torch.ones(nr_levels, device=self.dev)
+        # exp(10 * variance) of SingleVarianceNetwork (volume_rendering_modules.py:96-115) at variance 0.5; fixed here
+        self.inv_s = torch.full((1,), float(torch.exp(torch.tensor(5.0))), device=self.dev)
+        self.cos_anneal_ratio = 1.0
         self.params = [self.enc.lattice_values] + [p for l in self.mlp.layers for p in (l.weight, l.bias)]
         from .optim import FusedAdamW
         self.opt = FusedAdamW(self.params, lr=lr)
         self.events = None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, rs, rgb_samples):
-        """rs: RaySamplesPacked (positions, dt, ray ranges); rgb_samples [M,3].  Returns per-ray radiance [R,3] and the
-        tensors the backward needs."""
+    def forward(self, rs, rgb_samples, normals):
+        """rs: RaySamplesPacked (positions, directions, dt, ray ranges); rgb_samples [M,3]; normals [M,3]: the SDF gradient
+        direction at the samples, an INPUT here (the reference obtains it with a second, differentiated evaluation of the
+        same net, models.py:236-251; config 2 of BASELINE.json times the first-order path).  Returns per-ray radiance [R,3]
+        and the tensors the backward needs."""
         cfg = self.enc.cfg
         pos = rs.samples_pos
-        N = pos.shape[0]
         packed = pack_params(self.mlp.dims, [l.weight for l in self.mlp.layers], [l.bias for l in self.mlp.layers])
         # Two launches on purpose: the level-major encode kernel keeps one 2-MiB table at a time in every XCD's L2 and
         # runs at full occupancy, which measured faster than the single fused launch of csrc/fused.hip at this size
@@ -49,20 +56,20 @@ class SdfHotPath:
                                   self.enc.random_shift_per_level.detach(), self.window)
         sdf = mlp_forward_raw(self.mlp.dims, feat, packed)                    # [1, N] feature-major == [N,1] memory
         sdf_col = sdf.view(-1, 1)
-        alpha = VR.sdf2alpha(rs, sdf_col, 512.0, True, 1.0)
-        one_minus = 1.0 - alpha + 1e-7
+        alpha, one_minus = neus_alpha_forward_raw(sdf_col, rs.samples_dirs, normals, rs.samples_dt, self.inv_s,
+                                                  self.cos_anneal_ratio)
         T, bg = VR.cumprod_alpha2transmittance(rs, one_minus)
         w = alpha * T
-        w_sum, _ = VR.sum_over_each_ray(rs, w)
         pred = VR.integrate_with_weights(rs, rgb_samples, w)
-        return pred, dict(feat=feat, packed=packed, sdf=sdf, alpha=alpha, one_minus=one_minus, T=T, bg=bg, w=w, w_sum=w_sum)
+        return pred, dict(feat=feat, packed=packed, sdf=sdf, alpha=alpha, one_minus=one_minus, T=T, bg=bg, w=w,
+                          normals=normals)
 
     # ------------------------------------------------------------------ backward (+ optional all-reduce and optimiser)
-    def backward(self, rs, rgb_samples, saved, grad_pred, grad_sdf=None, reduce=True, optimizer_step=True,
-                 split_levels=None):
-        """Backward through integrate -> weights -> transmittance (the reference's native backward kernels), then the
-        fused MLP and the encoding.  The reference has no native sdf->alpha backward (its training path computes alpha
-        with torch elementwise ops); `grad_sdf` is therefore an input (default: ones), as in SURVEY.md section 8d cfg 2."""
+    def backward(self, rs, rgb_samples, saved, grad_pred, reduce=True, optimizer_step=True, split_levels=None):
+        """dL/d(pred) [R,3] -> gradients of the lattice and the MLP parameters (and of the per-sample radiance).
+        integrate_backward -> (w = alpha T) -> transmittance backward (per-ray inverse cumsum + the reference's
+        cumprod backward, volume_rendering_funcs.py:55-118) -> opacity backward (csrc/neus.hip) -> dL/d(sdf) -> fused MLP
+        backward -> encoding backward."""
         cfg = self.enc.cfg
         N = rs.samples_pos.shape[0]
         g_rgb, g_w = VR.integrate_with_weights_backward(grad_pred, rs, rgb_samples, saved["w"], None)
@@ -70,8 +77,11 @@ class SdfHotPath:
         cs = VR.cumsum_over_each_ray(rs, g_T * saved["T"], True)
         g_om = VR.cumprod_alpha2transmittance_backward(g_T, torch.zeros_like(saved["bg"]), rs, saved["one_minus"], saved["T"],
                                                        saved["bg"], cs)
-        if grad_sdf is None:
-            grad_sdf = torch.ones((1, N), dtype=torch.float32, device=self.dev)
+        g_alpha = torch.addcmul(-g_om, g_w, saved["T"])      # alpha enters as w = alpha T and as 1 - alpha + 1e-7
+        g_sdf, _, _ = neus_alpha_backward_raw(g_alpha, saved["sdf"].view(-1, 1), rs.samples_dirs, saved["normals"],
+                                               rs.samples_dt, self.inv_s, self.cos_anneal_ratio, need_grad=False,
+                                               need_inv_s=False)
+        grad_sdf = g_sdf.view(1, N)
         if self.events is not None:
             self.events["mlp_bwd"][0].record()
         d_feat, dWs, dbs = mlp_backward_raw(self.mlp.dims, saved["feat"], [l.weight for l in self.mlp.layers],
@@ -111,7 +121,7 @@ class SdfHotPath:
             for p, g in zip(self.params, grads):
                 p.grad = g
             self.opt.step(grad_scale=1.0 / parallel.world_size())
-        return dict(g_rgb=g_rgb, g_one_minus=g_om, grads=grads)
+        return dict(g_rgb=g_rgb, g_one_minus=g_om, g_alpha=g_alpha, g_sdf=g_sdf, grads=grads)
 
     def _encode_backward_levels(self, pos, d_feat, g_lat, l0, l1):
         """lattice gradient of levels [l0, l1) only: every operand of the kernel is contiguous per level (tables
@@ -125,7 +135,11 @@ class SdfHotPath:
                             self.enc.random_shift_per_level[l0:l1], self.window[l0:l1], d_feat[F * l0:F * l1],
                             g_lat[l0:l1], None)
 
-    def step(self, rs, rgb_samples, grad_pred, **kw):
-        pred, saved = self.forward(rs, rgb_samples)
-        out = self.backward(rs, rgb_samples, saved, grad_pred, **kw)
+    def step(self, rs, rgb_samples, normals, gt, **kw):
+        """forward -> L1 radiance loss against `gt` [R,3] (rgb_loss, permuto_sdf_utils.py:43-47) -> backward"""
+        from .neus import l1_loss_raw
+        pred, saved = self.forward(rs, rgb_samples, normals)
+        loss, g_pred = l1_loss_raw(pred, gt)
+        out = self.backward(rs, rgb_samples, saved, g_pred, **kw)
+        out["loss"] = loss
         return pred, saved, out

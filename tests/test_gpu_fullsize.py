@@ -106,9 +106,9 @@ def test_level_split_backward_equals_single_launch(dev):
     import bench
     from permuto_sdf_amd.hotpath import SdfHotPath
     hp = SdfHotPath(nr_levels=16, hidden=64, out_channels=1, device=dev, seed=0)
-    rs, rgb, _ = bench.make_batch(dev, 11, nr_rays=4096)
+    rs, rgb, aux = bench.make_batch(dev, 11, nr_rays=4096)
     grad_pred = torch.ones(4096, 3, device=dev)
-    pred, saved = hp.forward(rs, rgb)
+    pred, saved = hp.forward(rs, rgb, aux[4])
     a = hp.backward(rs, rgb, saved, grad_pred, reduce=False, optimizer_step=False, split_levels=False)["grads"][0]
     b = hp.backward(rs, rgb, saved, grad_pred, reduce=False, optimizer_step=False, split_levels=True)["grads"][0]
     scale = float(a.abs().max())
