@@ -39,10 +39,30 @@ def eikonal_loss(sdf_gradients):
     return ((torch.linalg.norm(sdf_gradients.reshape(-1, 3), ord=2, dim=-1) - 1.0) ** 2).mean()
 
 
-def composite_equal(alpha, one_minus, rgb, nr_rays, per_ray):
-    """transmittance T_i = prod_{j<i} one_minus_j, weights alpha*T, per-ray sum of w*rgb; [R*n, .] packed ray-major"""
+class _IntegrateCompat(torch.autograd.Function):
+    """sum_i w_i rgb_i per ray with the backward of the reference's kernel: integrate_with_weights_backward_gpu builds the
+    sample colour as (r, g, G) -- `rgb_samples[..][1]` where channel 2 is meant, VolumeRenderingGPU.cuh:1247
+    -- so d/dw = g_r r + g_g g + g_b G.  This is the gradient the reference trains with."""
+
+    @staticmethod
+    def forward(ctx, w, rgb):                       # w [R,n], rgb [R,n,3]
+        ctx.save_for_backward(w, rgb)
+        return (w[:, :, None] * rgb).sum(1)
+
+    @staticmethod
+    def backward(ctx, g):                           # g [R,3]
+        w, rgb = ctx.saved_tensors
+        g_rgb = g[:, None, :] * w[:, :, None]
+        quirk = torch.stack([rgb[:, :, 0], rgb[:, :, 1], rgb[:, :, 1]], -1)
+        return (g[:, None, :] * quirk).sum(-1), g_rgb
+
+
+def composite_equal(alpha, one_minus, rgb, nr_rays, per_ray, reference_compat=True):
+    """transmittance T_i = prod_{j<i} one_minus_j, weights alpha*T, per-ray sum of w*rgb; [R*n, .] packed ray-major.
+    `reference_compat` selects the backward of the weighted sum: the reference kernel's (default) or the exact one."""
     om = one_minus.view(nr_rays, per_ray)
     T = torch.cumprod(torch.cat([torch.ones(nr_rays, 1, dtype=om.dtype), om[:, :-1]], 1), dim=1)
     w = alpha.view(nr_rays, per_ray) * T
-    pred = (w[:, :, None] * rgb.view(nr_rays, per_ray, -1)).sum(1)
+    rgb3 = rgb.view(nr_rays, per_ray, -1)
+    pred = _IntegrateCompat.apply(w, rgb3) if (reference_compat and rgb3.shape[-1] == 3) else (w[:, :, None] * rgb3).sum(1)
     return pred, w.reshape(-1, 1), T.reshape(-1, 1)
