@@ -28,6 +28,7 @@ from .bridge import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRenderi
 from .encoding import Coarse2Fine, PermutoEncoding
 from .fused import encode_mlp_forward_raw
 from .mlp import FusedMLP, LipshitzMLP, pack_params
+from .neus import l1_loss, neus_alpha
 from .optim import FusedAdamW
 
 
@@ -180,12 +181,10 @@ class RgbNet(torch.nn.Module):
         v = self.variance if forced_variance is None else torch.tensor(float(forced_variance), device=sdf.device)
         inv_s = torch.exp(v * 10.0).clip(1e-6, 1e6)
         self.last_inv_s = inv_s.detach()
-        true_cos = (rs.samples_dirs * gradients).sum(-1, keepdim=True)
-        iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-true_cos) * cos_anneal_ratio)
-        half = iter_cos * rs.samples_dt.reshape(-1, 1) * 0.5
-        prev_cdf, next_cdf = torch.sigmoid((sdf - half) * inv_s), torch.sigmoid((sdf + half) * inv_s)
-        alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
-        T, bg = _Cumprod.apply(rs, 1 - alpha + 1e-7)
+        # cosine annealing, section-point SDFs, two sigmoids, clipped ratio: ONE launch per direction (csrc/neus.hip)
+        # instead of ~30 torch elementwise launches; gradients flow to sdf, the SDF gradient and inv_s (the variance)
+        alpha, one_minus = neus_alpha(sdf, rs.samples_dirs, gradients, rs.samples_dt, inv_s, cos_anneal_ratio)
+        T, bg = _Cumprod.apply(rs, one_minus)
         w = (alpha * T).view(-1, 1)
         w_sum, _ = _SumRay.apply(rs, w)
         return w, w_sum, bg
@@ -315,7 +314,7 @@ class Trainer:
             o, d, gt, _, _ = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
             _, _, _, _, hit = self.sphere.ray_intersection(o, d)
         pred, sdf_grad, fg = self._render(o, d, it, cos_anneal_ratio, forced_variance)
-        loss = ((gt - pred).abs() * hit).mean()                                                # rgb_loss
+        loss = l1_loss(pred, gt, hit)                                                          # rgb_loss, one launch
         n_fg = fg.samples_pos.shape[0]
         if n_fg:
             loss = loss + ((torch.linalg.norm(sdf_grad, ord=2, dim=-1) - 1.0) ** 2).mean() * hp.eikonal_weight
