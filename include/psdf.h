@@ -36,6 +36,12 @@ int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int 
     const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
     float points_scaling, float* sliced, void* stream);
 
+/* same operator; additionally sets touched_blocks[level][row >> block_rows_log2] = 1 for every table row the batch reads
+   (bytes, [nr_levels, ceil(capacity / 2^block_rows_log2)], never cleared here): what psdf_adamw_step_blocks consumes */
+int psdf_encode_forward_mark(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+    const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
+    float points_scaling, float* sliced, unsigned char* touched_blocks, int block_rows_log2, void* stream);
+
 /* replaces: permutohedral_encoding `backward_gpu` / `backward_gpu_only_pos` (autograd of models.py:186; positions grad needed by models.py:240-251) */
 int psdf_encode_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
     const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
@@ -129,6 +135,17 @@ int psdf_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, 
 int psdf_adamw_step_multi(int n_tensors, const int64_t* sizes, float* const* params, const float* const* grads, float*
     const* exp_avgs, float* const* exp_avg_sqs, float lr, float beta1, float beta2, float eps, float weight_decay, int
     step, float grad_scale, void* stream);
+
+/* replaces: the same dense update (train_permuto_sdf.py:293-304: weight_decay 0 on the lattices) restricted to the blocks
+   where it is not the identity.  The tensor is n_blocks blocks of block_elems floats; a block whose gradient and both
+   moments are exactly zero (no batch ever touched its rows) is skipped, every other block gets the dense update -- moments
+   of rows a batch does NOT touch keep decaying, as in torch.  touched [n_blocks] bytes: from psdf_encode_forward_mark,
+   consumed (reset to 0); active [n_blocks] bytes: 1 once a block has been updated; zero_grad != 0: the gradient of the
+   processed blocks is cleared in the same pass (persistent gradient buffer, no fill launch).  Bit-identical to
+   psdf_adamw_step over the whole tensor. */
+int psdf_adamw_step_blocks(int64_t n_blocks, int block_elems, float* param, float* grad, float* exp_avg, float*
+    exp_avg_sq, unsigned char* touched, unsigned char* active, float lr, float beta1, float beta2, float eps, int step,
+    float grad_scale, int zero_grad, void* stream);
 
 /* ---- sampling.hip ---- */
 /* replaces: OccupancyGrid::compute_grid_points / compute_random_sample_of_grid_points, src/OccupancyGrid.cu:88-117,179-208 */

@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_fwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
-                      int pad_points, const unsigned char* __restrict__ skip, float* __restrict__ sliced) {
+                      int pad_points, const unsigned char* __restrict__ skip, float* __restrict__ sliced,
+                      unsigned char* __restrict__ touched, int touch_shift, int blocks_per_level) {
   const int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (n >= N) return;
   if (skip && skip[n]) return;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
@@ -51,6 +52,13 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   uint32_t row[P + 1];
 #pragma unroll
   for (int r = 0; r <= P; r++) row[r] = vertex_row<P>(s, r, capacity);
+  // Training forward: remember which blocks of table rows this batch reads.  Every lattice-gradient contribution of the
+  // backward / double backward at these positions lands on exactly these rows, so the optimiser can skip blocks whose
+  // gradient and moments are still exactly zero (optim.hip: adamw_blocks_kernel) -- a superset is all it needs.
+  if (touched) {
+#pragma unroll
+    for (int r = 0; r <= P; r++) touched[(int64_t)level * blocks_per_level + (row[r] >> touch_shift)] = 1;
+  }
   float fv[P + 1][F];
 #pragma unroll
   for (int r = 0; r <= P; r++) {
@@ -790,7 +798,7 @@ int64_t psdf_encode_convention(int which) {
 static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
                                const float* lattice, const float* scale_factor, const float* shifts, const float* window,
                                int concat_points, float points_scaling, const unsigned char* skip, float* sliced,
-                               void* stream) {
+                               void* stream, unsigned char* touched = nullptr, int touch_shift = 0) {
   if (N == 0) return PSDF_OK;
   if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !sliced || !concat_ok(concat_points))
     return PSDF_ERR_ARG;
@@ -799,7 +807,8 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);
 #define FWD(P_, F_)                                                                                            \
   hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, \
-                     positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced)
+                     positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced,  \
+                     touched, touch_shift, (capacity + (1 << touch_shift) - 1) >> touch_shift)
   if (pos_dim == 3 && nr_feat == 2)
     FWD(3, 2);
   else if (pos_dim == 4 && nr_feat == 2)
@@ -859,6 +868,17 @@ static void queue_carve(void* ws, int nr_feat, int nr_levels, Queues& Q) {
   Q.rows = (uint16_t*)p;
   Q.vals = (float*)(p + rows_b);
   Q.tails = (int*)(p + rows_b + vals_b);
+}
+
+// Forward that also records the blocks of 2^block_rows_log2 table rows it reads: touched_blocks [nr_levels, ceil(capacity /
+// 2^block_rows_log2)] bytes, set to 1 (never cleared here).  See psdf_adamw_step_blocks.
+int psdf_encode_forward_mark(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
+                             const float* lattice, const float* scale_factor, const float* shifts, const float* window,
+                             int concat_points, float points_scaling, float* sliced, unsigned char* touched_blocks,
+                             int block_rows_log2, void* stream) {
+  if (!touched_blocks || block_rows_log2 < 0 || block_rows_log2 > 20) return PSDF_ERR_ARG;
+  return encode_forward_impl(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts, window,
+                             concat_points, points_scaling, nullptr, sliced, stream, touched_blocks, block_rows_log2);
 }
 
 int64_t psdf_encode_backward_workspace_bytes(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity) {

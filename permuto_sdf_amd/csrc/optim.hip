@@ -72,9 +72,76 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   adamw_range(a.n[t], a.p[t], a.g[t], a.m[t], a.v[t], lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt,
               grad_scale, ((int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x) * 4, (int64_t)gridDim.x * PSDF_BLOCK * 4);
 }
+// AdamW over a tensor cut into blocks of `block_elems` floats, skipping the blocks where the dense update is the identity:
+// a block whose gradient AND both moments are exactly zero (its rows were never touched by any batch) keeps p, m, v as they
+// are under AdamW with weight_decay = 0 -- so with `touched` (set by psdf_encode_forward_mark, a superset of the rows the
+// backward writes) and `active` (1 once a block has ever been updated: its moments keep decaying, exactly as torch's dense
+// AdamW makes them) the result is bit-for-bit what the dense kernel produces, while never-touched blocks are not even
+// read.  The gradient is zeroed in the same pass (the buffer is persistent: no allocation, no separate fill launch).
+// One wave per block, float4 per lane.
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    adamw_blocks_kernel(int64_t n_blocks, int block_elems, float* __restrict__ p, float* __restrict__ g,
+                        float* __restrict__ m, float* __restrict__ v, unsigned char* __restrict__ touched,
+                        unsigned char* __restrict__ active, float lr, float beta1, float beta2, float eps, float bias_corr1,
+                        float bias_corr2_sqrt, float grad_scale, int zero_grad) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t b = (int64_t)blockIdx.x * (PSDF_BLOCK / 64) + (threadIdx.x >> 6); b < n_blocks;
+       b += (int64_t)gridDim.x * (PSDF_BLOCK / 64)) {
+    const unsigned char t = touched[b], a = active[b];
+    if (!(t | a)) continue;   // wave-uniform
+    if (lane == 0) {
+      if (!a) active[b] = 1;
+      if (t) touched[b] = 0;
+    }
+    const int64_t base = b * block_elems;
+    for (int i = lane * 4; i < block_elems; i += 256) {
+      float4 P = *reinterpret_cast<float4*>(p + base + i);
+      float4 G = *reinterpret_cast<float4*>(g + base + i);
+      float4 M = *reinterpret_cast<float4*>(m + base + i);
+      float4 V = *reinterpret_cast<float4*>(v + base + i);
+      float* pp = &P.x;
+      const float* gp = &G.x;
+      float* mp = &M.x;
+      float* vp = &V.x;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {   // same expression order as adamw_range with weight_decay = 0
+        const float gk = gp[k] * grad_scale;
+        pp[k] = pp[k] * (1.f - lr * 0.f);
+        mp[k] = beta1 * mp[k] + (1.f - beta1) * gk;
+        vp[k] = beta2 * vp[k] + (1.f - beta2) * gk * gk;
+        const float denom = sqrtf(vp[k]) / bias_corr2_sqrt + eps;
+        pp[k] = pp[k] - (lr / bias_corr1) * (mp[k] / denom);
+      }
+      *reinterpret_cast<float4*>(p + base + i) = P;
+      *reinterpret_cast<float4*>(m + base + i) = M;
+      *reinterpret_cast<float4*>(v + base + i) = V;
+      if (zero_grad && t) *reinterpret_cast<float4*>(g + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
 }  // namespace
 
 extern "C" {
+// AdamW (weight_decay = 0) over n_blocks blocks of block_elems floats (a multiple of 4; tensors 16-byte aligned), skipping
+// never-touched blocks; `touched` / `active` are [n_blocks] bytes (touched is consumed: reset to 0), zero_grad != 0 clears
+// the gradient of the blocks it processed.  Same result as psdf_adamw_step on the whole tensor.
+int psdf_adamw_step_blocks(int64_t n_blocks, int block_elems, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                           unsigned char* touched, unsigned char* active, float lr, float beta1, float beta2, float eps,
+                           int step, float grad_scale, int zero_grad, void* stream) {
+  if (n_blocks <= 0) return PSDF_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !touched || !active || step < 1 || block_elems <= 0 || (block_elems & 3))
+    return PSDF_ERR_ARG;
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0) return PSDF_ERR_ARG;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  unsigned blocks = psdf_blocks(n_blocks, PSDF_BLOCK / 64);
+  if (blocks > 8192u) blocks = 8192u;
+  hipLaunchKernelGGL(adamw_blocks_kernel, dim3(blocks), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, n_blocks, block_elems,
+                     param, grad, exp_avg, exp_avg_sq, touched, active, lr, beta1, beta2, eps, bc1, bc2, grad_scale, zero_grad);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
 // step >= 1.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
 int psdf_adamw_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {

@@ -46,13 +46,18 @@ def _tail(cfg):
     return (L.c_i(int(cfg.concat_mode)), L.c_f(cfg.points_scaling))
 
 
-def encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window, skip=None, out=None):
+def encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window, skip=None, out=None, touched=None,
+                       block_rows_log2=7):
     """-> sliced [channels, N] (feature-major).  `skip` [N] bool/uint8: masked points are not evaluated and their columns
-    of `out` (pass a persistent buffer) stay as they are."""
+    of `out` (pass a persistent buffer) stay as they are.  `touched` [L, ceil(T / 2^block_rows_log2)] uint8: the blocks of
+    table rows this batch reads are set to 1 (training forward, see TouchedRows)."""
     L.require_cuda(positions, lattice)
     N = positions.shape[0]
     sliced = out if out is not None else torch.empty((cfg.channels, N), dtype=torch.float32, device=positions.device)
-    if skip is None:
+    if touched is not None and skip is None:
+        L.call("psdf_encode_forward_mark", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
+               L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(sliced), L.ptr(touched), L.c_i(block_rows_log2), L.stream())
+    elif skip is None:
         L.call("psdf_encode_forward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
                L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(sliced), L.stream())
     else:
@@ -84,12 +89,34 @@ def _feature_major(g):
     return gt if gt.is_contiguous() else gt.contiguous()
 
 
+class TouchedRows:
+    """Opt-in state of one encoding for the touched-rows optimiser: a PERSISTENT dense gradient buffer
+    that every backward / double backward of the step accumulates into (no `zeros_like` + add per call), and the byte map
+    of row blocks the step's forwards read.  `FusedAdamW.step` then updates only blocks that are touched or carry non-zero
+    moments and clears their gradient in the same pass (csrc/optim.hip: adamw_blocks_kernel)."""
+
+    def __init__(self, lattice, block_rows_log2=7):
+        L_, T, F = lattice.shape
+        self.block_rows_log2 = block_rows_log2
+        self.blocks_per_level = (T + (1 << block_rows_log2) - 1) >> block_rows_log2
+        if T % (1 << block_rows_log2) != 0 or ((1 << block_rows_log2) * F) % 4 != 0:
+            raise ValueError("capacity must be a multiple of the row block (2^%d rows)" % block_rows_log2)
+        self.block_elems = (1 << block_rows_log2) * F
+        self.grad = torch.zeros_like(lattice)
+        self.touched = torch.zeros((L_, self.blocks_per_level), dtype=torch.uint8, device=lattice.device)
+        self.active = torch.zeros_like(self.touched)
+
+
 class PermutoEncodingFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window):
         positions = positions.contiguous()
         window = window.contiguous()
-        sliced = encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window)
+        tr = getattr(cfg, "touched_rows", None)
+        mark = tr is not None and lattice.requires_grad and torch.is_grad_enabled()
+        sliced = encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window,
+                                    touched=tr.touched if mark else None,
+                                    block_rows_log2=tr.block_rows_log2 if mark else 7)
         ctx.cfg = cfg
         ctx.save_for_backward(scale_factor, shifts, lattice, positions, window)
         # [N, C] view of the feature-major buffer: zero copy; BLAS consumes the transposed operand natively
@@ -111,9 +138,16 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
     def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window, grad_out, need_lat, need_pos):
         g = _feature_major(grad_out)
         N = positions.shape[0]
-        g_lat = torch.zeros_like(lattice) if need_lat else None
-        g_pos = torch.zeros_like(positions) if need_pos else None
-        encode_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, g, g_lat, g_pos)
+        tr = getattr(cfg, "touched_rows", None)
+        if need_lat and tr is not None:
+            # accumulate straight into the persistent buffer; autograd sees no lattice gradient (None) for this call
+            g_pos = torch.zeros_like(positions) if need_pos else None
+            encode_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, g, tr.grad, g_pos)
+            g_lat = None
+        else:
+            g_lat = torch.zeros_like(lattice) if need_lat else None
+            g_pos = torch.zeros_like(positions) if need_pos else None
+            encode_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, g, g_lat, g_pos)
         ctx.cfg = cfg
         ctx.save_for_backward(scale_factor, shifts, lattice, positions, window, g)
         if g_lat is None:
@@ -135,11 +169,13 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
             return (None,) * 9
         N = positions.shape[0]
         dd = dd_positions.contiguous()
-        g_lat = torch.zeros_like(lattice) if need_lat else None
+        tr = getattr(cfg, "touched_rows", None)
+        buffered = need_lat and tr is not None
+        g_lat = tr.grad if buffered else (torch.zeros_like(lattice) if need_lat else None)
         gg = torch.empty_like(g)
         L.call("psdf_encode_double_backward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
                L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(dd), L.ptr(g), L.ptr(g_lat), L.ptr(gg), L.stream())
-        return None, None, None, g_lat, None, None, (gg.t() if need_g else None), None, None
+        return None, None, None, (None if buffered else g_lat), None, None, (gg.t() if need_g else None), None, None
 
 
 class PermutoEncoding(torch.nn.Module):
@@ -176,6 +212,14 @@ class PermutoEncoding(torch.nn.Module):
 
     def output_dims(self):
         return self.cfg.channels
+
+    def enable_touched_rows(self, block_rows_log2=7):
+        """Opt in to the touched-rows optimiser path (trainer only; the reference's Python keeps the plain autograd
+        semantics): lattice gradients accumulate in `self.touched_rows.grad`, `lattice_values.grad` stays None, and
+        `FusedAdamW.step` must be given this object (`optim.FusedAdamW.attach`)."""
+        self.touched_rows = TouchedRows(self.lattice_values, block_rows_log2)
+        self.cfg.touched_rows = self.touched_rows
+        return self.touched_rows
 
     def forward(self, positions, anneal_window=None):
         if positions.dim() != 2 or positions.shape[1] != self.pos_dim:

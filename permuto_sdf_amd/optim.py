@@ -11,6 +11,16 @@ class FusedAdamW(torch.optim.Optimizer):
 
     SMALL = 1 << 16  # tensors below this many elements are batched into one launch (64 per launch)
 
+    def attach(self, param, touched_rows):
+        """`param` (a lattice) is updated from `touched_rows` (encoding.TouchedRows): its persistent gradient buffer, only in
+        blocks of rows that a batch has touched or that carry non-zero moments; the gradient is cleared in the same launch.
+        Result: bit-identical to the dense update (untouched rows' moments keep decaying exactly as torch.optim.AdamW
+        makes them, train_permuto_sdf.py:293-304); blocks that no batch ever touched are never read.  Needs weight_decay 0
+        for that group (with decay every row moves every step: the dense kernel is used then)."""
+        if not hasattr(self, "_touched"):
+            self._touched = {}
+        self._touched[param] = touched_rows
+
     @torch.no_grad()
     def step(self, grad_scale=1.0):
         import ctypes
@@ -18,6 +28,27 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             small = {}   # step count -> [(p, g, m, v)]
             for p in group["params"]:
+                tr = getattr(self, "_touched", {}).get(p)
+                if tr is not None:
+                    st = self.state[p]
+                    if not st:
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p)
+                        st["exp_avg_sq"] = torch.zeros_like(p)
+                    st["step"] += 1
+                    if group["weight_decay"] != 0.0:       # every row moves: dense update from the same buffer
+                        L.call("psdf_adamw_step", L.c_l(p.numel()), L.ptr(p), L.ptr(tr.grad), L.ptr(st["exp_avg"]),
+                               L.ptr(st["exp_avg_sq"]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
+                               L.c_f(group["weight_decay"]), L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())
+                        tr.grad.zero_()
+                        tr.active.fill_(1)
+                        tr.touched.zero_()
+                    else:
+                        L.call("psdf_adamw_step_blocks", L.c_l(tr.touched.numel()), L.c_i(tr.block_elems), L.ptr(p),
+                               L.ptr(tr.grad), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(tr.touched),
+                               L.ptr(tr.active), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
+                               L.c_i(st["step"]), L.c_f(float(grad_scale)), L.c_i(1), L.stream())
+                    continue
                 if p.grad is None:
                     continue
                 if p.dtype != torch.float32 or not p.is_contiguous():

@@ -64,6 +64,20 @@ def step_seed(base_seed, rank, iteration, world=None):
     return (int(base_seed) * 1000003 + int(iteration)) * world + int(rank)
 
 
+def all_reduce_max_(t):
+    """in-place MAX all-reduce of a small tensor (the touched-block byte maps); no-op for one process"""
+    if world_size() == 1:
+        return t
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo" and t.is_cuda:      # test-only path, as in GradientBuckets
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
 class GradientBuckets:
     """Async sum all-reduce of gradient tensors, bucket by bucket; `finish()` waits for all of them."""
 

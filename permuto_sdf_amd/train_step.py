@@ -237,7 +237,7 @@ class SyntheticReel:
 
 # ------------------------------------------------------------------------------------------------------ trainer
 class Trainer:
-    def __init__(self, device, hp=None, seed=0):
+    def __init__(self, device, hp=None, seed=0, touched_rows=True):
         self.hp = hp or HyperParams()
         self.dev = torch.device(device)
         torch.manual_seed(seed)  # identical replicas on every rank
@@ -246,6 +246,14 @@ class Trainer:
         self.grid = OccupancyGrid(256, 1.0, [0, 0, 0], device=self.dev)
         self.params = [p for m in (self.sdf, self.rgb, self.bg) for p in m.parameters() if p.requires_grad]
         self.opt = FusedAdamW(self.params, lr=self.hp.lr, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+        # touched-rows path for the three 50-MB lattices: persistent gradient buffers that all backward calls
+        # of the step accumulate into, AdamW + zero-fill only over row blocks that are touched or carry non-zero moments
+        self.touched = []
+        if touched_rows:
+            for m in (self.sdf, self.rgb, self.bg):
+                tr = m.encoding.enable_touched_rows()
+                self.opt.attach(m.encoding.lattice_values, tr)
+                self.touched.append(tr)
         self.nr_rays = self.hp.nr_rays
         self.iter = 0
         self.last = {}
@@ -330,16 +338,20 @@ class Trainer:
         for p in self.params:
             p.grad = None
         loss.backward()
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        for p, g in zip(self.params, grads):
+        buffered = {id(m.encoding.lattice_values) for m in (self.sdf, self.rgb, self.bg)} if self.touched else set()
+        dense = [p for p in self.params if id(p) not in buffered]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in dense]
+        for p, g in zip(dense, grads):
             p.grad = g
         if parallel.world_size() > 1:
             buckets = parallel.GradientBuckets()
             small = [g for g in grads if g.numel() < (1 << 20)]
-            big = [g for g in grads if g.numel() >= (1 << 20)]
+            big = [g for g in grads if g.numel() >= (1 << 20)] + [tr.grad for tr in self.touched]
             buckets.reduce(small)
             for g in big:           # one bucket per lattice (50 MB): the ring is per-link bound, fewer larger messages
                 buckets.reduce([g])
+            for tr in self.touched:  # a block touched on ANY rank carries a gradient after the sum: OR of the byte maps
+                parallel.all_reduce_max_(tr.touched)
             buckets.finish()
         self.opt.step(grad_scale=1.0 / parallel.world_size())
         # ---- occupancy refresh, every 8th step, same random voxels on every rank (train_permuto_sdf.py:386-391)

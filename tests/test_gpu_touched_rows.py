@@ -1,0 +1,107 @@
+"""touched-rows AdamW.  Semantics, stated: the update is the reference's dense torch.optim.AdamW
+(train_permuto_sdf.py:293-304: betas (0.9, 0.99), eps 1e-15, weight_decay 0 on the lattices) -- moments of rows a batch does
+not touch KEEP DECAYING and keep moving the parameter, exactly as torch does -- and only the blocks of table rows that no
+batch has ever touched (gradient and both moments exactly zero, where the dense update is the identity) are skipped.
+Checked here: (1) the forward's touched map covers every row the backward / double backward writes; (2) several training
+steps with changing batches are BIT-IDENTICAL to torch.optim.AdamW on a dense autograd gradient; (3) how much is skipped."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc(dev, L_=12, T=2 ** 14, seed=0):
+    from permuto_sdf_amd import PermutoEncoding
+    torch.manual_seed(seed)
+    return PermutoEncoding(3, T, L_, 2, np.geomspace(1.0, 1e-3, L_), concat_points=True, concat_points_scaling=1e-3,
+                           init_scale=1e-2).to(dev)
+
+
+def _loss(enc, w1, pts, win):
+    """first- and second-order use of the encoding, like the SDF net's eikonal term (models.py:236-251)"""
+    pts = pts.clone().requires_grad_(True)
+    sdf = torch.tanh(enc(pts, win) @ w1).sum(1, keepdim=True)
+    (grad,) = torch.autograd.grad(sdf, pts, torch.ones_like(sdf), create_graph=True)
+    return (sdf ** 2).mean() + ((grad.norm(dim=1) - 1.0) ** 2).mean() * 0.1
+
+
+def test_touched_map_covers_every_written_row(dev):
+    enc = _enc(dev)
+    tr = enc.enable_touched_rows(block_rows_log2=5)
+    win = torch.ones(12, device=dev)
+    w1 = torch.randn(enc.output_dims(), 3, device=dev)
+    pts = (torch.rand(3000, 3, device=dev) - 0.5) * 0.6
+    _loss(enc, w1, pts, win).backward()
+    assert enc.lattice_values.grad is None                       # the gradient went to the persistent buffer
+    g = tr.grad
+    assert float(g.abs().max()) > 0
+    rows = (g != 0).any(-1)                                      # [L, T]
+    blocks = rows.view(12, -1, 32).any(-1)
+    assert bool((tr.touched.bool() | ~blocks).all())             # written => touched
+    frac = float(tr.touched.float().mean())
+    assert 0.0 < frac < 0.9                                      # and the map is not trivially "everything"
+    # no-grad forwards (occupancy refresh, importance sampling) do not mark
+    before = tr.touched.clone()
+    with torch.no_grad():
+        enc((torch.rand(5000, 3, device=dev) - 0.5) * 1.9, win)
+    assert torch.equal(before, tr.touched)
+
+
+def test_block_adamw_is_bit_identical_to_dense_torch_adamw(dev):
+    from permuto_sdf_amd.optim import FusedAdamW
+    win = torch.ones(12, device=dev)
+    ref, ours = _enc(dev, seed=3), _enc(dev, seed=3)
+    assert torch.equal(ref.lattice_values, ours.lattice_values)
+    w1 = torch.randn(ref.output_dims(), 3, device=dev)
+    opt_ref = torch.optim.AdamW([ref.lattice_values], lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+    opt = FusedAdamW([ours.lattice_values], lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+    dense_fused = FusedAdamW([ref.lattice_values], lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+    tr = ours.enable_touched_rows()
+    opt.attach(ours.lattice_values, tr)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    # the reference semantic with the SAME gradients: dense FusedAdamW (== torch.optim.AdamW, tests/test_gpu_optim.py) fed
+    # the buffer's gradient; then torch.optim.AdamW itself on an autograd gradient within rounding of the scatter order
+    ref2 = _enc(dev, seed=3)
+    opt_t = torch.optim.AdamW([ref2.lattice_values], lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+    skipped = []
+    for it in range(6):
+        # batches move: rows touched in one step are NOT touched in a later one, their moments must keep decaying
+        centre = torch.tensor([[0.3 * np.cos(it), 0.3 * np.sin(it), 0.0]])
+        pts = ((torch.rand(2000, 3, generator=g) - 0.5) * 0.25 + centre).to(dev)
+        _loss(ours, w1, pts, win).backward()
+        _loss(ours, w1, pts * 0.5, win).backward()                # two backward calls accumulate into the one buffer
+        grad = tr.grad.clone()
+        ref.lattice_values.grad = grad.clone()
+        dense_fused.step()
+        ref2.lattice_values.grad = grad.clone()
+        opt_t.step()
+        skipped.append(1.0 - float((tr.touched | tr.active).float().mean()))
+        opt.step()
+        assert float(tr.grad.abs().max()) == 0.0 and int(tr.touched.sum()) == 0      # zero-fill fused into the update
+        assert torch.equal(ours.lattice_values, ref.lattice_values), it               # bit-identical to the dense kernel
+        assert torch.allclose(ours.lattice_values, ref2.lattice_values, rtol=0, atol=2e-7), it   # and to torch.optim.AdamW
+    st, st_ref = opt.state[ours.lattice_values], dense_fused.state[ref.lattice_values]
+    assert torch.equal(st["exp_avg"], st_ref["exp_avg"]) and torch.equal(st["exp_avg_sq"], st_ref["exp_avg_sq"])
+    # rows touched only in step 0 still have (decayed, non-zero) moments: untouched rows are NOT frozen
+    assert float(st["exp_avg"].abs().max()) > 0
+    assert skipped[0] > 0.3 and skipped[-1] > 0.1, skipped       # a real share of the table is never read
+
+
+def test_trainer_steps_with_and_without_touched_rows_agree(dev):
+    """the cfg-4 trainer: same seeds, touched-rows path on / off -> same parameters after 3 steps (scatter order aside)"""
+    from permuto_sdf_amd.train_step import SyntheticReel, Trainer
+    reel = SyntheticReel(dev, nr_images=4, height=60, width=80)
+    out = []
+    for flag in (True, False):
+        from permuto_sdf_amd.bridge import OccupancyGrid, RaySampler, VolumeRendering
+        for cls in (OccupancyGrid, RaySampler, VolumeRendering):          # same jitter streams for both runs
+            cls._rng = type(cls._rng)()
+        tr = Trainer(dev, seed=1, touched_rows=flag)
+        tr.nr_rays = 128
+        for _ in range(3):
+            loss = tr.step(reel)
+        out.append((float(loss), tr.sdf.encoding.lattice_values.detach().clone(), tr.rgb.encoding.lattice_values.detach().clone()))
+    assert abs(out[0][0] - out[1][0]) <= 1e-4 * abs(out[1][0])
+    for a, b in ((out[0][1], out[1][1]), (out[0][2], out[1][2])):
+        assert float((a - b).abs().max()) <= 5e-5           # lr 1e-3 steps: sign flips of tiny gradients move a value by ~2e-3 at most; typical agreement is exact
