@@ -128,7 +128,8 @@ class PermutoEncodingFunc(torch.autograd.Function):
         need_lat, need_pos = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
         g_lat, g_pos = PermutoEncodingBackFunc.apply(ctx.cfg, scale_factor, shifts, lattice, positions, window,
                                                      grad_out, need_lat, need_pos)
-        return None, None, None, (g_lat if need_lat else None), (g_pos if need_pos else None), None
+        # buffered mode (TouchedRows): the lattice gradient went into the persistent buffer, autograd gets None
+        return None, None, None, (g_lat if (need_lat and g_lat.dim() > 0) else None), (g_pos if need_pos else None), None
 
 
 class PermutoEncodingBackFunc(torch.autograd.Function):

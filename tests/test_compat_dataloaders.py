@@ -94,3 +94,48 @@ def test_neus_layout_scene_round_trip(dl, tmp_path):
     c0 = np.linalg.inv(frames[0].tf_cam_world.m)[:3, 3]
     c1 = lo2.get_all_frames()[0].tf_cam_world.inverse().translation()
     assert abs(np.linalg.norm(c1) - 0.4 * np.linalg.norm(c0)) < 1e-4
+
+
+def test_mesh_export_marching_tetrahedra_and_ply(tmp_path):
+    """compat/skimage.measure.marching_cubes + compat/easypbr.Mesh.save_to_file: the pieces the reference's mesh export
+    (sdf_utils.py:252-292, create_my_meshes.py:162) needs; on an analytic sphere: watertight, genus 0, right area."""
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "compat", *rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    measure = load("psdf_compat_measure", ("skimage", "measure.py"))
+    n = 64
+    t = np.linspace(-0.5, 0.5, n, dtype=np.float32)
+    x, y, z = np.meshgrid(t, t, t, indexing="ij")
+    vol = np.sqrt(x * x + y * y + z * z) - 0.3
+    V, F, N, vals = measure.marching_cubes(vol, 0.0)
+    assert V.dtype == np.float32 and F.dtype == np.int32 and V.shape[1] == 3 and F.shape[1] == 3 and len(N) == len(V)
+    P = V / (n - 1.0) - 0.5                                        # the reference's index -> world mapping (sdf_utils.py:279)
+    assert np.abs(np.linalg.norm(P, axis=1) - 0.3).max() < 1e-3
+    e = np.sort(np.concatenate([F[:, [0, 1]], F[:, [1, 2]], F[:, [2, 0]]]), 1)
+    u, c = np.unique(e, axis=0, return_counts=True)
+    assert (c == 2).all() and len(V) - len(u) + len(F) == 2        # closed 2-manifold, Euler characteristic of a sphere
+    fn = np.cross(P[F[:, 1]] - P[F[:, 0]], P[F[:, 2]] - P[F[:, 0]])
+    assert ((fn * P[F].mean(1)).sum(1) > 0).all()                  # faces wind outwards
+    assert ((N * P).sum(1) < 0).all()                              # 'descent' normals (the reference negates them)
+    assert abs(0.5 * np.linalg.norm(fn, axis=1).sum() - 4 * np.pi * 0.09) < 2e-3
+    with pytest.raises(ValueError):
+        measure.marching_cubes(vol, 10.0)
+    sys.path.insert(0, os.path.join(ROOT, "compat"))
+    try:
+        easypbr = load("psdf_compat_easypbr", ("easypbr", "__init__.py"))
+    finally:
+        sys.path.remove(os.path.join(ROOT, "compat"))
+    mesh = easypbr.Mesh()
+    mesh.V, mesh.F, mesh.NV = P, F, -N
+    out = tmp_path / "sphere.ply"
+    mesh.save_to_file(str(out))
+    raw = out.read_bytes()
+    head, body = raw.split(b"end_header\n")
+    assert b"element vertex %d" % len(V) in head and b"element face %d" % len(F) in head and b"property float nx" in head
+    assert len(body) == len(V) * 24 + len(F) * 13
+    back = np.frombuffer(body[:len(V) * 24], dtype="<f4").reshape(-1, 6)
+    assert np.array_equal(back[:, :3], P.astype(np.float32))
+    mesh.save_to_file(str(tmp_path / "sphere.obj"))
+    assert (tmp_path / "sphere.obj").read_text().count("\nf ") + 1 >= len(F)
