@@ -61,6 +61,13 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced, float* grad_lattice,
     float* grad_grad_sliced, void* stream);
 
+/* ---- mlp_bwd_split.hip ---- */
+/* same contract as psdf_mlp_backward for dims = {K0 <= 36, 64, 64, 64, 1} with dW/db requested, computed on the bf16 matrix
+   pipe with split fp32 operands (three bf16 pieces, six products kept: fp32-level accuracy); -2 for every other net and when
+   stream-ordered scratch is unavailable (stream capture).  psdf_mlp_backward routes large batches here by itself. */
+int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+    const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
+
 /* ---- neus.hip ---- */
 /* replaces: the torch elementwise chain of VolumeRenderingNeus.compute_weights, permuto_sdf_py/volume_rendering/
    volume_rendering_modules.py:129-172 (cos anneal, section-point SDFs, two sigmoids, (p+1e-5)/(c+1e-5) clipped to [0,1]);

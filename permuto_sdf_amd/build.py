@@ -20,6 +20,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics
          "--offload-arch=" + ARCH]
 
 
+# per-file extra flags.  mlp_bwd_split.hip: let MFMAs write plain VGPRs, so that only the persistent accumulators live in
+# AGPRs (otherwise every chain / transpose result is copied out with v_accvgpr_read and the kernel spills; the flag crashes
+# this compiler on mlp_bwd.hip, hence per file)
+EXTRA = {"mlp_bwd_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -47,7 +53,7 @@ def build(force=False, verbose=True):
         objs.append(o)
         stale = force or _newer(s, o) or any(_newer(h, o) for h in headers) or _newer(__file__, o)
         if stale:
-            jobs.append([hipcc] + FLAGS + ["-I", CSRC, "-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-I", CSRC, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -28,6 +28,7 @@
 //   weights in LDS: see struct Img below (separate forward / transposed images read 128 bits at a time); the images
 //   are built by the kernel itself from the torch-layout parameters (no separate packing pass).  The packed layout of
 //   Plan16 (row stride 65) is only the layout of the GRADIENT image the workgroup flushes at the end.
+#include <cstdlib>
 #include "mlp_device.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1117,6 +1118,10 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
 
 extern "C" {
 
+int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                            const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                            void* stream);   // mlp_bwd_split.hip
+
 // Backward of psdf_mlp_forward.  weights[l] / biases[l]: the torch-layout parameters (W_l [dims[l+1], dims[l]]);
 // X [dims[0], N], dY [dims[n_layers], N] and dX [dims[0], N] (or NULL) are feature-major; dW[l] (torch layout) and
 // db[l] are ACCUMULATED INTO (caller zero-fills); pass dW = db = NULL for the data gradient only (a lighter kernel).
@@ -1129,6 +1134,19 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   if (N == 0) return PSDF_OK;
   if (N < 0 || !X || !weights || !biases || !dY || ((dW == nullptr) != (db == nullptr))) return PSDF_ERR_ARG;
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
+  // Large batches of the BASELINE net (<= 36 inputs, 64x3, 1 output) with parameter gradients: the split-bf16 kernel on
+  // the bf16 matrix pipe (mlp_bwd_split.hip; same contract, fp32-level accuracy).  PSDF_MLP_BWD_SPLIT=0 keeps the fp32-MFMA
+  // kernel below; -2 from the split entry (other widths, no stream-ordered scratch) falls through to it as well.
+  if (dW && N >= (1 << 18)) {
+    static const bool enabled = [] {
+      const char* v = getenv("PSDF_MLP_BWD_SPLIT");
+      return !(v && v[0] == '0');
+    }();
+    if (enabled) {
+      const int r = psdf_mlp_backward_split(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
+      if (r != PSDF_ERR_UNSUPPORTED) return r;
+    }
+  }
   BwdPtrs a;
   a.partial = nullptr;
   for (int l = 0; l < MAXL; l++) {

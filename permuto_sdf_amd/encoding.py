@@ -109,11 +109,11 @@ class TouchedRows:
 
 class PermutoEncodingFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window):
+    def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window, mark=False):
         positions = positions.contiguous()
         window = window.contiguous()
         tr = getattr(cfg, "touched_rows", None)
-        mark = tr is not None and lattice.requires_grad and torch.is_grad_enabled()
+        mark = mark and tr is not None       # decided by the caller: grad mode is always off inside Function.forward
         sliced = encode_forward_raw(cfg, positions, lattice, scale_factor, shifts, window,
                                     touched=tr.touched if mark else None,
                                     block_rows_log2=tr.block_rows_log2 if mark else 7)
@@ -129,7 +129,7 @@ class PermutoEncodingFunc(torch.autograd.Function):
         g_lat, g_pos = PermutoEncodingBackFunc.apply(ctx.cfg, scale_factor, shifts, lattice, positions, window,
                                                      grad_out, need_lat, need_pos)
         # buffered mode (TouchedRows): the lattice gradient went into the persistent buffer, autograd gets None
-        return None, None, None, (g_lat if (need_lat and g_lat.dim() > 0) else None), (g_pos if need_pos else None), None
+        return None, None, None, (g_lat if (need_lat and g_lat.dim() > 0) else None), (g_pos if need_pos else None), None, None
 
 
 class PermutoEncodingBackFunc(torch.autograd.Function):
@@ -233,8 +233,9 @@ class PermutoEncoding(torch.nn.Module):
             if anneal_window.numel() != self.nr_levels:
                 raise ValueError("anneal_window must have nr_levels entries")
         positions = positions.to(torch.float32)
+        mark = torch.is_grad_enabled() and self.lattice_values.requires_grad      # a forward whose backward will run
         return PermutoEncodingFunc.apply(self.cfg, self.scale_factor, self.random_shift_per_level.detach(),
-                                         self.lattice_values, positions, anneal_window)
+                                         self.lattice_values, positions, anneal_window, mark)
 
     def forward_feature_major(self, positions, anneal_window=None):
         """No-grad fast path used by the fused evaluators: returns the [channels, N] buffer itself."""

@@ -101,9 +101,24 @@ def backward_supported(dims):
                    (4, 4, 4, 4, 3, False), (5, 4, 4, 0, 1, True), (3, 2, 2, 2, 3, False), (3, 4, 4, 4, 3, False)}
 
 
+_ANNOUNCED = set()
+
+
+def _announce(kind, dims):
+    """say ONCE per (operator, widths) that a net is served by torch/rocBLAS on the GPU instead of a fused kernel"""
+    key = (kind, tuple(dims))
+    if key not in _ANNOUNCED:
+        _ANNOUNCED.add(key)
+        import warnings
+        warnings.warn("permuto_sdf_amd: no fused %s kernel is instantiated for the MLP widths %s; using torch autograd over "
+                      "rocBLAS on the GPU for it (csrc/mlp_bwd.hip lists the instantiated widths)" % (kind, list(dims)),
+                      RuntimeWarning, stacklevel=3)
+
+
 def _torch_gpu_backward(dims, x_fm, weights, biases, gy_fm, need_dx):
     """Backward for widths the fused kernel family does not cover yet (the 128-wide colour net): the same
     Linear/GELU stack re-evaluated with torch ops ON THE GPU (rocBLAS) under autograd.  Not a CPU path."""
+    _announce("backward", dims)
     n_layers = len(dims) - 1
     with torch.enable_grad():
         x = x_fm.t().detach().requires_grad_(need_dx)
@@ -124,6 +139,7 @@ def _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
     """VJP of the map (x, params) -> dx = J_x^T gy with the upstream gradient v (what differentiating through the
     analytic input gradient needs: eikonal / curvature losses, models.py:245-251), by torch autograd ON THE GPU.
     Generic fallback for widths without a fused double-backward kernel.  -> (dX [C,N], [dW_l], [db_l])"""
+    _announce("double backward", dims)
     n_layers = len(dims) - 1
     with torch.enable_grad():
         x = x_fm.t().detach().requires_grad_(True)
@@ -186,6 +202,7 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         else:
             dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, need_dx)
         ctx.module, ctx.n_layers = module, n_layers
+        ctx.set_materialize_grads(False)      # unused outputs (dW, db are never differentiated) arrive as None in backward
         ctx.save_for_backward(x_fm, gy_fm, *weights, *biases)
         if dx is None:
             dx_out = torch.zeros((), device=x.device)
@@ -200,6 +217,13 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         x_fm, gy_fm = ctx.saved_tensors[0], ctx.saved_tensors[1]
         weights = ctx.saved_tensors[2:2 + n_layers]
         biases = ctx.saved_tensors[2 + n_layers:]
+        # Only the path the reference needs is implemented: d<dx, v>/d(x, params) with gy a CONSTANT (models.py:240-251 passes
+        # ones).  The two others would be silently wrong gradients, so they raise.
+        if any(g is not None for g in g_params):
+            raise NotImplementedError("FusedMLP: differentiating through the parameter gradients (dW, db) is not implemented")
+        if ctx.needs_input_grad[3] and g_dx is not None:
+            raise NotImplementedError("FusedMLP: the upstream gradient of the MLP output requires grad (a differentiable "
+                                      "function of the output is being differentiated twice); the J_x v term is not implemented")
         if g_dx is None:
             return (None,) * (4 + 2 * n_layers)
         v_fm = g_dx.t()

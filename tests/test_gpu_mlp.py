@@ -221,3 +221,74 @@ def test_data_gradient_only_variant(dev, dims):
     dx_only, none_w, none_b = mlp_backward_raw(dims, x, ws, bs, gy, need_dw=False)
     assert none_w == [] and none_b == [] and len(dWs) == len(dims) - 1
     assert torch.equal(dx_full, dx_only)
+
+
+def test_unimplemented_second_order_terms_raise(dev):
+    """ADVICE r1: `_FusedMLPBackFunc.backward` only implements the reference's path (gy constant, models.py:240-251);
+    an upstream gradient that requires grad must raise instead of silently dropping the J_x v term"""
+    from permuto_sdf_amd import FusedMLP
+    torch.manual_seed(0)
+    mlp = FusedMLP([36, 32, 32, 32, 1]).to(dev)
+    x = torch.randn(512, 36, device=dev, requires_grad=True)
+    scale = torch.ones(1, device=dev, requires_grad=True)
+    y = mlp(x)
+    (gx,) = torch.autograd.grad(y, x, torch.ones_like(y) * scale, create_graph=True)      # gy depends on a leaf
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        gx.pow(2).sum().backward()
+    # the supported path still works
+    y = mlp(x)
+    (gx,) = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=True)
+    gx.pow(2).sum().backward()
+    assert mlp.layers[0].weight.grad is not None and torch.isfinite(mlp.layers[0].weight.grad).all()
+
+
+@pytest.mark.parametrize("K0,N", [(36, 300_001), (35, 262_160), (20, 270_000), (36, 1_000)])
+def test_split_bf16_backward_matches_float64(dev, K0, N):
+    """csrc/mlp_bwd_split.hip (the BASELINE 64x3 -> 1 net on the bf16 matrix pipe, three bf16 pieces per fp32 operand, six
+    products): every gradient against a float64 evaluation, and no worse than 4x the error of torch's own fp32 backward.
+    Called through the C ABI entry itself (psdf_mlp_backward routes batches >= 2^18 to it); ragged N, K0 not a multiple of 4."""
+    import ctypes
+    from permuto_sdf_amd import _lib as L
+    from permuto_sdf_amd.mlp import _dims_array, _zero_grads
+    torch.manual_seed(K0 + N % 7)
+    dims = [K0, 64, 64, 64, 1]
+    lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
+    for l in lin:
+        torch.nn.init.normal_(l.bias, 0.0, 0.1)
+    net = torch.nn.Sequential(lin[0], torch.nn.GELU(), lin[1], torch.nn.GELU(), lin[2], torch.nn.GELU(), lin[3]).to(dev)
+    x = torch.randn(N, K0, device=dev)
+    gy = torch.randn(N, 1, device=dev)
+    # float64 truth and torch's fp32 backward
+    net64 = torch.nn.Sequential(*[m for m in net]).double()
+    import copy
+    net64 = copy.deepcopy(net).double()
+    x64 = x.double().requires_grad_(True)
+    net64(x64).backward(gy.double())
+    ref = [x64.grad] + [p.grad for p in net64.parameters()]
+    x32 = x.clone().requires_grad_(True)
+    net(x32).backward(gy)
+    t32 = [x32.grad] + [p.grad for p in net.parameters()]
+    # the kernel
+    x_fm, gy_fm = x.t().contiguous(), gy.t().contiguous()
+    ws = [m.weight.detach().contiguous() for m in net if isinstance(m, torch.nn.Linear)]
+    bs = [m.bias.detach().contiguous() for m in net if isinstance(m, torch.nn.Linear)]
+    dx = torch.empty((K0, N), device=dev)
+    dWs, dbs = _zero_grads(dims, dev)
+    arr = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    fn = L.lib().psdf_mlp_backward_split
+    fn.restype = ctypes.c_int
+    rc = fn(L.c_i(4), _dims_array(dims), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx), arr(dWs), arr(dbs),
+            L.stream())
+    assert rc == 0, rc
+    got = [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
+    names = ["dX", "dW1", "db1", "dW2", "db2", "dW3", "db3", "dW4", "db4"]
+    for name, g, r, t in zip(names, got, ref, t32):
+        scale = float(r.abs().max())
+        err = float((g.double() - r).abs().max()) / scale
+        err_t = float((t.double() - r).abs().max()) / scale
+        assert err <= max(4 * err_t, 2e-6), (name, err, err_t)
+    # unsupported shapes say so (-2) and leave the fp32 kernel to do the work
+    assert fn(L.c_i(4), _dims_array([52, 64, 64, 64, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
+              arr(dWs), arr(dbs), L.stream()) == -2
+    assert fn(L.c_i(4), _dims_array([36, 32, 32, 32, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
+              arr(dWs), arr(dbs), L.stream()) == -2
