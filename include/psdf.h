@@ -68,6 +68,15 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
 int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
     const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 
+/* ---- mlp_wide.hip ---- */
+/* same contract as psdf_mlp_backward for 4-layer nets wider than one wave's register file holds (dims[0] <= 112, dims[1],
+   dims[2] <= 128, dims[3] <= 64, dims[4] <= 16): the colour network LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3 of
+   permuto_sdf_py/models/models.py:54-129,349-350 (weights = the already normalised ones).  Workgroup-cooperative: 8 waves
+   share a 32-sample tile through LDS, each owns one output tile per layer.  -2 for other widths / no stream-ordered scratch;
+   psdf_mlp_backward falls through to it. */
+int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+    const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
+
 /* ---- neus.hip ---- */
 /* replaces: the torch elementwise chain of VolumeRenderingNeus.compute_weights, permuto_sdf_py/volume_rendering/
    volume_rendering_modules.py:129-172 (cos anneal, section-point SDFs, two sigmoids, (p+1e-5)/(c+1e-5) clipped to [0,1]);

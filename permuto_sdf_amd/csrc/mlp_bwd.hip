@@ -1121,6 +1121,9 @@ extern "C" {
 int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
                             const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
                             void* stream);   // mlp_bwd_split.hip
+int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                           const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                           void* stream);    // mlp_wide.hip
 
 // Backward of psdf_mlp_forward.  weights[l] / biases[l]: the torch-layout parameters (W_l [dims[l+1], dims[l]]);
 // X [dims[0], N], dY [dims[n_layers], N] and dX [dims[0], N] (or NULL) are feature-major; dW[l] (torch layout) and
@@ -1175,6 +1178,8 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   CASE(3, 4, 4, 4, 3, false)  // 36 -> 64x3 -> 33
   CASE(5, 4, 4, 0, 1, true)   // 80 -> 64x2 -> 3          (background colour head, models.py:463-469)
 #undef CASE
+  // nets too wide for one wave's registers (the 128-wide colour network): workgroup-cooperative kernel, mlp_wide.hip
+  if (dW) return psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
   return PSDF_ERR_UNSUPPORTED;
 }
 

@@ -1,0 +1,367 @@
+// Fused backward (with forward recompute) of the WIDE colour network: LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3 of the reference
+// (permuto_sdf_py/models/models.py:54-129, 349-350; the largest GEMM of the training step: 77 952 FLOP/sample forward).
+//
+// The narrow nets keep their whole weight-gradient accumulator in one wave's registers (mlp_bwd.hip); 39 303 parameters do
+// not fit (608 registers), and the 157-KB fp32 weight set does not fit LDS beside the activations either.  So here a
+// WORKGROUP of 8 waves (two per SIMD) owns a tile of 32 samples and the waves split every layer by OUTPUT tile (16 rows):
+//   * activations, their GELU derivatives (overwritten in place by dZ) and the upstream gradient live in LDS as
+//     [feature][32 samples] (row stride 36 floats): the SAME buffer is the B operand of the chain (lane = sample, 4 features
+//     per read) and, read the other way (lane = feature, one 128-bit read = 4 samples), both operands of dW = dZ H^T --
+//     no transposes anywhere;
+//   * weights are streamed from L2 as MFMA A operands, 128 bits per lane = 4 MFMAs (W for the forward, W^T -- written once
+//     per call by the pack kernel, which also applies the Lipschitz normalisation -- for dH); every weight byte is used for
+//     32 samples, ~10 KB of L2 traffic per sample;
+//   * each wave keeps the dW rows of ITS output tile in registers for the whole kernel (<= 108 registers) and they leave as
+//     one gradient image per workgroup, summed by a second launch;
+//   * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products, no operand splitting; the batch is ~49 k samples per step, the
+//     kernel is latency / launch bound, not matrix bound.
+// One barrier per layer and direction (8 per tile).
+#include "psdf_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int WN = 8;        // waves per workgroup
+constexpr int TS = 32;       // samples per workgroup tile (two 16-sample MFMA column blocks)
+constexpr int RS = 36;       // LDS row stride in floats (144 B: 128-bit reads of 16 consecutive rows spread over the banks)
+
+__device__ __forceinline__ float erf_w(float a) {   // < 1 ulp (same polynomial as mlp_device.h)
+  const float t = fabsf(a), s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float hi = copysignf(1.0f - __expf(r), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  const float lo = fmaf(q, a, a);
+  return t > 0.927734375f ? hi : lo;
+}
+__device__ __forceinline__ void gelu_both_w(float z, float& h, float& gp) {
+  const float cdf = fmaf(0.5f, erf_w(z * 0.70710678118654752440f), 0.5f);
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+  h = z * cdf;
+  gp = fmaf(z, pdf, cdf);
+}
+
+struct WideArgs {
+  const float* W[4];    // normalised weights, row major [out][in_pad]  (in_pad = 16 * tiles of the input)
+  const float* WT[4];   // their transposes [in_pad][out_pad]
+  const float* b[4];
+  int dims[5];          // true widths
+};
+
+// One layer forward for the wave's own output tile `t`: Z[16 rows][32 samples] = W[rows][:] * In + bias, GELU (unless last),
+// H and gelu' go to LDS.  In/H/G are LDS [feature][RS].
+template <int TIN, bool ACT>
+__device__ __forceinline__ void layer_fwd(const float* __restrict__ W, int in_pad, const float* __restrict__ bias, int out_true,
+                                          int t, const float* __restrict__ In, float* __restrict__ H, float* __restrict__ G,
+                                          int c, int g) {
+  f32x4 acc[2];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = 16 * t + 4 * g + r;
+    const float bv = row < out_true ? bias[row] : 0.f;
+    acc[0][r] = bv;
+    acc[1][r] = bv;
+  }
+  const float* wrow = W + (size_t)(16 * t + c) * in_pad + 4 * g;
+#pragma unroll 2
+  for (int kg = 0; kg < TIN; kg++) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(wrow + 16 * kg);      // k = 16 kg + 4 g + j
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float* in = In + (16 * kg + 4 * g + j) * RS + c;
+      acc[0] = MFMA4(a4[j], in[0], acc[0]);
+      acc[1] = MFMA4(a4[j], in[16], acc[1]);
+    }
+  }
+#pragma unroll
+  for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * t + 4 * g + r;
+      float h = acc[sb][r], gp = 1.f;
+      if (ACT) gelu_both_w(acc[sb][r], h, gp);
+      H[row * RS + 16 * sb + c] = h;
+      if (G) G[row * RS + 16 * sb + c] = gp;
+    }
+}
+
+// dW[own tile `to`][all input tiles] += dZ_l(own rows) * H_{l-1}^T over the 32 samples; db += row sums
+template <int TIN>
+__device__ __forceinline__ void layer_dw(const float* __restrict__ D, const float* __restrict__ Hin, int to, f32x4 (&dW)[TIN],
+                                         float& db, int c, int g) {
+#pragma unroll
+  for (int sb = 0; sb < 2; sb++) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(D + (16 * to + c) * RS + 16 * sb + 4 * g);   // samples 16 sb + 4 g + j
+    db += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+#pragma unroll
+    for (int ti = 0; ti < TIN; ti++) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(Hin + (16 * ti + c) * RS + 16 * sb + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; j++) dW[ti] = MFMA4(a4[j], b4[j], dW[ti]);
+    }
+  }
+}
+
+// dH_{l-1}[own input tile `ti`] = W_l^T dZ_l, then * gelu'(z_{l-1}) in place (G -> dZ), or to global dX for the first layer
+template <int TOUT>
+__device__ __forceinline__ void layer_dh(const float* __restrict__ WT, int out_pad, int ti, const float* __restrict__ D,
+                                         f32x4 (&acc)[2], int c, int g) {
+  acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+  acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wrow = WT + (size_t)(16 * ti + c) * out_pad + 4 * g;
+#pragma unroll 2
+  for (int kg = 0; kg < TOUT; kg++) {
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(wrow + 16 * kg);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float* d = D + (16 * kg + 4 * g + j) * RS + c;
+      acc[0] = MFMA4(a4[j], d[0], acc[0]);
+      acc[1] = MFMA4(a4[j], d[16], acc[1]);
+    }
+  }
+}
+
+// gradient image of one workgroup (floats): dW1 [T1*16][TI0*16], dW2 [T2*16][T1*16], dW3 [T3*16][T2*16], dW4 [16][T3*16],
+// then db1, db2, db3, db4 (padded widths)
+template <int TI0, int T1, int T2, int T3>
+struct GImg {
+  static constexpr int W1 = 0, W2 = W1 + T1 * 16 * TI0 * 16, W3 = W2 + T2 * 16 * T1 * 16, W4 = W3 + T3 * 16 * T2 * 16,
+                       B1 = W4 + 16 * T3 * 16, B2 = B1 + T1 * 16, B3 = B2 + T2 * 16, B4 = B3 + T3 * 16, TOTAL = B4 + 16;
+};
+
+template <int TI0, int T1, int T2, int T3>
+__global__ void __launch_bounds__(WN * 64, 1)
+    mlp_wide_bwd_kernel(WideArgs a, int64_t N, const float* __restrict__ X, const float* __restrict__ dY,
+                        float* __restrict__ dX, float* __restrict__ partial) {
+  static_assert(TI0 <= WN && T1 <= WN && T2 <= WN && T3 <= WN, "one output tile per wave and layer");
+  extern __shared__ __align__(16) float lds[];
+  float* H0 = lds;                         // [TI0*16][RS]   inputs
+  float* H1 = H0 + TI0 * 16 * RS;          // activations
+  float* H2 = H1 + T1 * 16 * RS;
+  float* H3 = H2 + T2 * 16 * RS;
+  float* D1 = H3 + T3 * 16 * RS;           // gelu' of the layer, overwritten by dZ
+  float* D2 = D1 + T1 * 16 * RS;
+  float* D3 = D2 + T2 * 16 * RS;
+  float* D4 = D3 + T3 * 16 * RS;           // [16][RS]: upstream gradient of the (linear) last layer, rows >= out are zero
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int K0 = a.dims[0], OUT = a.dims[4];
+  const int in_pad[4] = {TI0 * 16, T1 * 16, T2 * 16, T3 * 16};
+  f32x4 dW1[TI0], dW2[T1], dW3[T2], dW4[T3];
+#pragma unroll
+  for (int i = 0; i < TI0; i++) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < T1; i++) dW2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < T2; i++) dW3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < T3; i++) dW4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db1 = 0.f, db2 = 0.f, db3 = 0.f, db4 = 0.f;
+  const int64_t ntiles = (N + TS - 1) / TS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();   // the previous tile's last readers are done with the buffers
+    // ---- stage X rows (zero beyond K0 / N) and dY
+    for (int e = threadIdx.x; e < TI0 * 16 * TS; e += WN * 64) {
+      const int row = e / TS, s = e % TS;
+      const int64_t n = n0 + s;
+      H0[row * RS + s] = (row < K0 && n < N) ? X[(int64_t)row * N + n] : 0.f;
+    }
+    for (int e = threadIdx.x; e < 16 * TS; e += WN * 64) {
+      const int row = e / TS, s = e % TS;
+      const int64_t n = n0 + s;
+      D4[row * RS + s] = (row < OUT && n < N) ? dY[(int64_t)row * N + n] : 0.f;
+    }
+    __syncthreads();
+    // ---- forward
+    if (wave < T1) layer_fwd<TI0, true>(a.W[0], in_pad[0], a.b[0], a.dims[1], wave, H0, H1, D1, c, g);
+    __syncthreads();
+    if (wave < T2) layer_fwd<T1, true>(a.W[1], in_pad[1], a.b[1], a.dims[2], wave, H1, H2, D2, c, g);
+    __syncthreads();
+    if (wave < T3) layer_fwd<T2, true>(a.W[2], in_pad[2], a.b[2], a.dims[3], wave, H2, H3, D3, c, g);
+    __syncthreads();
+    // (the last layer's output is not needed: the upstream gradient is given)
+    // ---- backward, layer 4 (linear): dW4, db4 by wave 0; dH3 -> dZ3 by the owners of H3's tiles
+    if (wave == 0) layer_dw<T3>(D4, H3, 0, dW4, db4, c, g);
+    if (wave < T3) {
+      f32x4 acc[2];
+      layer_dh<1>(a.WT[3], 16, wave, D4, acc, c, g);
+#pragma unroll
+      for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float* p = D3 + (16 * wave + 4 * g + r) * RS + 16 * sb + c;
+          *p = acc[sb][r] * *p;
+        }
+    }
+    __syncthreads();
+    // ---- layer 3
+    if (wave < T3) layer_dw<T2>(D3, H2, wave, dW3, db3, c, g);
+    if (wave < T2) {
+      f32x4 acc[2];
+      layer_dh<T3>(a.WT[2], in_pad[3], wave, D3, acc, c, g);
+#pragma unroll
+      for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float* p = D2 + (16 * wave + 4 * g + r) * RS + 16 * sb + c;
+          *p = acc[sb][r] * *p;
+        }
+    }
+    __syncthreads();
+    // ---- layer 2
+    if (wave < T2) layer_dw<T1>(D2, H1, wave, dW2, db2, c, g);
+    if (wave < T1) {
+      f32x4 acc[2];
+      layer_dh<T2>(a.WT[1], in_pad[2], wave, D2, acc, c, g);
+#pragma unroll
+      for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float* p = D1 + (16 * wave + 4 * g + r) * RS + 16 * sb + c;
+          *p = acc[sb][r] * *p;
+        }
+    }
+    __syncthreads();
+    // ---- layer 1
+    if (wave < T1) layer_dw<TI0>(D1, H0, wave, dW1, db1, c, g);
+    if (dX && wave < TI0) {
+      f32x4 acc[2];
+      layer_dh<T1>(a.WT[0], in_pad[1], wave, D1, acc, c, g);
+#pragma unroll
+      for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 16 * wave + 4 * g + r;
+          const int64_t n = n0 + 16 * sb + c;
+          if (row < K0 && n < N) dX[(int64_t)row * N + n] = acc[sb][r];
+        }
+    }
+  }
+  // ---- the wave's accumulators -> this workgroup's gradient image.  D layout of an MFMA result: lane (col = c, g), register
+  // r = row 4 g + r; the dW tiles have rows = output feature (own tile), cols = input feature.
+  using GI = GImg<TI0, T1, T2, T3>;
+  float* img = partial + (size_t)blockIdx.x * GI::TOTAL;
+  auto put = [&](int base, int ncols_pad, int to, int ntiles_in, const f32x4* acc) {
+    for (int ti = 0; ti < ntiles_in; ti++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) img[base + (16 * to + 4 * g + r) * ncols_pad + 16 * ti + c] = acc[ti][r];
+  };
+  auto put_db = [&](int base, int to, float v) {   // lane (feature c, g) holds the sum over its 2 x 4 samples: add the 4 groups
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) img[base + 16 * to + c] = v;
+  };
+  if (wave < T1) { put(GI::W1, TI0 * 16, wave, TI0, dW1); put_db(GI::B1, wave, db1); }
+  if (wave < T2) { put(GI::W2, T1 * 16, wave, T1, dW2); put_db(GI::B2, wave, db2); }
+  if (wave < T3) { put(GI::W3, T2 * 16, wave, T2, dW3); put_db(GI::B3, wave, db3); }
+  if (wave == 0) { put(GI::W4, T3 * 16, 0, T3, dW4); put_db(GI::B4, 0, db4); }
+}
+
+// sum of the workgroup images -> ACCUMULATED into the torch-layout gradients of the (normalised) weights
+template <int TI0, int T1, int T2, int T3>
+__global__ void mlp_wide_reduce_kernel(const float* __restrict__ partial, int nimg, WideArgs a, float* dW0, float* dW1,
+                                       float* dW2, float* dW3, float* db0, float* db1, float* db2, float* db3) {
+  using GI = GImg<TI0, T1, T2, T3>;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= GI::TOTAL) return;
+  float s = 0.f;
+  for (int b = 0; b < nimg; b++) s += partial[(size_t)b * GI::TOTAL + e];
+  auto mat = [&](int off, int cols_pad, int rows_true, int cols_true, float* dst) {
+    const int row = off / cols_pad, col = off % cols_pad;
+    if (row < rows_true && col < cols_true) dst[row * cols_true + col] += s;
+  };
+  if (e < GI::W2) mat(e - GI::W1, TI0 * 16, a.dims[1], a.dims[0], dW0);
+  else if (e < GI::W3) mat(e - GI::W2, T1 * 16, a.dims[2], a.dims[1], dW1);
+  else if (e < GI::W4) mat(e - GI::W3, T2 * 16, a.dims[3], a.dims[2], dW2);
+  else if (e < GI::B1) mat(e - GI::W4, T3 * 16, a.dims[4], a.dims[3], dW3);
+  else if (e < GI::B2) { if (e - GI::B1 < a.dims[1]) db0[e - GI::B1] += s; }
+  else if (e < GI::B3) { if (e - GI::B2 < a.dims[2]) db1[e - GI::B2] += s; }
+  else if (e < GI::B4) { if (e - GI::B3 < a.dims[3]) db2[e - GI::B3] += s; }
+  else { if (e - GI::B4 < a.dims[4]) db3[e - GI::B4] += s; }
+}
+
+// zero-padded copies of the weights in the two orientations the kernel streams: Wp [out_pad][in_pad], WTp [in_pad][out_pad]
+__global__ void mlp_wide_pack_kernel(int out, int in, int out_pad, int in_pad, const float* __restrict__ W,
+                                     float* __restrict__ Wp, float* __restrict__ WTp) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= out_pad * in_pad) return;
+  const int o = e / in_pad, i = e % in_pad;
+  const float v = (o < out && i < in) ? W[o * in + i] : 0.f;
+  Wp[e] = v;
+  WTp[i * out_pad + o] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Same contract as psdf_mlp_backward (include/psdf.h) for 4-layer nets whose widths the narrow kernels do not hold:
+// dims[0] <= 112, dims[1], dims[2] <= 128, dims[3] <= 64, dims[4] <= 16; -2 otherwise.  The reference's colour network
+// (LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3, models.py:349-350) is the net it is instantiated for.
+int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                           const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                           void* stream) {
+  constexpr int TI0 = 7, T1 = 8, T2 = 8, T3 = 4;
+  if (n_layers != 4 || !dims || !dW || !db) return PSDF_ERR_UNSUPPORTED;
+  if (dims[0] > TI0 * 16 || dims[1] > T1 * 16 || dims[2] > T2 * 16 || dims[3] > T3 * 16 || dims[4] > 16) return PSDF_ERR_UNSUPPORTED;
+  if (dims[1] <= 64 && dims[2] <= 64) return PSDF_ERR_UNSUPPORTED;   // the narrow family's territory
+  if (N <= 0 || !X || !weights || !biases || !dY) return PSDF_ERR_ARG;
+  for (int l = 0; l < 4; l++)
+    if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return PSDF_ERR_UNSUPPORTED;
+  using GI = GImg<TI0, T1, T2, T3>;
+  const int pads[5] = {TI0 * 16, T1 * 16, T2 * 16, T3 * 16, 16};
+  size_t wfloats = 0;
+  for (int l = 0; l < 4; l++) wfloats += 2 * (size_t)pads[l] * pads[l + 1];
+  const int64_t ntiles = (N + TS - 1) / TS;
+  int64_t blocks = ntiles < 256 ? ntiles : 256;
+  char* scratch = nullptr;
+  if (hipMallocAsync((void**)&scratch, (wfloats + (size_t)blocks * GI::TOTAL) * sizeof(float), st) != hipSuccess || !scratch) {
+    (void)hipGetLastError();
+    return PSDF_ERR_UNSUPPORTED;
+  }
+  WideArgs a;
+  float* wp = reinterpret_cast<float*>(scratch);
+  for (int l = 0; l < 4; l++) {
+    const int n = pads[l] * pads[l + 1];
+    float* Wp = wp;
+    float* WTp = wp + n;
+    wp += 2 * n;
+    hipLaunchKernelGGL(mlp_wide_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dims[l + 1], dims[l], pads[l + 1],
+                       pads[l], weights[l], Wp, WTp);
+    a.W[l] = Wp;
+    a.WT[l] = WTp;
+    a.b[l] = biases[l];
+  }
+  for (int i = 0; i < 5; i++) a.dims[i] = dims[i];
+  float* partial = wp;
+  const size_t lds_bytes = (size_t)((TI0 + 2 * T1 + 2 * T2 + 2 * T3 + 1) * 16) * RS * sizeof(float);
+  auto kern = mlp_wide_bwd_kernel<TI0, T1, T2, T3>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) {
+    (void)hipFreeAsync(scratch, st);
+    return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, dY, dX, partial);
+  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3>), dim3((GI::TOTAL + 255) / 256), dim3(256), 0, st, partial,
+                     (int)blocks, a, dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
+  (void)hipFreeAsync(scratch, st);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+}  // extern "C"

@@ -95,6 +95,8 @@ def backward_supported(dims):
     if n_layers not in (3, 4):
         return False
     t = [(d + 15) // 16 for d in dims]
+    if n_layers == 4 and t[0] <= 7 and t[1] <= 8 and t[2] <= 8 and t[3] <= 4 and dims[4] <= 16 and (t[1] > 4 or t[2] > 4):
+        return True     # csrc/mlp_wide.hip: the 128-wide colour network (workgroup-cooperative kernel)
     sig = (t[0], t[1], t[2], t[3] if n_layers == 4 else 0, t[n_layers], dims[-1] <= 4)
     return sig in {(3, 4, 4, 4, 1, True), (4, 4, 4, 4, 1, True), (2, 4, 4, 4, 1, True), (4, 2, 2, 2, 1, True),
                    (3, 2, 2, 2, 1, True), (2, 2, 2, 2, 1, True), (4, 2, 2, 2, 3, False), (4, 4, 4, 4, 5, False),

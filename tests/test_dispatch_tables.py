@@ -36,5 +36,6 @@ def test_predicates_on_the_nets_of_the_reference():
     assert backward_supported([52, 32, 32, 32, 33]) and double_backward_supported([52, 32, 32, 32, 33])   # SDF net
     assert backward_supported([36, 64, 64, 64, 1]) and double_backward_supported([36, 64, 64, 64, 1])     # BASELINE net
     assert backward_supported([52, 64, 64, 64, 65]) and backward_supported([80, 64, 64, 3])               # background nets
-    assert not backward_supported([112, 128, 128, 64, 3])                                                 # colour net: torch (GPU)
+    assert backward_supported([112, 128, 128, 64, 3]) and backward_supported([111, 128, 128, 64, 3])     # colour net: mlp_wide.hip
+    assert not backward_supported([200, 256, 256, 64, 3]) and not double_backward_supported([112, 128, 128, 64, 3])
     assert not double_backward_supported([80, 64, 64, 3])
