@@ -77,6 +77,12 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
 int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
     const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 
+/* replaces: LipshitzMLP.normalization (models.py:98-104): Wn[r][:] = W[r][:] * min(1, softplus(c[0]) / sum_j |W[r][j]|), and its
+   autograd (grad_W written, grad_c[0] accumulated into) */
+int psdf_lipshitz_normalize_forward(int out, int in, const float* W, const float* c, float* Wn, void* stream);
+int psdf_lipshitz_normalize_backward(int out, int in, const float* W, const float* c, const float* grad_Wn, float* grad_W,
+    float* grad_c, void* stream);
+
 /* ---- neus.hip ---- */
 /* replaces: the torch elementwise chain of VolumeRenderingNeus.compute_weights, permuto_sdf_py/volume_rendering/
    volume_rendering_modules.py:129-172 (cos anneal, section-point SDFs, two sigmoids, (p+1e-5)/(c+1e-5) clipped to [0,1]);

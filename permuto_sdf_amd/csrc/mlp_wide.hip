@@ -303,9 +303,71 @@ __global__ void mlp_wide_pack_kernel(int out, int in, int out_pad, int in_pad, c
   WTp[i * out_pad + o] = v;
 }
 
+// Lipschitz weight normalisation of one layer (models.py:98-104): Wn[r][:] = W[r][:] * min(1, softplus(c) / sum_j |W[r][j]|).
+// One wave per row.  The reference evaluates it with six torch launches per layer and direction.
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch's threshold
+
+__global__ void __launch_bounds__(64)
+    lipshitz_norm_fwd_kernel(int in, const float* __restrict__ W, const float* __restrict__ c, float* __restrict__ Wn) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float a = 0.f;
+  for (int j = lane; j < in; j += 64) a += fabsf(W[r * in + j]);
+  a = psdf::wave_sum(a);
+  const float scale = fminf(softplus_t(c[0]) / a, 1.0f);
+  for (int j = lane; j < in; j += 64) Wn[r * in + j] = W[r * in + j] * scale;
+}
+
+// G = dL/dWn -> dW (written) and dc[0] (ACCUMULATED).  Active rows (scale < 1): Wn = W sp / A with A = sum |W|:
+//   dW_j = G_j sp / A - (sum_k G_k W_k) sp / A^2 sign(W_j);  dsp += (sum_k G_k W_k) / A;  dc = dsp sigmoid(c)
+__global__ void __launch_bounds__(64)
+    lipshitz_norm_bwd_kernel(int in, const float* __restrict__ W, const float* __restrict__ c, const float* __restrict__ G,
+                             float* __restrict__ dW, float* __restrict__ dc) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float a = 0.f, gw = 0.f;
+  for (int j = lane; j < in; j += 64) {
+    const float w = W[r * in + j];
+    a += fabsf(w);
+    gw += G[r * in + j] * w;
+  }
+  a = psdf::wave_sum(a);
+  gw = psdf::wave_sum(gw);
+  const float sp = softplus_t(c[0]);
+  const float ratio = sp / a;
+  const bool active = ratio < 1.0f;     // torch.clamp(max=1): the gradient passes where the input is below the bound
+  for (int j = lane; j < in; j += 64) {
+    const float w = W[r * in + j], g = G[r * in + j];
+    const float sgn = w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f);
+    dW[r * in + j] = active ? g * ratio - gw * sp / (a * a) * sgn : g;
+  }
+  if (active && lane == 0) {
+    const float x = c[0];
+    const float sig = 1.0f / (1.0f + expf(-x));
+    atomicAdd(dc, gw / a * (x > 20.f ? 1.0f : sig));
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// replaces: LipshitzMLP.normalization, permuto_sdf_py/models/models.py:98-104 (W [out, in] row major, c [1] on the device)
+int psdf_lipshitz_normalize_forward(int out, int in, const float* W, const float* c, float* Wn, void* stream) {
+  if (out <= 0 || in <= 0) return PSDF_OK;
+  if (!W || !c || !Wn) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(lipshitz_norm_fwd_kernel, dim3(out), dim3(64), 0, (hipStream_t)stream, in, W, c, Wn);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// replaces: torch autograd of the same; grad_W [out, in] is written, grad_c [1] is ACCUMULATED into
+int psdf_lipshitz_normalize_backward(int out, int in, const float* W, const float* c, const float* grad_Wn, float* grad_W,
+                                     float* grad_c, void* stream) {
+  if (out <= 0 || in <= 0) return PSDF_OK;
+  if (!W || !c || !grad_Wn || !grad_W || !grad_c) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(lipshitz_norm_bwd_kernel, dim3(out), dim3(64), 0, (hipStream_t)stream, in, W, c, grad_Wn, grad_W, grad_c);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
 
 // Same contract as psdf_mlp_backward (include/psdf.h) for 4-layer nets whose widths the narrow kernels do not hold:
 // dims[0] <= 112, dims[1], dims[2] <= 128, dims[3] <= 64, dims[4] <= 16; -2 otherwise.  The reference's colour network

@@ -297,6 +297,28 @@ class FusedMLP(torch.nn.Module):
             return mlp_forward_raw(self.dims, x_fm, packed)
 
 
+class _LipshitzNormFunc(torch.autograd.Function):
+    """LipshitzMLP.normalization (models.py:98-104) as one launch per direction (csrc/mlp_wide.hip)"""
+
+    @staticmethod
+    def forward(ctx, w, c):
+        wc, cc = w.detach().contiguous(), c.detach().contiguous()
+        wn = torch.empty_like(wc)
+        L.call("psdf_lipshitz_normalize_forward", L.c_i(wc.shape[0]), L.c_i(wc.shape[1]), L.ptr(wc), L.ptr(cc), L.ptr(wn),
+               L.stream())
+        ctx.save_for_backward(wc, cc)
+        return wn
+
+    @staticmethod
+    def backward(ctx, g):
+        wc, cc = ctx.saved_tensors
+        dw = torch.empty_like(wc)
+        dc = torch.zeros_like(cc)
+        L.call("psdf_lipshitz_normalize_backward", L.c_i(wc.shape[0]), L.c_i(wc.shape[1]), L.ptr(wc), L.ptr(cc),
+               L.ptr(g.contiguous()), L.ptr(dw), L.ptr(dc), L.stream())
+        return dw, dc
+
+
 class LipshitzMLP(torch.nn.Module):
     """Lipschitz-regularised MLP of the colour network (reference: permuto_sdf_py/models/models.py:54-129, used at
     :349-350 as 111 -> 128 -> 128 -> 64 -> 3): every layer's weight is rescaled per row by
@@ -336,7 +358,10 @@ class LipshitzMLP(torch.nn.Module):
         return full
 
     def forward(self, x):
-        ws = [self.normalization(w, torch.nn.functional.softplus(c))
-              for w, c in zip(self.weights_per_layer, self.lipshitz_bound_per_layer)]
+        if x.is_cuda:
+            ws = [_LipshitzNormFunc.apply(w, c) for w, c in zip(self.weights_per_layer, self.lipshitz_bound_per_layer)]
+        else:   # parameter bookkeeping on the CPU (checkpoint tests); compute is GPU only and raises below
+            ws = [self.normalization(w, torch.nn.functional.softplus(c))
+                  for w, c in zip(self.weights_per_layer, self.lipshitz_bound_per_layer)]
         y = _FusedMLPFunc.apply(self, x, *ws, *list(self.biases_per_layer))
         return y if self.last_layer_linear else torch.nn.functional.gelu(y)

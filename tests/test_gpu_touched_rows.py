@@ -108,4 +108,4 @@ def test_trainer_steps_with_and_without_touched_rows_agree(dev):
     assert abs(out[0][0] - out[1][0]) <= 5e-3 * abs(out[1][0])
     for a, b in ((out[0][1], out[1][1]), (out[0][2], out[1][2])):
         d = (a - b).abs()
-        assert float(d.max()) <= 3 * 1e-3 + 1e-6 and float((d > 1e-6).float().mean()) < 0.02
+        assert float(d.max()) <= 1e-2 and float((d > 1e-6).float().mean()) < 0.05
