@@ -89,23 +89,29 @@ def test_block_adamw_is_bit_identical_to_dense_torch_adamw(dev):
 
 
 def test_trainer_steps_with_and_without_touched_rows_agree(dev):
-    """the cfg-4 trainer: same seeds, touched-rows path on / off -> same parameters after 3 steps (scatter order aside)"""
+    """the cfg-4 trainer, same seeds: touched-rows path vs dense path.  The runs differ only in the accumulation order of the
+    scatter-adds, which is run-to-run noise of the dense path as well; the first AdamW steps are sign-like (m / sqrt(v) = +-1),
+    so an entry whose tiny gradient flips sign moves by ~lr per step.  The noise floor is therefore MEASURED (dense vs dense)
+    and the touched-rows run must sit within it.  (The optimiser itself is checked bit for bit above.)"""
     from permuto_sdf_amd.train_step import SyntheticReel, Trainer
     reel = SyntheticReel(dev, nr_images=4, height=60, width=80)
-    out = []
-    for flag in (True, False):
+
+    def run(flag):
         from permuto_sdf_amd.bridge import OccupancyGrid, RaySampler, VolumeRendering
-        for cls in (OccupancyGrid, RaySampler, VolumeRendering):          # same jitter streams for both runs
+        for cls in (OccupancyGrid, RaySampler, VolumeRendering):          # same jitter streams for every run
             cls._rng = type(cls._rng)()
         tr = Trainer(dev, seed=1, touched_rows=flag)
         tr.nr_rays = 128
         for _ in range(3):
             loss = tr.step(reel)
-        out.append((float(loss), tr.sdf.encoding.lattice_values.detach().clone(), tr.rgb.encoding.lattice_values.detach().clone()))
-    # The two runs differ only in the accumulation order of the scatter-adds (run-to-run noise of the dense path as well); the
-    # first AdamW steps are sign-like (m / sqrt(v) = +-1), so an entry whose tiny gradient flips sign moves by up to lr per
-    # step.  The optimiser itself is checked bit for bit above; here: same trajectory within that noise.
-    assert abs(out[0][0] - out[1][0]) <= 5e-3 * abs(out[1][0])
-    for a, b in ((out[0][1], out[1][1]), (out[0][2], out[1][2])):
-        d = (a - b).abs()
-        assert float(d.max()) <= 1e-2 and float((d > 1e-6).float().mean()) < 0.05
+        return float(loss), tr.sdf.encoding.lattice_values.detach().clone(), tr.rgb.encoding.lattice_values.detach().clone()
+
+    dense_a, dense_b, touched = run(False), run(False), run(True)
+
+    def dist(x, y):
+        d = [(a - b).abs() for a, b in zip(x[1:], y[1:])]
+        return (abs(x[0] - y[0]) / abs(y[0]), max(float(t.max()) for t in d), max(float((t > 1e-6).float().mean()) for t in d))
+    noise, got = dist(dense_a, dense_b), dist(touched, dense_a)
+    assert got[0] <= 3 * noise[0] + 1e-3, (got, noise)
+    assert got[1] <= 3 * noise[1] + 1e-4, (got, noise)
+    assert got[2] <= 3 * noise[2] + 1e-3, (got, noise)
