@@ -186,7 +186,7 @@ def main():
             dt24 = (time.perf_counter() - t24) / K24
             extra["L24_52-64-64-64-1"] = {"ms_per_step": dt24 * 1e3, "samples_per_s": N / dt24, "steps": K24,
                                          "note": "same batch and step with a 24-level encoding (the reference's level count, "
-                                                 "models.py:144); MLP backward on the fp32-MFMA kernel (52 inputs)"}
+                                                 "models.py:144)"}
             del hp24
         except Exception as e:  # the extra row must never take the headline down
             extra["L24_52-64-64-64-1"] = {"error": repr(e)}

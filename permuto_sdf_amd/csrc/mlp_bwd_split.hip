@@ -21,18 +21,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HID = 64, NT = 4 /* 16-feature tiles of a hidden layer */, NT0 = 3 /* tiles covering the input (<= 48) */;
+constexpr int HID = 64, NT = 4 /* 16-feature tiles of a hidden layer */;   // NT0 (template) = tiles covering the input: 3 (<= 48) or 4 (<= 64)
 __host__ __device__ inline int kf(int s, int g, int j) { return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3); }
 
 // ------------------------------------------------------------------ LDS image (units: 16-byte lane records)
 // every layer: [tile][k-step 2][piece 3][lane 64]
-constexpr int RECL = NT * 2 * 3 * 64, RECT0 = NT0 * 2 * 3 * 64;
+constexpr int RECL = NT * 2 * 3 * 64;
 constexpr int OFF_W0 = 0, OFF_W1 = RECL, OFF_W2 = 2 * RECL, OFF_T2 = 3 * RECL, OFF_T1 = 4 * RECL, OFF_T0 = 5 * RECL;
-constexpr int OFF_F32 = 5 * RECL + RECT0;
+constexpr int off_f32(int nt0) { return 5 * RECL + nt0 * 2 * 3 * 64; }
 constexpr int TAIL_FLOATS = 3 * HID + HID + 1;  // biases of the three hidden layers, final weights, final bias
-constexpr size_t IMG_BYTES = (size_t)OFF_F32 * 16 + TAIL_FLOATS * 4;
 constexpr int NWAVES = 4;
-constexpr size_t IMG_ALIGNED = (IMG_BYTES + 15) / 16 * 16;
+constexpr size_t img_aligned(int nt0) { return ((size_t)off_f32(nt0) * 16 + TAIL_FLOATS * 4 + 15) / 16 * 16; }
 // gradient image (floats): dW1 [64][64 (K0 used)], dW2 [64][64], dW3 [64][64], db1, db2, db3 [64], dW4 [64], db4
 constexpr int G_W1 = 0, G_W2 = 4096, G_W3 = 8192, G_B1 = 12288, G_B2 = 12352, G_B3 = 12416, G_W4 = 12480, G_B4 = 12544,
               G_TOTAL = 12545;
@@ -237,10 +236,16 @@ __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO
 
 // X [K0, N], dY [1, N], dX [K0, N] (optional) feature-major; img = the LDS image (mlp_split_pack_kernel); partial
 // [gridDim.x][G_TOTAL] receives this workgroup's gradient image.  rows4 = K0 rounded up to a multiple of 4.
+// DOUBLE: the staged inputs are double buffered and serve the whole tile (K0 <= 36: it fits beside the image in 160 KB of
+// LDS).  Otherwise ONE staging buffer per wave: it is read at the top of the tile and refilled at once for the next tile;
+// the feature-lane copy of X that the last layer's dW needs comes from global memory (an L2 hit: the tile was just staged).
+template <int NT0, bool DOUBLE>
 __global__ void __launch_bounds__(NWAVES * 64, 1)
     mlp_bwd_split_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
                          const u32x4* __restrict__ img, float* __restrict__ dX, float* __restrict__ partial) {
   extern __shared__ __align__(16) u32x4 lds[];
+  constexpr size_t IMG_ALIGNED = img_aligned(NT0);
+  constexpr int OFF_F32 = off_f32(NT0);
   constexpr int NREC = (int)(IMG_ALIGNED / 16);
   for (int i = threadIdx.x; i < NREC; i += NWAVES * 64) lds[i] = img[i];
   __syncthreads();
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
         dw4[NT] = {0.f, 0.f, 0.f, 0.f}, db4 = 0.f;
   const int64_t ntiles = (N + 15) / 16;
   const int stage_floats = rows4 * 16 + 64;
-  float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED) + wave * 2 * stage_floats;
+  float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED) + wave * (DOUBLE ? 2 : 1) * stage_floats;
   // The inputs of the NEXT tile are requested with global_load_lds while this one is computed: instruction i brings rows
   // 4 i + g (clamped to the last real row) of the 16 samples of the tile to buf[(4 i + g) * 16 + c], the last one dY.
   auto prefetch = [&](int64_t t, float* buf) {
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   int cur = 0;
   for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA completion is not tracked by the compiler
-    const float* xb = stage + cur * stage_floats;
+    const float* xb = stage + (DOUBLE ? cur : 0) * stage_floats;
     // loop-invariant lane arithmetic (addresses, masks) is cheap to redo and expensive to keep: hoisted out of the loop it
     // ends up in scratch, and every scratch reload waits (vmcnt) for the LDS-DMA prefetch in flight
     int lane_l = lane_k;
@@ -307,6 +312,16 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
         mac16<NT>(a, bx, lds + OFF_W0 + s * 192 + lane);
       }
     }
+    // single staging buffer: take the two dY operands now and refill the buffer for the next tile at once
+    f32x4 dyT_early = zero4();
+    float dy_early = 0.f;
+    if (!DOUBLE) {
+      dyT_early = *reinterpret_cast<const f32x4*>(xb + rows4 * 16 + 4 * g);
+      dy_early = xb[rows4 * 16 + c];
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the LDS reads above have returned before the DMA overwrites
+      if (tile + tstride < ntiles) prefetch(tile + tstride, stage);
+    }
     act_both(a, g1);  // a = h1
     bias_init<NT>(b, tail + HID, g);
     chain<NT>(a, b, lds + OFF_W1, lane, [&](int s, const BP& p) {
@@ -324,7 +339,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     // ---------------- output layer: dW4 = sum dy h3, db4 = sum dy, dZ3 = w4 dy gelu'(z3); samples past N carry dy = 0,
     // which zeroes every contribution of theirs below
     {
-      f32x4 dyT = *reinterpret_cast<const f32x4*>(xb + rows4 * 16 + 4 * g);  // samples 4 g + r
+      f32x4 dyT = DOUBLE ? *reinterpret_cast<const f32x4*>(xb + rows4 * 16 + 4 * g) : dyT_early;  // samples 4 g + r
 #pragma unroll
       for (int r = 0; r < 4; r++) dyT[r] = (n0 + 4 * g + r < N) ? dyT[r] : 0.f;
       db4 += (dyT[0] + dyT[1]) + (dyT[2] + dyT[3]);
@@ -341,7 +356,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
         }
       }
     }
-    const float dy = live ? xb[rows4 * 16 + c] : 0.f;
+    const float dy = live ? (DOUBLE ? xb[rows4 * 16 + c] : dy_early) : 0.f;
     const float* wf = tail + 3 * HID;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -356,7 +371,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     for (int t = 0; t < NT; t++) a[t] *= g2[t];                       // dZ2^T
     // ---------------- layer 2 (the prefetch goes out here: late enough that the early part of the tile does not wait on
     // it, early enough for an HBM round trip before the next tile)
-    if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats);
+    if (DOUBLE && tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats);
     zero_init<NT>(dz);
     layer_bwd<NT, NT>(a, dz, lds + OFF_T1, lane, id, h1T, dW2, db2);  // dz = dH1^T
 #pragma unroll
@@ -367,7 +382,18 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     for (int u = 0; u < NT0; u++) {
       const int feat = 16 * u + c;
       xT[u] = zero4();
-      if (feat < K0) xT[u] = *reinterpret_cast<const f32x4*>(xb + feat * 16 + 4 * g);
+      if (feat < K0) {
+        if (DOUBLE) {
+          xT[u] = *reinterpret_cast<const f32x4*>(xb + feat * 16 + 4 * g);
+        } else {   // samples n0 + 4 g + r of feature `feat` (clamped at the end of the batch: their dZ is zero)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            int64_t nn = n0 + 4 * g + r;
+            nn = nn < N ? nn : N - 1;
+            xT[u][r] = X[(int64_t)feat * N + nn];
+          }
+        }
+      }
     }
     zero_init<NT0>(dx);
     layer_bwd<NT0, NT0>(dz, dx, lds + OFF_T0, lane, id, xT, dW1, db1);  // dx = dX^T
@@ -468,6 +494,7 @@ __device__ __forceinline__ void split3(float x, uint16_t (&p)[3]) {
 
 // The LDS image from the torch-layout parameters: thread = (image 0..5, tile, k-step, lane) writes its three 16-byte
 // records (one per piece); the tail threads copy biases / final weights.
+template <int NT0>
 __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, const float* __restrict__ W1,
                                       const float* __restrict__ W2, const float* __restrict__ W3,
                                       const float* __restrict__ b0, const float* __restrict__ b1,
@@ -505,7 +532,7 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
     }
   } else {
     const int e = t - NTHR;
-    float* tail = reinterpret_cast<float*>(rec + (size_t)OFF_F32 * 8);
+    float* tail = reinterpret_cast<float*>(rec + (size_t)off_f32(NT0) * 8);
     if (e < HID) tail[e] = b0[e];
     else if (e < 2 * HID) tail[e] = b1[e - HID];
     else if (e < 3 * HID) tail[e] = b2[e - 2 * HID];
@@ -518,7 +545,7 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
 
 extern "C" {
 
-// Same contract as psdf_mlp_backward (include/psdf.h) for the nets this kernel covers: dims = {K0 <= 36, 64, 64, 64, 1},
+// Same contract as psdf_mlp_backward (include/psdf.h) for the nets this kernel covers: dims = {K0 <= 64, 64, 64, 64, 1},
 // dW / db requested; returns PSDF_ERR_UNSUPPORTED (-2) for everything else (the caller then takes the fp32 kernel).
 // Needs stream-ordered scratch (hipMallocAsync: the 142-KB operand image and one gradient image per workgroup); when that
 // is not available (stream capture, allocation failure) it also returns -2.
@@ -528,9 +555,14 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
   if (n_layers != 4 || !dims || dims[1] != HID || dims[2] != HID || dims[3] != HID || dims[4] != 1 || !dW || !db)
     return PSDF_ERR_UNSUPPORTED;
   const int K0 = dims[0];
+  if (K0 < 1 || K0 > 64) return PSDF_ERR_UNSUPPORTED;
   const int rows4 = (K0 + 3) & ~3;
-  const size_t lds_bytes = IMG_ALIGNED + (size_t)NWAVES * 2 * (rows4 * 16 + 64) * 4;
-  if (K0 < 1 || K0 > 16 * NT0 || lds_bytes > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
+  const int nt0 = K0 <= 48 ? 3 : 4;
+  const size_t stage_bytes = (size_t)NWAVES * (rows4 * 16 + 64) * 4;
+  const bool dbl = nt0 == 3 && img_aligned(3) + 2 * stage_bytes <= 160 * 1024;      // K0 <= 36
+  const size_t img_bytes = img_aligned(nt0);
+  const size_t lds_bytes = img_bytes + (dbl ? 2 : 1) * stage_bytes;
+  if (lds_bytes > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
   if (N <= 0 || !X || !weights || !biases || !dY) return PSDF_ERR_ARG;
   for (int l = 0; l < 4; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
@@ -542,23 +574,39 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
   if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
   char* scratch = nullptr;
   const size_t part_bytes = (size_t)blocks * G_TOTAL * sizeof(float);
-  if (hipMallocAsync((void**)&scratch, IMG_ALIGNED + part_bytes, st) != hipSuccess || !scratch) {
+  if (hipMallocAsync((void**)&scratch, img_bytes + part_bytes, st) != hipSuccess || !scratch) {
     (void)hipGetLastError();
     return PSDF_ERR_UNSUPPORTED;
   }
   uint16_t* rec = reinterpret_cast<uint16_t*>(scratch);
-  float* partial = reinterpret_cast<float*>(scratch + IMG_ALIGNED);
-  constexpr int PACK_THREADS = (5 * NT + NT0) * 2 * 64 + TAIL_FLOATS;
-  hipLaunchKernelGGL(mlp_split_pack_kernel, dim3((PACK_THREADS + 255) / 256), dim3(256), 0, st, K0, weights[0], weights[1],
-                     weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], rec);
-  hipError_t e = hipFuncSetAttribute((const void*)mlp_bwd_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes);
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(scratch, st);
-    return (int)e;
+  float* partial = reinterpret_cast<float*>(scratch + img_bytes);
+  const int pack_threads = (5 * NT + nt0) * 2 * 64 + TAIL_FLOATS;
+#define PACK(NT0_)                                                                                                         \
+  hipLaunchKernelGGL(mlp_split_pack_kernel<NT0_>, dim3((pack_threads + 255) / 256), dim3(256), 0, st, K0, weights[0],        \
+                     weights[1], weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], rec)
+#define MAIN(NT0_, DBL_)                                                                                                    \
+  do {                                                                                                                      \
+    auto kern = mlp_bwd_split_kernel<NT0_, DBL_>;                                                                            \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);       \
+    if (e != hipSuccess) {                                                                                                  \
+      (void)hipFreeAsync(scratch, st);                                                                                      \
+      return (int)e;                                                                                                        \
+    }                                                                                                                       \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,                  \
+                       reinterpret_cast<const u32x4*>(rec), dX, partial);                                                   \
+  } while (0)
+  if (nt0 == 3) {
+    PACK(3);
+    if (dbl)
+      MAIN(3, true);
+    else
+      MAIN(3, false);
+  } else {
+    PACK(4);
+    MAIN(4, false);
   }
-  hipLaunchKernelGGL(mlp_bwd_split_kernel, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,
-                     reinterpret_cast<const u32x4*>(rec), dX, partial);
+#undef PACK
+#undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256), dim3(256), 0, st, partial, (int)blocks, K0, dW[0],
                      dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
   (void)hipFreeAsync(scratch, st);
