@@ -62,7 +62,7 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     float* grad_grad_sliced, void* stream);
 
 /* ---- mlp_bwd_split.hip ---- */
-/* same contract as psdf_mlp_backward for dims = {K0 <= 64, 64, 64, 64, 1} with dW/db requested, computed on the bf16 matrix
+/* same contract as psdf_mlp_backward for dims = {K0 <= 52, 64, 64, 64, 1} with dW/db requested, computed on the bf16 matrix
    pipe with split fp32 operands (three bf16 pieces, six products kept: fp32-level accuracy); -2 for every other net and when
    stream-ordered scratch is unavailable (stream capture).  psdf_mlp_backward routes large batches here by itself. */
 int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,

@@ -56,12 +56,34 @@ __device__ __forceinline__ float erf_fast(float a) {
   return t > 0.927734375f ? hi : lo;
 }
 // gelu and its derivative Phi(z) + z phi(z) from one erf and one exp
+#ifndef PSDF_SPLIT_GELU_POLY
 __device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
   const float cdf = fmaf(0.5f, erf_fast(z * 0.70710678118654752440f), 0.5f);
   const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
   hval = z * cdf;
   gprime = fmaf(z, pdf, cdf);
 }
+#else
+// tools/gelu_fit.py: e = Phi(-t) = exp2(P8(t)), t = min(|z|, 5.75); gelu = max(z, 0) - t e (error 8.6e-8 |z| against float64, the
+// fp32 erf formula itself has 1.06e-7 |z|); gelu' = (z < 0 ? e : 1 - e) + z phi(t) from the same e (1.5e-7)
+__device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
+  const float t = fminf(fabsf(z), 5.75f);
+  float p = -2.772052994e-06f;
+  p = fmaf(p, t, 3.862077210e-05f);
+  p = fmaf(p, t, -1.825476502e-04f);
+  p = fmaf(p, t, -1.458701736e-04f);
+  p = fmaf(p, t, 7.075471804e-03f);
+  p = fmaf(p, t, -5.250502750e-02f);
+  p = fmaf(p, t, -4.592049122e-01f);
+  p = fmaf(p, t, -1.151105762e+00f);
+  p = fmaf(p, t, -1.000000000e+00f);
+  const float e = __builtin_amdgcn_exp2f(p);
+  hval = fmaf(-t, e, fmaxf(z, 0.f));
+  const float cdf = z < 0.f ? e : 1.0f - e;
+  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(t * t * -0.72134752044448170368f);
+  gprime = fmaf(copysignf(t, z), pdf, cdf);
+}
+#endif
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -545,7 +567,7 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
 
 extern "C" {
 
-// Same contract as psdf_mlp_backward (include/psdf.h) for the nets this kernel covers: dims = {K0 <= 64, 64, 64, 64, 1},
+// Same contract as psdf_mlp_backward (include/psdf.h) for the nets this kernel covers: dims = {K0 <= 52, 64, 64, 64, 1} (what fits 160 KB of LDS),
 // dW / db requested; returns PSDF_ERR_UNSUPPORTED (-2) for everything else (the caller then takes the fp32 kernel).
 // Needs stream-ordered scratch (hipMallocAsync: the 142-KB operand image and one gradient image per workgroup); when that
 // is not available (stream capture, allocation failure) it also returns -2.

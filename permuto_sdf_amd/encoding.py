@@ -126,8 +126,16 @@ class PermutoEncodingFunc(torch.autograd.Function):
     def backward(ctx, grad_out):
         scale_factor, shifts, lattice, positions, window = ctx.saved_tensors
         need_lat, need_pos = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        # `needs_input_grad` says what requires grad, not what THIS backward pass was asked for: torch.autograd.grad(sdf,
+        # points, create_graph=True) (models.py:245-251) comes through here with need_lat = True and throws the lattice
+        # gradient away.  (a) A caller that knows it (the trainer) says so with `positions_gradient_only()` and the lattice
+        # scatter is not even launched; (b) the persistent-buffer accumulation of TouchedRows is a side effect, so it is only
+        # allowed in a plain backward (grad mode off here), never while a differentiable backward is being recorded.
+        if getattr(ctx.cfg, "skip_lattice_grad", False):
+            need_lat = False
+        buffer_ok = not torch.is_grad_enabled()
         g_lat, g_pos = PermutoEncodingBackFunc.apply(ctx.cfg, scale_factor, shifts, lattice, positions, window,
-                                                     grad_out, need_lat, need_pos)
+                                                     grad_out, need_lat, need_pos, buffer_ok)
         # buffered mode (TouchedRows): the lattice gradient went into the persistent buffer, autograd gets None
         return None, None, None, (g_lat if (need_lat and g_lat.dim() > 0) else None), (g_pos if need_pos else None), None, None
 
@@ -136,10 +144,10 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
     """Backward as a Function so it can itself be differentiated (double backward from positions)."""
 
     @staticmethod
-    def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window, grad_out, need_lat, need_pos):
+    def forward(ctx, cfg, scale_factor, shifts, lattice, positions, window, grad_out, need_lat, need_pos, buffer_ok=False):
         g = _feature_major(grad_out)
         N = positions.shape[0]
-        tr = getattr(cfg, "touched_rows", None)
+        tr = getattr(cfg, "touched_rows", None) if buffer_ok else None
         if need_lat and tr is not None:
             # accumulate straight into the persistent buffer; autograd sees no lattice gradient (None) for this call
             g_pos = torch.zeros_like(positions) if need_pos else None
@@ -167,16 +175,16 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
         cfg = ctx.cfg
         need_lat, need_g = ctx.needs_input_grad[3], ctx.needs_input_grad[6]
         if dd_positions is None or not (need_lat or need_g):
-            return (None,) * 9
+            return (None,) * 10
         N = positions.shape[0]
         dd = dd_positions.contiguous()
         tr = getattr(cfg, "touched_rows", None)
-        buffered = need_lat and tr is not None
+        buffered = need_lat and tr is not None and not torch.is_grad_enabled()    # side effects only in a plain backward
         g_lat = tr.grad if buffered else (torch.zeros_like(lattice) if need_lat else None)
         gg = torch.empty_like(g)
         L.call("psdf_encode_double_backward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
                L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(dd), L.ptr(g), L.ptr(g_lat), L.ptr(gg), L.stream())
-        return None, None, None, (None if buffered else g_lat), None, None, (gg.t() if need_g else None), None, None
+        return None, None, None, (None if buffered else g_lat), None, None, (gg.t() if need_g else None), None, None, None
 
 
 class PermutoEncoding(torch.nn.Module):
@@ -213,6 +221,22 @@ class PermutoEncoding(torch.nn.Module):
 
     def output_dims(self):
         return self.cfg.channels
+
+    def positions_gradient_only(self):
+        """context manager: backward passes through this encoding inside it compute the gradient w.r.t. the POSITIONS only
+        (the lattice scatter-add is not launched).  For `torch.autograd.grad(sdf, points, create_graph=True)`: autograd would
+        compute the lattice gradient there and drop it."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = getattr(self.cfg, "skip_lattice_grad", False)
+            self.cfg.skip_lattice_grad = True
+            try:
+                yield
+            finally:
+                self.cfg.skip_lattice_grad = old
+        return cm()
 
     def enable_touched_rows(self, block_rows_log2=7):
         """Opt in to the touched-rows optimiser path (trainer only; the reference's Python keeps the plain autograd

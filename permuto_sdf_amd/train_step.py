@@ -148,7 +148,8 @@ class SdfNet(torch.nn.Module):
         with torch.enable_grad():
             points = points.detach().requires_grad_(True)
             sdf, feat = self.forward(points, it)
-            (grad,) = torch.autograd.grad(sdf, points, torch.ones_like(sdf), create_graph=True, retain_graph=True)
+            with self.encoding.positions_gradient_only():     # autograd would compute the lattice gradient here and drop it
+                (grad,) = torch.autograd.grad(sdf, points, torch.ones_like(sdf), create_graph=True, retain_graph=True)
         return sdf, grad, feat
 
     def curvature(self, points, sdf_gradients, it):  # models.py:261-296

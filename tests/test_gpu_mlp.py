@@ -242,7 +242,7 @@ def test_unimplemented_second_order_terms_raise(dev):
     assert mlp.layers[0].weight.grad is not None and torch.isfinite(mlp.layers[0].weight.grad).all()
 
 
-@pytest.mark.parametrize("K0,N", [(36, 300_001), (35, 262_160), (20, 270_000), (36, 1_000), (52, 290_003), (44, 262_147), (64, 5_000)])
+@pytest.mark.parametrize("K0,N", [(36, 300_001), (35, 262_160), (20, 270_000), (36, 1_000), (52, 290_003), (44, 262_147)])
 def test_split_bf16_backward_matches_float64(dev, K0, N):
     """csrc/mlp_bwd_split.hip (the BASELINE 64x3 -> 1 net on the bf16 matrix pipe, three bf16 pieces per fp32 operand, six
     products): every gradient against a float64 evaluation, and no worse than 4x the error of torch's own fp32 backward.
@@ -287,7 +287,7 @@ def test_split_bf16_backward_matches_float64(dev, K0, N):
         err_t = float((t.double() - r).abs().max()) / scale
         assert err <= max(4 * err_t, 5e-6), (name, err, err_t)     # bias gradients: fp32 sums over 3e5 samples
     # unsupported shapes say so (-2) and leave the fp32 kernel to do the work
-    assert fn(L.c_i(4), _dims_array([80, 64, 64, 64, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
+    assert fn(L.c_i(4), _dims_array([56, 64, 64, 64, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
               arr(dWs), arr(dbs), L.stream()) == -2
     assert fn(L.c_i(4), _dims_array([36, 32, 32, 32, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
               arr(dWs), arr(dbs), L.stream()) == -2
