@@ -15,7 +15,8 @@ cd $R
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, collections, sys
 out, tag = sys.argv[1], sys.argv[2]
-names = ["encode_fwd_kernel", "mlp_fwd_kernel", "mlp_bwd_kernel", "encode_bwd_kernel", "encode_bwd_reduce_kernel", "adamw_kernel"]
+names = ["encode_fwd_kernel", "mlp_fwd_kernel", "mlp_fwd_split_kernel", "mlp_bwd_kernel", "mlp_bwd_split_kernel", "encode_bwd_kernel",
+         "encode_bwd_reduce_kernel", "adamw_kernel", "neus_alpha_fwd_kernel", "neus_alpha_bwd_kernel"]
 res = {n: {} for n in names}
 for c, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
     agg = collections.defaultdict(lambda: [0.0, 0])
