@@ -6,6 +6,7 @@ torch.nn.Linear layout/names (``layers.{i}.weight|bias``) so a state_dict maps 1
 ``mlp_sdf.{2i}.weight|bias``.  Activations are exchanged feature-major ([C, N]) with the encoding kernels.
 """
 import ctypes
+import math
 
 import torch
 
@@ -268,12 +269,17 @@ def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
 class FusedMLP(torch.nn.Module):
     """Linear(d0,d1)-GELU-...-Linear(d_{n-1},d_n), GELU(erf) after every layer but the last."""
 
-    def __init__(self, dims):
+    def __init__(self, dims, reference_init=False, last_layer_linear_init=True):
+        """reference_init: initialise like the reference's nets (leaky_relu_init on every layer, gain 1 on the last one when
+        `last_layer_linear_init`; models.py:161-162) instead of torch.nn.Linear's default"""
         super().__init__()
         self.dims = [int(d) for d in dims]
         self.n_layers = len(self.dims) - 1
         self.layers = torch.nn.ModuleList(
             [torch.nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(self.n_layers)])
+        if reference_init:
+            for i, l in enumerate(self.layers):
+                leaky_relu_init_(l, 1.0 if (i == self.n_layers - 1 and last_layer_linear_init) else 0.0)
 
     @classmethod
     def from_sequential(cls, seq):
@@ -295,6 +301,18 @@ class FusedMLP(torch.nn.Module):
         with torch.no_grad():
             packed = pack_params(self.dims, [l.weight for l in self.layers], [l.bias for l in self.layers])
             return mlp_forward_raw(self.dims, x_fm, packed)
+
+
+def leaky_relu_init_(linear, negative_slope=0.0):
+    """The reference's initialiser for every Linear (permuto_sdf_py/utils/common_utils.py:248-293, `leaky_relu_init`): uniform
+    in +-sqrt(3) * gain * sqrt(2 / (n_in + n_out)) with gain = sqrt(2 / (1 + slope^2)), zero bias.  The nets use slope 0 on
+    hidden layers and slope 1 (gain 1) on a linear last layer (models.py:161-162, 69-71, 465-472)."""
+    gain = math.sqrt(2.0 / (1.0 + negative_slope ** 2))
+    std = gain * math.sqrt(2.0 / (linear.in_features + linear.out_features))
+    with torch.no_grad():
+        linear.weight.uniform_(-std * math.sqrt(3.0), std * math.sqrt(3.0))
+        linear.bias.zero_()
+    return linear
 
 
 class _LipshitzNormFunc(torch.autograd.Function):
@@ -333,11 +351,9 @@ class LipshitzMLP(torch.nn.Module):
         self.n_layers = len(self.dims) - 1
         self.layers = torch.nn.ModuleList(
             [torch.nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(self.n_layers)])
-        for i, l in enumerate(self.layers):   # reference: leaky_relu_init, slope 0 (hidden) / 1 (linear last layer)
+        for i, l in enumerate(self.layers):   # reference: leaky_relu_init, slope 0 (hidden) / 1 (linear last layer), models.py:68-71
             last = i == self.n_layers - 1
-            gain = 1.0 if (last and last_layer_linear) else 2.0 ** 0.5
-            torch.nn.init.normal_(l.weight, 0.0, gain / (l.in_features ** 0.5))
-            torch.nn.init.zeros_(l.bias)
+            leaky_relu_init_(l, 1.0 if (last and last_layer_linear) else 0.0)
         self.weights_per_layer = torch.nn.ParameterList([l.weight for l in self.layers])
         self.biases_per_layer = torch.nn.ParameterList([l.bias for l in self.layers])
         self.lipshitz_bound_per_layer = torch.nn.ParameterList()

@@ -12,6 +12,13 @@ restated on this repository's operators -- same order of operations, same hyper-
   gradient all-reduce (RCCL) overlapped with nothing it depends on; fused AdamW; every 8th step the occupancy grid is
   refreshed from 262 144 random voxel centres (same seed on every rank: replicas stay identical without communication).
 
+Not carried over from the reference's loop (they act after tens of thousands of iterations and do not change the cost of a
+step): the learning-rate warm-up / MultiStepLR decay (train_permuto_sdf.py:305,419-423), the weight-decay switch of the
+colour lattice and the eikonal weight change at iteration 50 000 (:400-406), the colour calibration module (:270-273), and
+the sphere-initialisation phase (:322-326).  The occupancy refresh runs after the optimiser step here, before it there
+(:383-391): the grid sees the parameters one step later.  Network initialisation follows the reference (leaky_relu_init,
+common_utils.py:248-293; sdf_shift added to the whole last bias vector, models.py:163-165).
+
 Differences from the reference, all structural: no-grad SDF evaluations run in the fused single-launch evaluator with
 a 1-row head (csrc/fused.hip); the samplers are exact-size (no second compaction pass); the per-step ray count adapts
 from the sample count the step already knows (no extra sync).  The image data are synthetic (DTU is not available
@@ -118,9 +125,9 @@ class SdfNet(torch.nn.Module):
         super().__init__()
         self.encoding = _lattice(3, 1e-3)
         g = hp.sdf_geom_feat_size
-        self.mlp_sdf = FusedMLP([self.encoding.output_dims(), 32, 32, 32, 1 + g])
-        with torch.no_grad():  # models.py:163-165: the shift sits in the bias of the SDF row
-            self.mlp_sdf.layers[-1].bias[0] += 1e-2
+        self.mlp_sdf = FusedMLP([self.encoding.output_dims(), 32, 32, 32, 1 + g], reference_init=True)   # models.py:161-162
+        with torch.no_grad():  # models.py:163-165: `mlp_sdf[-1].bias += sdf_shift`, the whole bias vector
+            self.mlp_sdf.layers[-1].bias += 1e-2
         self.c2f = Coarse2Fine(24)
         self.nr_iters_for_c2f = hp.sdf_nr_iters_for_c2f
 
@@ -197,8 +204,10 @@ class BgNet(torch.nn.Module):
     def __init__(self):
         super().__init__()
         self.encoding = _lattice(4, 1.0)
-        self.mlp_feat_and_density = FusedMLP([self.encoding.output_dims(), 64, 64, 64, 65])
-        self.mlp_rgb = FusedMLP([64 + 16, 64, 64, 3])
+        # models.py:451-472: leaky_relu_init everywhere; only mlp_rgb's last layer gets the linear (gain 1) init
+        self.mlp_feat_and_density = FusedMLP([self.encoding.output_dims(), 64, 64, 64, 65], reference_init=True,
+                                             last_layer_linear_init=False)
+        self.mlp_rgb = FusedMLP([64 + 16, 64, 64, 3], reference_init=True)
 
     def forward(self, pos4d, dirs):
         win = torch.ones(24, device=pos4d.device)

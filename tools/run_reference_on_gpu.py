@@ -163,6 +163,23 @@ def main():
     trainer.load_checkpoint(mp)
     for m in (trainer.sdf, trainer.rgb, trainer.bg):
         m.eval()
+    # checkpoint files both ways: the reference's files were just loaded (strict) into this repository's nets;
+    # now this repository's files go back into the reference's own model classes, strict, including RGB (LipshitzMLP's
+    # duplicated keys, volume_renderer_neus.deviation_network.variance) which cannot be constructed without a GPU
+    back = tempfile.mkdtemp(prefix="psdf_ck_back_")
+    trainer.save_checkpoint(back)
+    report = {}
+    for name, model, fname in (("sdf", model_sdf, "sdf_model.pt"), ("rgb", model_rgb, "rgb_model.pt"),
+                               ("bg", model_bg, "nerf_hash_model_bg.pt")):
+        sd = torch.load(os.path.join(back, fname), map_location=o.device)
+        ref_sd = model.state_dict()
+        assert set(sd) == set(ref_sd), (name, sorted(set(sd) ^ set(ref_sd)))
+        assert all(sd[k].shape == ref_sd[k].shape for k in ref_sd), name
+        same = all(torch.equal(sd[k].to(ref_sd[k].device), ref_sd[k]) for k in ref_sd)
+        model.load_state_dict(sd, strict=True)
+        report[name] = {"keys": len(sd), "identical_after_round_trip": bool(same)}
+    log["checkpoint_round_trip_reference_classes"] = report
+    print("[checkpoints]", report, flush=True)
     pred2, _, fg2 = trainer._render(o, d, it_eval, cos_anneal, forced_var, jitter=False)
     num = (pred2.detach() - pred_rgb.detach()).abs()
     log["run_net_vs_trainer_render"] = {
