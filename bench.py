@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra 24-level row (profiling runs: one kernel variant per name)")
     args = ap.parse_args()
 
     from permuto_sdf_amd import parallel
@@ -172,7 +173,7 @@ def main():
     hp.events = None
     # ---- extra row (not the headline): the north_star's stated shape, 24 levels -> 52-64-64-64-1, same batch, same step
     extra = {}
-    if world == 1:
+    if world == 1 and not args.no_extra:
         try:
             hp24 = SdfHotPath(nr_levels=24, hidden=64, out_channels=1, device=dev, seed=0)
             for _ in range(3):

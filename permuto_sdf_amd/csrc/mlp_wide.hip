@@ -277,19 +277,19 @@ __global__ void mlp_wide_reduce_kernel(const float* __restrict__ partial, int ni
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= GI::TOTAL) return;
   float s = 0.f;
-  for (int b = 0; b < nimg; b++) s += partial[(size_t)b * GI::TOTAL + e];
+  for (int b = blockIdx.y; b < nimg; b += gridDim.y) s += partial[(size_t)b * GI::TOTAL + e];   // slices meet by atomics
   auto mat = [&](int off, int cols_pad, int rows_true, int cols_true, float* dst) {
     const int row = off / cols_pad, col = off % cols_pad;
-    if (row < rows_true && col < cols_true) dst[row * cols_true + col] += s;
+    if (row < rows_true && col < cols_true) atomicAdd(&dst[row * cols_true + col], s);
   };
   if (e < GI::W2) mat(e - GI::W1, TI0 * 16, a.dims[1], a.dims[0], dW0);
   else if (e < GI::W3) mat(e - GI::W2, T1 * 16, a.dims[2], a.dims[1], dW1);
   else if (e < GI::W4) mat(e - GI::W3, T2 * 16, a.dims[3], a.dims[2], dW2);
   else if (e < GI::B1) mat(e - GI::W4, T3 * 16, a.dims[4], a.dims[3], dW3);
-  else if (e < GI::B2) { if (e - GI::B1 < a.dims[1]) db0[e - GI::B1] += s; }
-  else if (e < GI::B3) { if (e - GI::B2 < a.dims[2]) db1[e - GI::B2] += s; }
-  else if (e < GI::B4) { if (e - GI::B3 < a.dims[3]) db2[e - GI::B3] += s; }
-  else { if (e - GI::B4 < a.dims[4]) db3[e - GI::B4] += s; }
+  else if (e < GI::B2) { if (e - GI::B1 < a.dims[1]) atomicAdd(&db0[e - GI::B1], s); }
+  else if (e < GI::B3) { if (e - GI::B2 < a.dims[2]) atomicAdd(&db1[e - GI::B2], s); }
+  else if (e < GI::B4) { if (e - GI::B3 < a.dims[3]) atomicAdd(&db2[e - GI::B3], s); }
+  else { if (e - GI::B4 < a.dims[4]) atomicAdd(&db3[e - GI::B4], s); }
 }
 
 // zero-padded copies of the weights in the two orientations the kernel streams: Wp [out_pad][in_pad], WTp [in_pad][out_pad]
@@ -419,7 +419,7 @@ int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float
     return (int)e;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, dY, dX, partial);
-  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3>), dim3((GI::TOTAL + 255) / 256), dim3(256), 0, st, partial,
+  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3>), dim3((GI::TOTAL + 255) / 256, 8), dim3(256), 0, st, partial,
                      (int)blocks, a, dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
   (void)hipFreeAsync(scratch, st);
   PSDF_LAUNCH_CHECK();

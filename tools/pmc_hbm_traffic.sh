@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/pmc_hbm_$TAG
 mkdir -p $OUT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/$C.log 2>&1
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT/$C.log 2>&1
 done
 cd $R
 python - "$OUT" "$TAG" <<'PY'
@@ -33,7 +33,7 @@ for n in names:
     if "fetch_kib" in res[n] and "write_kib" in res[n]:
         res[n]["hbm_bytes"] = int(2 * res[n]["fetch_kib"] * 1024 + res[n]["write_kib"] * 1024)
 doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 3 "
-                 "--warmup 1 --no-cpu-baseline; MI355X; units KiB per launch (mean over launches)",
+                 "--warmup 1 --no-cpu-baseline --no-extra; MI355X; units KiB per launch (mean over launches)",
        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section; "
                      "confirmed here: mlp_fwd reads 302 MB of features, counter says ~151 MB) -> hbm_bytes = 2*FETCH_SIZE*1024 + "
                      "WRITE_SIZE*1024; WRITE_SIZE calibrated exact on encode_fwd (294912 KiB = 36*2097152*4 B)",

@@ -8,12 +8,12 @@ mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 > $O/bench_final.json 2> $O/bench_final.err
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 cd $R
 python tools/rocpd_summary.py $O/prof_bench $O/bench_kernel_stats.txt > /dev/null 2>&1
 rm -rf $O/prof_bench
 bash tools/pmc_hbm_traffic.sh r02 > $O/pmc_hbm.log 2>&1
-bash tools/pmc_sq.sh mlp_bwd_split_kernel mlpbwdsplit -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_mlp_bwd_split.log 2>&1
+bash tools/pmc_sq.sh mlp_bwd_split_kernel mlpbwdsplit -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_sq_mlp_bwd_split.log 2>&1
 python tools/cfg2_matrix.py > $O/cfg2_matrix.jsonl 2> $O/cfg2_matrix.err
 python tools/cfg3_render.py > $O/cfg3.json 2> $O/cfg3.err
 python tools/sphere_trace_bench.py > $O/cfg5.json 2> $O/cfg5.err
