@@ -118,6 +118,12 @@ def _announce(kind, dims):
                       RuntimeWarning, stacklevel=3)
 
 
+def dx_only_supported(dims):
+    """the data-gradient-only variant exists for the narrow kernel family (csrc/mlp_bwd.hip), not for mlp_wide.hip"""
+    t = [(d + 15) // 16 for d in dims]
+    return backward_supported(dims) and not (len(dims) == 5 and (t[1] > 4 or t[2] > 4))
+
+
 def _torch_gpu_backward(dims, x_fm, weights, biases, gy_fm, need_dx):
     """Backward for widths the fused kernel family does not cover yet (the 128-wide colour net): the same
     Linear/GELU stack re-evaluated with torch ops ON THE GPU (rocBLAS) under autograd.  Not a CPU path."""
@@ -159,6 +165,24 @@ def _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
     return outs[0].t().contiguous(), list(outs[1:1 + n_layers]), list(outs[1 + n_layers:])
 
 
+class _InputGradOnly:
+    """`with input_gradient_only():` -- backward passes of FusedMLP inside it compute d/dx only (the data-gradient-only kernel:
+    no accumulators, more waves per CU).  For torch.autograd.grad(sdf, points, create_graph=True) (models.py:245-251), where
+    autograd would compute the parameter gradients too and drop them."""
+    active = False
+
+    def __enter__(self):
+        self.prev = _InputGradOnly.active
+        _InputGradOnly.active = True
+
+    def __exit__(self, *exc):
+        _InputGradOnly.active = self.prev
+
+
+def input_gradient_only():
+    return _InputGradOnly()
+
+
 class _FusedMLPFunc(torch.autograd.Function):
     """y = MLP(x).  Its backward is itself a Function (_FusedMLPBackFunc) so that `create_graph=True` works: the
     reference differentiates through d sdf / d x (models.py:236-251)."""
@@ -181,6 +205,9 @@ class _FusedMLPFunc(torch.autograd.Function):
     def backward(ctx, gy):
         x = ctx.saved_tensors[0]
         params = ctx.saved_tensors[1:]
+        if _InputGradOnly.active:      # the caller only wants d/dx from this pass
+            outs = _FusedMLPBackFunc.apply(ctx.module, (ctx.needs_input_grad[1], False), x, gy, *params)
+            return (None, outs[0] if ctx.needs_input_grad[1] else None, *([None] * len(params)))
         outs = _FusedMLPBackFunc.apply(ctx.module, ctx.needs_input_grad[1], x, gy, *params)
         dx = outs[0] if ctx.needs_input_grad[1] else None
         return (None, dx, *outs[1:])
@@ -192,6 +219,9 @@ class _FusedMLPBackFunc(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, need_dx, x, gy, *params):
+        need_dw = True
+        if isinstance(need_dx, tuple):
+            need_dx, need_dw = need_dx
         n_layers = module.n_layers
         weights, biases = params[:n_layers], params[n_layers:]
         x_fm = x.t()
@@ -200,8 +230,12 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         gy_fm = gy.t()
         if not gy_fm.is_contiguous():
             gy_fm = gy_fm.contiguous()
-        if backward_supported(module.dims):
+        if not need_dw and dx_only_supported(module.dims):
+            dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=need_dx, need_dw=False)
+        elif backward_supported(module.dims):
             dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=need_dx)
+            if not need_dw:
+                dWs, dbs = [], []
         else:
             dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, need_dx)
         ctx.module, ctx.n_layers = module, n_layers

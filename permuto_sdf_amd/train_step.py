@@ -34,7 +34,7 @@ from . import parallel
 from .bridge import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRendering
 from .encoding import Coarse2Fine, PermutoEncoding
 from .fused import encode_mlp_forward_raw
-from .mlp import FusedMLP, LipshitzMLP, pack_params
+from .mlp import FusedMLP, LipshitzMLP, input_gradient_only, pack_params
 from .neus import l1_loss, neus_alpha
 from .optim import FusedAdamW
 
@@ -155,7 +155,8 @@ class SdfNet(torch.nn.Module):
         with torch.enable_grad():
             points = points.detach().requires_grad_(True)
             sdf, feat = self.forward(points, it)
-            with self.encoding.positions_gradient_only():     # autograd would compute the lattice gradient here and drop it
+            # autograd would compute the lattice and the MLP parameter gradients here and drop them
+            with self.encoding.positions_gradient_only(), input_gradient_only():
                 (grad,) = torch.autograd.grad(sdf, points, torch.ones_like(sdf), create_graph=True, retain_graph=True)
         return sdf, grad, feat
 

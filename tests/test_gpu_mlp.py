@@ -321,3 +321,38 @@ def test_wide_net_backward_matches_float64(dev, dims, N):
         err = float((g.double() - r).abs().max()) / scale
         err_t = float((t.double() - r).abs().max()) / scale
         assert err <= max(4 * err_t, 5e-6), (i, err, err_t)
+
+
+def test_gradient_only_contexts_leave_the_training_gradients_unchanged(dev):
+    """`positions_gradient_only()` / `input_gradient_only()` around torch.autograd.grad(sdf, points, create_graph=True) skip
+    work whose results autograd drops (lattice scatter, MLP parameter gradients of THAT pass); the gradients of a loss on
+    (sdf, d sdf / d x) must be the same with and without them"""
+    import contextlib
+    import numpy as np
+    from permuto_sdf_amd import FusedMLP, PermutoEncoding
+    from permuto_sdf_amd.mlp import input_gradient_only
+    torch.manual_seed(2)
+    enc = PermutoEncoding(3, 2 ** 14, 8, 2, np.geomspace(1.0, 1e-2, 8), concat_points=True, concat_points_scaling=1e-3,
+                          init_scale=1e-1).to(dev)
+    mlp = FusedMLP([enc.output_dims(), 32, 32, 32, 33], reference_init=True).to(dev)
+    win = torch.ones(8, device=dev)
+    pts0 = (torch.rand(4000, 3, device=dev) - 0.5) * 0.8
+    params = [enc.lattice_values] + list(mlp.parameters())
+
+    def run(use_ctx):
+        for p in params:
+            p.grad = None
+        pts = pts0.clone().requires_grad_(True)
+        y = mlp(enc(pts, win))
+        sdf = y[:, 0:1]
+        with (enc.positions_gradient_only() if use_ctx else contextlib.nullcontext()), \
+             (input_gradient_only() if use_ctx else contextlib.nullcontext()):
+            (g,) = torch.autograd.grad(sdf, pts, torch.ones_like(sdf), create_graph=True, retain_graph=True)
+        loss = (sdf ** 2).mean() + ((g.norm(dim=1) - 1.0) ** 2).mean() + y[:, 1:].pow(2).mean() * 0.1
+        loss.backward()
+        return float(loss), [p.grad.clone() for p in params]
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert l0 == l1
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12
