@@ -353,6 +353,6 @@ def test_gradient_only_contexts_leave_the_training_gradients_unchanged(dev):
         return float(loss), [p.grad.clone() for p in params]
     l0, g0 = run(False)
     l1, g1 = run(True)
-    assert l0 == l1
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)      # the create_graph pass runs the data-gradient-only kernel: last-bit differences
     for a, b in zip(g0, g1):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12
