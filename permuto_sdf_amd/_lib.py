@@ -48,7 +48,12 @@ def ptr(t):
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """raw handle of torch's CURRENT stream.  `torch.cuda.current_stream()` builds a Stream object (10 us per call on the
+    host: 1 ms of a 7 ms training step, measured with cProfile); the C binding underneath returns the pointer directly."""
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:      # a torch build without these private bindings
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def check(status, name):

@@ -127,13 +127,14 @@ class RaySamplesPacked:
         out.fixed_nr_of_samples_per_ray = self.fixed_nr_of_samples_per_ray
         if self._exact:
             # producer already packed the samples densely in ray order: the compaction is a narrow view
-            n = min(int(self.cur_nr_samples.item()), self.max_nr_samples)
+            cur = int(self.cur_nr_samples.item())      # the one host sync of this call
+            n = min(cur, self.max_nr_samples)
             out.max_nr_samples = n
             for name in ("samples_pos", "samples_pos_4d", "samples_dirs", "samples_z", "samples_dt", "samples_sdf"):
                 setattr(out, name, getattr(self, name)[:n])
             out.ray_fixed_dt = self.ray_fixed_dt
             out.ray_start_end_idx = self.ray_start_end_idx
-            if n < int(self.cur_nr_samples.item()):  # pool overflow: drop the rays that did not fit
+            if n < cur:  # pool overflow: drop the rays that did not fit
                 se = self.ray_start_end_idx
                 bad = se[:, 1] > n
                 out.ray_start_end_idx = torch.where(bad[:, None], torch.zeros_like(se), se)
