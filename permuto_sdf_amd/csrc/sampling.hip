@@ -26,8 +26,18 @@ __host__ __device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
   v = (v * 0x00000005u) & 0x49249249u;
   return v;
 }
+// the same spreading for v < 1024 (every in-grid coordinate) with shifts instead of the four quarter-rate integer multiplies:
+// v * (2^k + 1) = v | (v << k) when the two terms share no bit, which the masks guarantee from 10 bits on
+__host__ __device__ __forceinline__ uint32_t expand_bits10_small(uint32_t v) {
+  v = (v | (v << 16)) & 0xFF0000FFu;
+  v = (v | (v << 8)) & 0x0F00F00Fu;
+  v = (v | (v << 4)) & 0xC30C30C3u;
+  v = (v | (v << 2)) & 0x49249249u;
+  return v;
+}
 __host__ __device__ __forceinline__ uint32_t morton3(uint32_t x, uint32_t y, uint32_t z) {
-  return expand_bits10(x) | (expand_bits10(y) << 1) | (expand_bits10(z) << 2);
+  if ((x | y | z) < 1024u) return expand_bits10_small(x) | (expand_bits10_small(y) << 1) | (expand_bits10_small(z) << 2);
+  return expand_bits10(x) | (expand_bits10(y) << 1) | (expand_bits10(z) << 2);   // out-of-grid coordinates: the reference's arithmetic
 }
 __host__ __device__ __forceinline__ uint32_t compact_bits10(uint32_t x) {
   x &= 0x49249249u;
@@ -48,13 +58,20 @@ struct Grid {
   int n;         // voxels per dimension (power of two)
   float extent;  // edge length of the cube
   float tx, ty, tz;
+  // The reference divides by `extent` and by `n` in every DDA step (two correctly rounded fp32 divisions, ~10 instructions
+  // each, on the dependent chain that bounds these loops).  Dividing by 1.0 is the identity and dividing by a power of two is
+  // an exact scaling, so for the grids the reference builds (extent 1, n = 256) both become bit-identical cheap forms.
+  float inv_n;   // 1 / n when n is a power of two (exact), else 0: use the division
+  int unit;      // extent == 1
+  __device__ __forceinline__ float div_n(float x) const { return inv_n != 0.f ? x * inv_n : x / n; }
+  __device__ __forceinline__ float div_extent(float x) const { return unit ? x : x / extent; }
   __device__ __forceinline__ int nr_voxels() const { return n * n * n; }
   // voxel centre (or corner) of a Morton index (OccupancyGridGPU.cuh:112-155)
   __device__ __forceinline__ v3 idx_to_pos(uint32_t idx, bool centre) const {
     float x = (float)compact_bits10(idx), y = (float)compact_bits10(idx >> 1), z = (float)compact_bits10(idx >> 2);
-    x = x / n;
-    y = y / n;
-    z = z / n;
+    x = div_n(x);
+    y = div_n(y);
+    z = div_n(z);
     x = x - 0.5f;
     y = y - 0.5f;
     z = z - 0.5f;
@@ -68,7 +85,7 @@ struct Grid {
   }
   // world position -> Morton index (OccupancyGridGPU.cuh:158-193, get_center_of_voxel=false)
   __device__ __forceinline__ int pos_to_idx(v3 p) const {
-    float x = (p.x - tx) / extent, y = (p.y - ty) / extent, z = (p.z - tz) / extent;
+    float x = div_extent(p.x - tx), y = div_extent(p.y - ty), z = div_extent(p.z - tz);
     x = (x + 0.5f) * n;
     y = (y + 0.5f) * n;
     z = (z + 0.5f) * n;
@@ -80,13 +97,14 @@ struct Grid {
 __device__ __forceinline__ int sgn(float x) { return x > 0 ? 1 : (x < 0 ? -1 : 0); }
 
 // DDA step to the next voxel face, in world units (OccupancyGridGPU.cuh:95-109)
-__device__ __forceinline__ float dist_to_next_voxel(v3 pos, v3 dir, v3 idir, int n) {
+__device__ __forceinline__ float dist_to_next_voxel(v3 pos, v3 dir, v3 idir, const Grid& g) {
+  const int n = g.n;
   pos = (float)n * pos;
   const float tx = (floorf(pos.x + 0.5f + 0.5f * sgn(dir.x)) - pos.x) * idir.x;
   const float ty = (floorf(pos.y + 0.5f + 0.5f * sgn(dir.y)) - pos.y) * idir.y;
   const float tz = (floorf(pos.z + 0.5f + 0.5f * sgn(dir.z)) - pos.z) * idir.z;
   const float t = fminf(fminf(fabsf(tx), fabsf(ty)), fabsf(tz));
-  return fmaxf(t / n, 0.0f);
+  return fmaxf(g.div_n(t), 0.0f);
 }
 __device__ __forceinline__ v3 safe_inverse(v3 d) {
   v3 r;
@@ -189,7 +207,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       const v3 pos = along(org, t, dir);
       const int vox = g.pos_to_idx(pos);
       if (!g.in_range(vox)) break;
-      const float d = dist_to_next_voxel(pos, dir, idir, g.n);
+      const float d = dist_to_next_voxel(pos, dir, idir, g);
       t += d;
       t += DDA_EPS;
       if (occ[vox]) {
@@ -228,7 +246,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
         t += spacing;
         created++;
       } else if (USE_GRID) {
-        float delta = dist_to_next_voxel(pos, dir, idir, g.n);
+        float delta = dist_to_next_voxel(pos, dir, idir, g);
         if (jitter) delta = delta + spacing * rng.next_float();
         t += delta;
         t += DDA_EPS;
@@ -306,7 +324,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const v3 pos = along(org, t, dir);
     const int vox = g.pos_to_idx(pos);
     if (!g.in_range(vox)) break;
-    const float d = dist_to_next_voxel(pos, dir, idir, g.n);
+    const float d = dist_to_next_voxel(pos, dir, idir, g);
     t += d;
     t += DDA_EPS;
     if (occ[vox]) {  // the stored z is the t AFTER the step, the position the one before it (as in the reference)
@@ -361,7 +379,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       st3(pts + 3 * (int64_t)i, pos);
       break;
     }
-    const float d = dist_to_next_voxel(pos, dir, idir, g.n);
+    const float d = dist_to_next_voxel(pos, dir, idir, g);
     t += d;
     t += DDA_EPS;
     if (occ[vox]) {
@@ -396,7 +414,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const v3 pos_ = along(org, t, dir);
     const int vox = g.pos_to_idx(pos_);
     if (!g.in_range(vox)) break;
-    const float d = dist_to_next_voxel(pos_, dir, idir, g.n);
+    const float d = dist_to_next_voxel(pos_, dir, idir, g);
     t += d;
     t += DDA_EPS;
     if (occ[vox]) {
@@ -441,7 +459,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       out = q;
       break;
     }
-    const float d = dist_to_next_voxel(q, dir, idir, g.n);
+    const float d = dist_to_next_voxel(q, dir, idir, g);
     t += d;
     t += DDA_EPS;
     if (occ[vox]) {
@@ -722,7 +740,10 @@ __global__ void __launch_bounds__(1024)
   if (threadIdx.x == 0 && total_out) *total_out = carry_s;
 }
 
-inline Grid mk_grid(int n, float extent, const float* tr) { return Grid{n, extent, tr[0], tr[1], tr[2]}; }
+inline Grid mk_grid(int n, float extent, const float* tr) {
+  const bool pow2 = n > 0 && (n & (n - 1)) == 0;
+  return Grid{n, extent, tr[0], tr[1], tr[2], pow2 ? 1.0f / (float)n : 0.f, extent == 1.0f ? 1 : 0};
+}
 #define GRID1(n) dim3(psdf_blocks((n), PSDF_BLOCK)), dim3(PSDF_BLOCK), 0, st
 inline unsigned wave_ray_grid(int nr_rays) {
   unsigned b = psdf_blocks(nr_rays, PSDF_BLOCK / 64);
@@ -791,7 +812,7 @@ int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float e
   if (nr_rays <= 0) return PSDF_OK;
   if (max_nr_samples_per_ray < 0 || !scratch) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  Grid g = use_grid ? mk_grid(nr_voxels_per_dim, extent, grid_translation) : Grid{1, 1.f, 0.f, 0.f, 0.f};
+  Grid g = use_grid ? mk_grid(nr_voxels_per_dim, extent, grid_translation) : Grid{1, 1.f, 0.f, 0.f, 0.f, 1.f, 1};
   Pcg rng{rng_state, rng_inc};
   int* counts = scratch;
   int* offsets = scratch + nr_rays;
