@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpsdf_hip.so")
+LIB_PATH = os.environ.get("PSDF_LIB_PATH") or os.path.join(_HERE, "lib", "libpsdf_hip.so")   # env: A/B builds of the kernels
 _lib = None
 
 c_i = ctypes.c_int

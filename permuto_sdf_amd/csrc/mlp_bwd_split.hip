@@ -56,17 +56,35 @@ __device__ __forceinline__ float erf_fast(float a) {
   return t > 0.927734375f ? hi : lo;
 }
 // gelu and its derivative Phi(z) + z phi(z) from one erf and one exp
-#ifndef PSDF_SPLIT_GELU_POLY
-__device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
+// Three interchangeable evaluators; the kernel picks per instantiation (see gelu_both below).
+// tools/gelu_fit_rational.py: gelu AND gelu' from ONE exponential and ONE reciprocal (the recompute needs both):
+//   E = exp(-z^2/2), t = 1/(1 + p|z|), Phi(-|z|) = t P6(t) E, cdf = z < 0 ? Phi(-|z|) : 1 - Phi(-|z|),
+//   gelu = z cdf, gelu' = cdf + z E / sqrt(2 pi).  17 instructions against ~30; error against float64: gelu 1.8e-7 |z|
+//   (the fp32 formula 0.5 z (1 + erf(z / sqrt 2)) itself: 1.1e-7 |z|), gelu' 1.9e-7.
+__device__ __forceinline__ void gelu_rational(float z, float& hval, float& gprime) {
+  const float E = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(z), 0.39f, 1.0f));
+  float q = 5.384693295e-02f;
+  q = fmaf(q, t, -2.582434118e-01f);
+  q = fmaf(q, t, 3.751679361e-01f);
+  q = fmaf(q, t, -1.663514599e-02f);
+  q = fmaf(q, t, 1.944366544e-01f);
+  q = fmaf(q, t, 1.514270604e-01f);
+  const float tail = q * t * E;
+  const float cdf = z < 0.f ? tail : 1.0f - tail;
+  hval = z * cdf;
+  gprime = fmaf(z, E * 0.3989422804014327f, cdf);
+}
+// torch's formula 0.5 z (1 + erf(z / sqrt 2)): one erf (itself one exp) and one more exp
+__device__ __forceinline__ void gelu_erf(float z, float& hval, float& gprime) {
   const float cdf = fmaf(0.5f, erf_fast(z * 0.70710678118654752440f), 0.5f);
   const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
   hval = z * cdf;
   gprime = fmaf(z, pdf, cdf);
 }
-#else
 // tools/gelu_fit.py: e = Phi(-t) = exp2(P8(t)), t = min(|z|, 5.75); gelu = max(z, 0) - t e (error 8.6e-8 |z| against float64, the
 // fp32 erf formula itself has 1.06e-7 |z|); gelu' = (z < 0 ? e : 1 - e) + z phi(t) from the same e (1.5e-7)
-__device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
+__device__ __forceinline__ void gelu_poly(float z, float& hval, float& gprime) {
   const float t = fminf(fabsf(z), 5.75f);
   float p = -2.772052994e-06f;
   p = fmaf(p, t, 3.862077210e-05f);
@@ -83,7 +101,14 @@ __device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
   const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(t * t * -0.72134752044448170368f);
   gprime = fmaf(copysignf(t, z), pdf, cdf);
 }
-#endif
+// Measured on the headline batch (profiles/r02_mlp_bwd_prototype_timings.txt): rational 1.37 ms, erf 1.47 ms, poly 1.47 ms
+// for the double-staged instantiation (zero scratch in all three).  The single-staged instantiations (K0 > 36) are at the
+// register limit and the rational form's extra live values spill there (32-116 B scratch, slower), so they keep erf.
+template <bool RATIONAL>
+__device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
+  if constexpr (RATIONAL) gelu_rational(z, hval, gprime);
+  else gelu_erf(z, hval, gprime);
+}
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
@@ -211,13 +236,14 @@ __device__ __forceinline__ void zero_init(f32x4 (&acc)[NTILE]) {
   for (int t = 0; t < NTILE; t++) acc[t] = zero4();
 }
 // in place: acc <- gelu(acc), gp <- gelu'(acc)
+template <bool RATIONAL>
 __device__ __forceinline__ void act_both(f32x4 (&acc)[NT], f32x4 (&gp)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; t++) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float hv, d;
-      gelu_both(acc[t][r], hv, d);
+      gelu_both<RATIONAL>(acc[t][r], hv, d);
       acc[t][r] = hv;
       gp[t][r] = d;
     }
@@ -344,20 +370,20 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the LDS reads above have returned before the DMA overwrites
       if (tile + tstride < ntiles) prefetch(tile + tstride, stage);
     }
-    act_both(a, g1);  // a = h1
+    act_both<DOUBLE>(a, g1);  // a = h1
     bias_init<NT>(b, tail + HID, g);
     chain<NT>(a, b, lds + OFF_W1, lane, [&](int s, const BP& p) {
       h1T[2 * s] = transpose_f32(p, id[0]);
       h1T[2 * s + 1] = transpose_f32(p, id[1]);
     });
-    act_both(b, g2);  // b = h2
+    act_both<DOUBLE>(b, g2);  // b = h2
     bias_init<NT>(a, tail + 2 * HID, g);
     chain<NT>(b, a, lds + OFF_W2, lane, [&](int s, const BP& p) {
       h2T[2 * s] = transpose_f32(p, id[0]);
       h2T[2 * s + 1] = transpose_f32(p, id[1]);
     });
     f32x4 dz[NT];
-    act_both(a, dz);  // a = h3, dz = gelu'(z3) for now
+    act_both<DOUBLE>(a, dz);  // a = h3, dz = gelu'(z3) for now
     // ---------------- output layer: dW4 = sum dy h3, db4 = sum dy, dZ3 = w4 dy gelu'(z3); samples past N carry dy = 0,
     // which zeroes every contribution of theirs below
     {
