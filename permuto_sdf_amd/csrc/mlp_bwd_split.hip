@@ -6,6 +6,7 @@
 //   * 16-sample tiles on v_mfma_f32_16x16x32_bf16, one wave per SIMD, dW accumulators persistent in registers (176);
 //   * forward recomputed from X; gelu and gelu' from one erf + one exp;
 //   * the sample<->feature transposes that the dW products need are MFMAs against a 0/1 operand (no LDS, no VALU);
+//   * a dW MFMA (K = samples, only 16 of 32 slots filled by a tile) carries two piece products in its two K halves;
 //   * both weight orientations as pre-split pieces in LDS (142 KB), built per call by mlp_split_pack_kernel;
 //   * the next tile's inputs arrive by LDS-DMA (global_load_lds) while the current tile is computed (SQ counters of the
 //     version without it: 39 % of the wave's time in s_waitcnt), and loop-invariant lane arithmetic is re-materialised
@@ -137,25 +138,33 @@ __device__ __forceinline__ void split8(const float (&x)[8], BP& o) {
   o.p[1] = __builtin_bit_cast(bf16x8, q1);
   o.p[2] = __builtin_bit_cast(bf16x8, q2);
 }
-// four fp32 (a feature-lane tile: samples 4 g + r) -> dW operand pieces: k-slots (g, 0..3), slots (g, 4..7) zero
-__device__ __forceinline__ void split4(const f32x4& t, BP& o) {
+// dW operands.  A transposed tile gives a lane only four samples (k-slots (g, 0..3) of the 32-deep MFMA); instead of
+// leaving slots (g, 4..7) zero they carry ANOTHER PIECE of the same four samples, so that one MFMA sums two of the six
+// piece products:  [a0|a2] x [b2|b0] = a0 b2 + a2 b0,  [a1|a1] x [b0|b1] = a1 b0 + a1 b1,  [a0|a0] x [b0|b1] = a0 b0 + a0 b1.
+// Three MFMAs per 16x16 block of dW instead of six (132 instead of 264 per tile).
+struct AT {  // dZ side
+  bf16x8 t02, t11, t00;
+};
+struct BT {  // H side
+  bf16x8 t20, t01;
+};
+__device__ __forceinline__ bf16x8 halves(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
+  const u32x4 q = {a0, a1, b0, b1};
+  return __builtin_bit_cast(bf16x8, q);
+}
+// four fp32 (a feature-lane tile: samples 4 g + r) -> H-side operands
+__device__ __forceinline__ void split4(const f32x4& t, BT& o) {
   float r1[4], r2[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     r1[j] = t[j] - __uint_as_float(__float_as_uint(t[j]) & 0xFFFF0000u);
     r2[j] = r1[j] - __uint_as_float(__float_as_uint(r1[j]) & 0xFFFF0000u);
   }
-  const u32x4 q0 = {top_pair(t[1], t[0]), top_pair(t[3], t[2]), 0u, 0u};
-  const u32x4 q1 = {top_pair(r1[1], r1[0]), top_pair(r1[3], r1[2]), 0u, 0u};
-  const u32x4 q2 = {top_pair(r2[1], r2[0]), top_pair(r2[3], r2[2]), 0u, 0u};
-  o.p[0] = __builtin_bit_cast(bf16x8, q0);
-  o.p[1] = __builtin_bit_cast(bf16x8, q1);
-  o.p[2] = __builtin_bit_cast(bf16x8, q2);
-}
-// bf16-valued registers of a transposed piece -> dW operand
-__device__ __forceinline__ bf16x8 pack4(const f32x4& v) {
-  const u32x4 q = {top_pair(v[1], v[0]), top_pair(v[3], v[2]), 0u, 0u};
-  return __builtin_bit_cast(bf16x8, q);
+  const uint32_t p0a = top_pair(t[1], t[0]), p0b = top_pair(t[3], t[2]);
+  const uint32_t p1a = top_pair(r1[1], r1[0]), p1b = top_pair(r1[3], r1[2]);
+  const uint32_t p2a = top_pair(r2[1], r2[0]), p2b = top_pair(r2[3], r2[2]);
+  o.t20 = halves(p2a, p2b, p0a, p0b);
+  o.t01 = halves(p0a, p0b, p1a, p1b);
 }
 
 // out[t] += W(tile t, k-step s) x operand pieces: six products, smallest first; two tiles at a time so that consecutive
@@ -207,22 +216,24 @@ __device__ __forceinline__ f32x4 transpose_f32(const BP& b, bf16x8 id) {
   o = MFMA16(b.p[0], id, o);
   return o;
 }
-// piece-wise transpose: dW operand pieces of a 16-feature tile, plus this lane's fp32 sum for the bias gradient
-__device__ __forceinline__ void transpose_pieces(const BP& b, bf16x8 id, BP& out, float& sum) {
+// piece-wise transpose: dZ-side dW operands of a 16-feature tile, plus this lane's fp32 sum for the bias gradient
+__device__ __forceinline__ void transpose_pieces(const BP& b, bf16x8 id, AT& out, float& sum) {
+  uint32_t q[3][2];
 #pragma unroll
   for (int p = 0; p < 3; p++) {
-    const f32x4 o = MFMA16(b.p[p], id, zero4());
+    const f32x4 o = MFMA16(b.p[p], id, zero4());   // bf16-valued: the top halves are the piece
     sum += (o[0] + o[1]) + (o[2] + o[3]);
-    out.p[p] = pack4(o);
+    q[p][0] = top_pair(o[1], o[0]);
+    q[p][1] = top_pair(o[3], o[2]);
   }
+  out.t02 = halves(q[0][0], q[0][1], q[2][0], q[2][1]);
+  out.t11 = halves(q[1][0], q[1][1], q[1][0], q[1][1]);
+  out.t00 = halves(q[0][0], q[0][1], q[0][0], q[0][1]);
 }
-__device__ __forceinline__ f32x4 dw_mac(f32x4 acc, const BP& A, const BP& B) {
-  acc = MFMA16(A.p[2], B.p[0], acc);
-  acc = MFMA16(A.p[1], B.p[1], acc);
-  acc = MFMA16(A.p[0], B.p[2], acc);
-  acc = MFMA16(A.p[1], B.p[0], acc);
-  acc = MFMA16(A.p[0], B.p[1], acc);
-  acc = MFMA16(A.p[0], B.p[0], acc);
+__device__ __forceinline__ f32x4 dw_mac(f32x4 acc, const AT& A, const BT& B) {
+  acc = MFMA16(A.t02, B.t20, acc);   // smallest first
+  acc = MFMA16(A.t11, B.t01, acc);
+  acc = MFMA16(A.t00, B.t01, acc);
   return acc;
 }
 template <int NTILE>
@@ -268,14 +279,14 @@ __device__ __forceinline__ void chain(const f32x4 (&in)[NT], f32x4 (&out)[NTILE]
 template <int NTO, int NTI>
 __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO], const u32x4* __restrict__ wT, int lane,
                                           const bf16x8 (&id)[2], const f32x4 (&hT)[NTI], f32x4 (&dW)[NT][NTI], float (&db)[NT]) {
-  BP A[NT];
+  AT A[NT];
   chain<NTO>(dz, dh, wT, lane, [&](int s, const BP& b) {
     transpose_pieces(b, id[0], A[2 * s], db[2 * s]);
     transpose_pieces(b, id[1], A[2 * s + 1], db[2 * s + 1]);
   });
 #pragma unroll
   for (int ti = 0; ti < NTI; ti++) {
-    BP B;
+    BT B;
     split4(hT[ti], B);
 #pragma unroll
     for (int to = 0; to < NT; to++) dW[to][ti] = dw_mac(dW[to][ti], A[to], B);
