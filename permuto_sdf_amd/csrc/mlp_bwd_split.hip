@@ -103,8 +103,9 @@ __device__ __forceinline__ void gelu_poly(float z, float& hval, float& gprime) {
   gprime = fmaf(copysignf(t, z), pdf, cdf);
 }
 // Measured on the headline batch (profiles/r02_mlp_bwd_prototype_timings.txt): rational 1.37 ms, erf 1.47 ms, poly 1.47 ms
-// for the double-staged instantiation (zero scratch in all three).  The single-staged instantiations (K0 > 36) are at the
-// register limit and the rational form's extra live values spill there (32-116 B scratch, slower), so they keep erf.
+// for the double-staged instantiation (zero scratch in all three).  The widest instantiation (K0 > 48) is at the register
+// limit and the rational form's extra live values spill there (44 B scratch; a spill reload waits for the LDS-DMA in
+// flight), so it keeps erf.
 template <bool RATIONAL>
 __device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
   if constexpr (RATIONAL) gelu_rational(z, hval, gprime);
@@ -381,20 +382,20 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the LDS reads above have returned before the DMA overwrites
       if (tile + tstride < ntiles) prefetch(tile + tstride, stage);
     }
-    act_both<DOUBLE>(a, g1);  // a = h1
+    act_both<NT0 == 3>(a, g1);  // a = h1
     bias_init<NT>(b, tail + HID, g);
     chain<NT>(a, b, lds + OFF_W1, lane, [&](int s, const BP& p) {
       h1T[2 * s] = transpose_f32(p, id[0]);
       h1T[2 * s + 1] = transpose_f32(p, id[1]);
     });
-    act_both<DOUBLE>(b, g2);  // b = h2
+    act_both<NT0 == 3>(b, g2);  // b = h2
     bias_init<NT>(a, tail + 2 * HID, g);
     chain<NT>(b, a, lds + OFF_W2, lane, [&](int s, const BP& p) {
       h2T[2 * s] = transpose_f32(p, id[0]);
       h2T[2 * s + 1] = transpose_f32(p, id[1]);
     });
     f32x4 dz[NT];
-    act_both<DOUBLE>(a, dz);  // a = h3, dz = gelu'(z3) for now
+    act_both<NT0 == 3>(a, dz);  // a = h3, dz = gelu'(z3) for now
     // ---------------- output layer: dW4 = sum dy h3, db4 = sum dy, dZ3 = w4 dy gelu'(z3); samples past N carry dy = 0,
     // which zeroes every contribution of theirs below
     {
