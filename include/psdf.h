@@ -193,17 +193,27 @@ int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float e
     const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs, const float* ray_t_entry, const
     float* ray_t_exit, float min_dist_between_samples, int max_nr_samples_per_ray, int max_nr_samples, uint64_t
     rng_state, uint64_t rng_inc, int jitter, float* samples_pos, float* samples_dirs, float* samples_z, float*
-    samples_dt, float* ray_fixed_dt, int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream);
+    samples_dt, float* ray_fixed_dt, int* ray_start_end_idx, int* cur_nr_samples, int* scratch, const uint32_t*
+    coarse_mask, void* stream);
 
 /* replaces: OccupancyGrid::compute_first_sample_start_of_occupied_regions, src/OccupancyGrid.cu:259-300 */
 int psdf_first_hit_samples(int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation, const
     uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs, const float* ray_t_entry, const float*
     ray_t_exit, int max_nr_samples, float* samples_pos, float* samples_dirs, float* samples_z, float* samples_dt,
-    float* ray_fixed_dt, int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream);
+    float* ray_fixed_dt, int* ray_start_end_idx, int* cur_nr_samples, int* scratch, const uint32_t* coarse_mask,
+    void* stream);
 
 /* replaces: OccupancyGrid::advance_sample_to_next_occupied_voxel, src/OccupancyGrid.cu:302-337 */
 int psdf_advance_to_next_occupied_voxel(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
-    const uint8_t* grid_occupancy, const float* samples_dirs, float* samples_pos, uint8_t* is_within_bounds, void*
+    const uint8_t* grid_occupancy, const float* samples_dirs, float* samples_pos, uint8_t* is_within_bounds, const
+    uint32_t* coarse_mask, void* stream);
+
+/* helper of the four marches above/below (no reference counterpart): "some voxel occupied" bit per 8x8x8 block of the
+   Morton-ordered occupancy (kernels/permuto_sdf/OccupancyGridGPU.cuh:50-55 gives the order), psdf_occupancy_coarse_words(n)
+   32-bit words; the marches copy it into LDS and answer the probes of empty blocks there (same results bit for bit).
+   Optional everywhere: coarse_mask = NULL probes the bytes only.  Rebuild after every change of the occupancy. */
+int psdf_occupancy_coarse_words(int nr_voxels_per_dim);
+int psdf_occupancy_coarse_mask(int nr_voxels_per_dim, const uint8_t* grid_occupancy, uint32_t* coarse_mask, void*
     stream);
 
 /* replaces: RaySampler::compute_samples_bg, src/RaySampler.cu:37-101 */
@@ -245,10 +255,10 @@ int psdf_random_rays_from_reel(int nr_rays, int nr_images, int height, int width
    iteration step :167-185), with one slot per ray so that the loop is a fixed launch sequence (hipGraph) */
 int psdf_first_hit_dense(int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation, const
     uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs, const float* ray_t_entry, const float*
-    ray_t_exit, float* pos, uint8_t* converged, void* stream);
+    ray_t_exit, float* pos, uint8_t* converged, const uint32_t* coarse_mask, void* stream);
 int psdf_sphere_trace_step(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const
     uint8_t* grid_occupancy, const float* dirs, const float* sdf, float sdf_multiplier, float sdf_converged_thresh,
-    float* pts, uint8_t* converged, void* stream);
+    float* pts, uint8_t* converged, const uint32_t* coarse_mask, void* stream);
 
 /* ---- volume_rendering.hip ---- */
 /* replaces: (helper) replaces the atomicAdd slot counters, e.g. kernels/permuto_sdf/OccupancyGridGPU.cuh:599 */

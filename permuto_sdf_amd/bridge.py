@@ -240,6 +240,7 @@ class Sphere:
 class OccupancyGrid:
     _rng = Pcg32()  # process-global, like the reference's static member (include/permuto_sdf/OccupancyGrid.cuh:58)
     POOL = 1024 * 1024 * 2  # the reference's fixed sample pool (src/OccupancyGrid.cu:216)
+    use_coarse_mask = True  # DDA probes of empty 8x8x8 blocks answered from an LDS bit mask (same results; _coarse())
 
     def __init__(self, nr_voxels_per_dim, grid_extent, grid_translation, device=None):
         self.m_nr_voxels_per_dim = int(nr_voxels_per_dim)
@@ -295,6 +296,24 @@ class OccupancyGrid:
             raise ValueError("grid occupancy must be a contiguous bool tensor")
         L.require_cuda(occ)
         return occ
+
+    COARSE_MIN_RAYS = 4096
+
+    def _coarse(self, count):
+        """Coarse mask of the CURRENT occupancy for the DDA kernels (csrc/sampling.hip, struct Occ): one bit per 8x8x8
+        block, rebuilt on every use because Python may have written into the occupancy tensor since (one 16-MiB read).
+        Measured (tools/dda_march_bench.py, 256^3 shell grid): the march of 16 384 rays 707 -> 600 us, of 262 144 rays
+        1.29 -> 1.18 ms; for the ~700 rays of a training step the march is a latency chain per ray and the extra LDS
+        hop makes it 8 % slower, so small batches (and grids without a mask) get None."""
+        words = L.lib().psdf_occupancy_coarse_words(self.m_nr_voxels_per_dim)
+        if words == 0 or not OccupancyGrid.use_coarse_mask or count < OccupancyGrid.COARSE_MIN_RAYS:
+            return None
+        buf = getattr(self, "_coarse_buf", None)
+        occ = self._occ()
+        if buf is None or buf.numel() != words or buf.device != occ.device:
+            buf = self._coarse_buf = torch.empty(words, dtype=torch.int32, device=occ.device)
+        L.call("psdf_occupancy_coarse_mask", L.c_i(self.m_nr_voxels_per_dim), L.ptr(occ), L.ptr(buf), L.stream())
+        return buf
 
     def compute_grid_points(self, randomize_position):
         n = self.get_nr_voxels()
@@ -374,7 +393,7 @@ class OccupancyGrid:
                L.ptr(te), L.ptr(tx), L.c_f(min_dist_between_samples), L.c_i(int(max_nr_samples_per_ray)),
                L.c_i(rs.max_nr_samples), *rng.args(), L.c_i(int(jitter_samples)), L.ptr(rs.samples_pos),
                L.ptr(rs.samples_dirs), L.ptr(rs.samples_z), L.ptr(rs.samples_dt), L.ptr(rs.ray_fixed_dt),
-               L.ptr(rs.ray_start_end_idx), L.ptr(rs.cur_nr_samples), L.ptr(scratch), L.stream())
+               L.ptr(rs.ray_start_end_idx), L.ptr(rs.cur_nr_samples), L.ptr(scratch), L.ptr(self._coarse(R)), L.stream())
         if jitter_samples:
             rng.advance()
         rs._exact = True
@@ -390,7 +409,7 @@ class OccupancyGrid:
         L.call("psdf_first_hit_samples", L.c_i(R), *self._grid_args(), L.ptr(self._occ()), L.ptr(o), L.ptr(d), L.ptr(te),
                L.ptr(tx), L.c_i(rs.max_nr_samples), L.ptr(rs.samples_pos), L.ptr(rs.samples_dirs), L.ptr(rs.samples_z),
                L.ptr(rs.samples_dt), L.ptr(rs.ray_fixed_dt), L.ptr(rs.ray_start_end_idx), L.ptr(rs.cur_nr_samples),
-               L.ptr(scratch), L.stream())
+               L.ptr(scratch), L.ptr(self._coarse(R)), L.stream())
         rs._exact = True
         return rs
 
@@ -403,7 +422,7 @@ class OccupancyGrid:
         n = p.shape[0]
         within = torch.ones((n, 1), dtype=torch.bool, device=p.device)
         L.call("psdf_advance_to_next_occupied_voxel", L.c_i(n), *self._grid_args(), L.ptr(self._occ()), L.ptr(d), L.ptr(p),
-               L.ptr(within), L.stream())
+               L.ptr(within), L.ptr(self._coarse(n)), L.stream())
         return p, within
 
     def create_cubes_for_occupied_voxels(self):
@@ -455,7 +474,7 @@ class RaySampler:
                L.ptr(d), L.ptr(te), L.ptr(tx), L.c_f(min_dist_between_samples), L.c_i(int(max_nr_samples_per_ray)),
                L.c_i(rs.max_nr_samples), *rng.args(), L.c_i(int(randomize_position)), L.ptr(rs.samples_pos),
                L.ptr(rs.samples_dirs), L.ptr(rs.samples_z), L.ptr(rs.samples_dt), L.ptr(rs.ray_fixed_dt),
-               L.ptr(rs.ray_start_end_idx), L.ptr(rs.cur_nr_samples), L.ptr(scratch), L.stream())
+               L.ptr(rs.ray_start_end_idx), L.ptr(rs.cur_nr_samples), L.ptr(scratch), None, L.stream())
         if randomize_position:
             rng.advance()
         rs._exact = True

@@ -33,6 +33,50 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#include <mutex>
+#include <vector>
+
+namespace psdf {
+void* stream_scratch(size_t bytes, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  struct Entry {
+    hipStream_t st;
+    int dev;
+    void* ptr;
+    size_t cap;
+  };
+  static std::mutex mu;
+  static std::vector<Entry> entries;
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* e = nullptr;
+  for (auto& x : entries)
+    if (x.st == st && x.dev == dev) e = &x;
+  if (e && e->cap >= bytes) return e->ptr;
+  size_t cap = bytes + bytes / 2;
+  if (cap < ((size_t)1 << 22)) cap = (size_t)1 << 22;
+  void* np = nullptr;
+  if (hipMalloc(&np, cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (e) {
+    (void)hipStreamSynchronize(st);  // the old buffer may still be in use by queued work of this stream
+    (void)hipFree(e->ptr);
+    e->ptr = np;
+    e->cap = cap;
+  } else {
+    entries.push_back(Entry{st, dev, np, cap});
+  }
+  return np;
+}
+}  // namespace psdf
+
 namespace {
 
 struct Plan16 {
@@ -155,42 +199,17 @@ __global__ void __launch_bounds__(256) mlp_grad_reduce_kernel(Plan16 p, BwdPtrs 
   }
 }
 
-// The stream-ordered allocation costs ~0.2 ms of host time per call: it pays only when the launch is long enough to hide
-// it (the cfg-4 training step, 49 K samples per call and host bound, ran 8 % slower with it: 9.39 against 8.66 ms).
-constexpr int64_t GRAD_SCRATCH_MIN_N = 1 << 19;
-
-// Stream-ordered scratch for the workgroup images; NULL (-> atomics) while the stream is being captured or when the
-// allocation fails.
+// Workgroup gradient images live in the library's per-stream scratch (psdf::stream_scratch); NULL (-> float atomics into
+// dW / db: ~21 G/s on this chip, 0.2 ms for the 64-wide nets) only while the stream is being captured.
 static float* grad_scratch_alloc(size_t floats, hipStream_t st) {
   static const bool force_atomics = getenv("PSDF_MLP_GRAD_ATOMICS") != nullptr;  // A/B switch for measurements
   if (force_atomics) return nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  static bool pool_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !pool_set[dev]) {
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-      uint64_t keep = ~(uint64_t)0;  // keep freed blocks in the pool: the same size is asked for every step
-      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
-    pool_set[dev] = true;
-  }
-  void* ptr = nullptr;
-  if (hipMallocAsync(&ptr, floats * sizeof(float), st) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  return (float*)ptr;
+  return (float*)psdf::stream_scratch(floats * sizeof(float), st);
 }
 
-static void grad_scratch_reduce_and_free(const Plan16& p, const BwdPtrs& a, int nimages, hipStream_t st) {
+static void grad_scratch_reduce(const Plan16& p, const BwdPtrs& a, int nimages, hipStream_t st) {
   if (!a.partial) return;
   hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((unsigned)((p.total + 63) / 64)), dim3(256), 0, st, p, a, nimages);
-  (void)hipFreeAsync(a.partial, st);
 }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -1065,9 +1084,9 @@ int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, c
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return (int)e;
   BwdPtrs ap = a;
-  ap.partial = N >= GRAD_SCRATCH_MIN_N ? grad_scratch_alloc((size_t)blocks * p.total, st) : nullptr;
+  ap.partial = grad_scratch_alloc((size_t)blocks * p.total, st);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, V, dY, dX2, ap);
-  grad_scratch_reduce_and_free(p, ap, (int)blocks, st);
+  grad_scratch_reduce(p, ap, (int)blocks, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1103,13 +1122,13 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), shmem, st, p, N, X, dY, dX, ap);                 \
   } while (0)
   BwdPtrs ap = a;
-  ap.partial = N >= GRAD_SCRATCH_MIN_N ? grad_scratch_alloc((size_t)blocks * p.total, st) : nullptr;
+  ap.partial = grad_scratch_alloc((size_t)blocks * p.total, st);
   if (dX)
     GO(true);
   else
     GO(false);
 #undef GO
-  grad_scratch_reduce_and_free(p, ap, (int)blocks, st);
+  grad_scratch_reduce(p, ap, (int)blocks, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

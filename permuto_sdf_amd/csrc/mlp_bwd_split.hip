@@ -609,7 +609,7 @@ extern "C" {
 
 // Same contract as psdf_mlp_backward (include/psdf.h) for the nets this kernel covers: dims = {K0 <= 52, 64, 64, 64, 1} (what fits 160 KB of LDS),
 // dW / db requested; returns PSDF_ERR_UNSUPPORTED (-2) for everything else (the caller then takes the fp32 kernel).
-// Needs stream-ordered scratch (hipMallocAsync: the 142-KB operand image and one gradient image per workgroup); when that
+// Needs the library's per-stream scratch (psdf::stream_scratch: the 142-KB operand image and one gradient image per workgroup); when that
 // is not available (stream capture, allocation failure) it also returns -2.
 int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
                             const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
@@ -629,17 +629,12 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
   for (int l = 0; l < 4; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return PSDF_ERR_UNSUPPORTED;
   const int64_t ntiles = (N + 15) / 16;
   int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;
   if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
-  char* scratch = nullptr;
   const size_t part_bytes = (size_t)blocks * G_TOTAL * sizeof(float);
-  if (hipMallocAsync((void**)&scratch, img_bytes + part_bytes, st) != hipSuccess || !scratch) {
-    (void)hipGetLastError();
-    return PSDF_ERR_UNSUPPORTED;
-  }
+  char* scratch = (char*)psdf::stream_scratch(img_bytes + part_bytes, st);   // NULL while capturing
+  if (!scratch) return PSDF_ERR_UNSUPPORTED;
   uint16_t* rec = reinterpret_cast<uint16_t*>(scratch);
   float* partial = reinterpret_cast<float*>(scratch + img_bytes);
   const int pack_threads = (5 * NT + nt0) * 2 * 64 + TAIL_FLOATS;
@@ -650,10 +645,7 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
   do {                                                                                                                      \
     auto kern = mlp_bwd_split_kernel<NT0_, DBL_>;                                                                            \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);       \
-    if (e != hipSuccess) {                                                                                                  \
-      (void)hipFreeAsync(scratch, st);                                                                                      \
-      return (int)e;                                                                                                        \
-    }                                                                                                                       \
+    if (e != hipSuccess) return (int)e;                                                                                     \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,                  \
                        reinterpret_cast<const u32x4*>(rec), dX, partial);                                                   \
   } while (0)
@@ -671,7 +663,6 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
 #undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256, 16), dim3(256), 0, st, partial, (int)blocks, K0, dW[0],
                      dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
-  (void)hipFreeAsync(scratch, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

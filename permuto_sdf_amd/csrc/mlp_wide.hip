@@ -383,19 +383,14 @@ int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float
   for (int l = 0; l < 4; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return PSDF_ERR_UNSUPPORTED;
   using GI = GImg<TI0, T1, T2, T3>;
   const int pads[5] = {TI0 * 16, T1 * 16, T2 * 16, T3 * 16, 16};
   size_t wfloats = 0;
   for (int l = 0; l < 4; l++) wfloats += 2 * (size_t)pads[l] * pads[l + 1];
   const int64_t ntiles = (N + TS - 1) / TS;
   int64_t blocks = ntiles < 256 ? ntiles : 256;
-  char* scratch = nullptr;
-  if (hipMallocAsync((void**)&scratch, (wfloats + (size_t)blocks * GI::TOTAL) * sizeof(float), st) != hipSuccess || !scratch) {
-    (void)hipGetLastError();
-    return PSDF_ERR_UNSUPPORTED;
-  }
+  char* scratch = (char*)psdf::stream_scratch((wfloats + (size_t)blocks * GI::TOTAL) * sizeof(float), st);  // NULL while capturing
+  if (!scratch) return PSDF_ERR_UNSUPPORTED;
   WideArgs a;
   float* wp = reinterpret_cast<float*>(scratch);
   for (int l = 0; l < 4; l++) {
@@ -414,14 +409,10 @@ int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float
   const size_t lds_bytes = (size_t)((TI0 + 2 * T1 + 2 * T2 + 2 * T3 + 1) * 16) * RS * sizeof(float);
   auto kern = mlp_wide_bwd_kernel<TI0, T1, T2, T3>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) {
-    (void)hipFreeAsync(scratch, st);
-    return (int)e;
-  }
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, dY, dX, partial);
   hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3>), dim3((GI::TOTAL + 255) / 256, 8), dim3(256), 0, st, partial,
                      (int)blocks, a, dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
-  (void)hipFreeAsync(scratch, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

@@ -123,4 +123,10 @@ __device__ __forceinline__ float wave_incl_scan_mul(float v) {
   return v;
 }
 
+// Per-stream scratch owned by the library (defined in mlp_bwd.hip): grows on demand, is never handed back, and is safe
+// to re-use from call to call because the calls of one stream execute in order.  A stream-ordered allocation per call
+// (hipMallocAsync) cost ~0.2 ms of HOST time each, which the host-bound training step could not hide.
+// Returns NULL while the stream is being captured (a later growth would move the buffer under the graph) or when the
+// allocation fails: callers then take their allocation-free path.
+void* stream_scratch(size_t bytes, hipStream_t st);
 }  // namespace psdf

@@ -116,6 +116,51 @@ __device__ __forceinline__ v3 safe_inverse(v3 d) {
 constexpr int MAX_DDA_STEPS = 4096;
 constexpr float DDA_EPS = 1e-6f;
 
+// Occupancy as the DDA loops see it: the reference's one byte per voxel (Morton order) plus an OPTIONAL coarse mask, one
+// bit per 8x8x8 block (512 consecutive Morton indices) = "some voxel of the block is occupied" (occupancy_coarse_kernel).
+// The mask of a 256^3 grid is 4 KiB: every workgroup copies it into LDS, and a probe of a voxel whose block is empty is
+// answered there.  Why: the loops are chains of dependent, uncoalesced 1-byte probes -- latency bound for the few
+// hundred rays of a training step (~0.7 us per step of the march), texture-addresser bound for the 2 M rays of a
+// render; rays spend most of their steps in empty space.  The answer is the same bit for bit (the arithmetic of the march
+// is untouched), it only arrives from LDS.
+struct Occ {
+  const uint8_t* bytes;
+  const uint32_t* coarse;  // NULL: none
+  int words;               // 32-bit words of the mask
+};
+constexpr int COARSE_SHIFT = 9;
+// workgroup-collective; call before any thread returns
+__device__ __forceinline__ const uint32_t* stage_coarse(const Occ& o, uint32_t* lds) {
+  if (!o.coarse) return nullptr;
+  for (int i = threadIdx.x; i < o.words; i += blockDim.x) lds[i] = o.coarse[i];
+  __syncthreads();
+  return lds;
+}
+__device__ __forceinline__ bool probe(const Occ& o, const uint32_t* cm, int vox) {
+  if (cm) {
+    const uint32_t c = (uint32_t)vox >> COARSE_SHIFT;
+    if (!((cm[c >> 5] >> (c & 31u)) & 1u)) return false;
+  }
+  return o.bytes[vox] != 0;
+}
+// one wave per mask word: 32 blocks x 512 bytes, read 1 KiB (two blocks) at a time
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    occupancy_coarse_kernel(int words, const uint8_t* __restrict__ occ, uint32_t* __restrict__ coarse) {
+  const int w = blockIdx.x * (PSDF_BLOCK / 64) + (threadIdx.x >> 6);
+  if (w >= words) return;
+  const int lane = threadIdx.x & 63;
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(occ + ((size_t)w << (COARSE_SHIFT + 5)));
+  uint32_t bits = 0u;
+#pragma unroll 4
+  for (int it = 0; it < 16; it++) {
+    const uint4 v = src[it * 64 + lane];
+    const unsigned long long any = __ballot((v.x | v.y | v.z | v.w) != 0u);
+    if ((uint32_t)any) bits |= 1u << (2 * it);
+    if ((uint32_t)(any >> 32)) bits |= 1u << (2 * it + 1);
+  }
+  if (lane == 0) coarse[w] = bits;
+}
+
 // ---------------------------------------------------------------------------------- grid points
 __global__ void __launch_bounds__(PSDF_BLOCK)
     grid_points_kernel(int count, Grid g, const int* __restrict__ indices, Pcg rng, int randomize,
@@ -190,10 +235,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // volume render after the network itself.)
 template <bool USE_GRID>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    march_kernel(int nr_rays, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ origins,
+    march_kernel(int nr_rays, Grid g, Occ o, const float* __restrict__ origins,
                  const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
                  float min_dist, int max_per_ray, Pcg rng, int jitter, int* __restrict__ counts,
                  float* __restrict__ spacings, float* __restrict__ ztemp) {
+  extern __shared__ uint32_t cm_lds[];
+  const uint32_t* cm = stage_coarse(o, cm_lds);
   const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (ray >= nr_rays) return;
   const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
@@ -201,20 +248,50 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   const float t_start = t_entry[ray], t_exit = t_exit_p[ray];
   float occupied = 0.f;
   if (USE_GRID) {
+    // The walk of this first march does not depend on what it finds (only `occupied` does), so it runs AHEAD steps ahead of
+    // its probes: AHEAD probes in flight instead of one (a training step marches a few hundred rays: nothing else hides
+    // the latency).  Same float sequence, same order of the additions into `occupied`.
+    constexpr int AHEAD = 4;
     float t = t_start;
     int steps = 0;
-    while (t < t_exit && steps < MAX_DDA_STEPS) {
-      const v3 pos = along(org, t, dir);
-      const int vox = g.pos_to_idx(pos);
-      if (!g.in_range(vox)) break;
-      const float d = dist_to_next_voxel(pos, dir, idir, g);
-      t += d;
-      t += DDA_EPS;
-      if (occ[vox]) {
-        occupied += d;
-        if ((t - DDA_EPS) > t_exit) occupied -= (t - DDA_EPS) - t_exit;
+    bool walking = true;
+    while (walking) {
+      int vox[AHEAD] = {0, 0, 0, 0};
+      float dd[AHEAD], tt[AHEAD];
+      int m = 0;
+#pragma unroll
+      for (int k = 0; k < AHEAD; k++) {
+        if (walking) {
+          if (!(t < t_exit && steps < MAX_DDA_STEPS)) {
+            walking = false;
+          } else {
+            const v3 pos = along(org, t, dir);
+            const int v = g.pos_to_idx(pos);
+            if (!g.in_range(v)) {
+              walking = false;
+            } else {
+              const float d = dist_to_next_voxel(pos, dir, idir, g);
+              t += d;
+              t += DDA_EPS;
+              vox[k] = v;
+              dd[k] = d;
+              tt[k] = t;
+              m = k + 1;
+              steps++;
+            }
+          }
+        }
       }
-      steps++;
+      // unconditional reads (slots past m re-read voxel 0): a guarded read is a branch, and branches serialise the probes
+      uint8_t byte[AHEAD];
+#pragma unroll
+      for (int k = 0; k < AHEAD; k++) byte[k] = o.bytes[k < m ? vox[k] : 0];
+#pragma unroll
+      for (int k = 0; k < AHEAD; k++)
+        if (k < m && byte[k]) {
+          occupied += dd[k];
+          if ((tt[k] - DDA_EPS) > t_exit) occupied -= (tt[k] - DDA_EPS) - t_exit;
+        }
     }
   } else {
     occupied = t_exit - t_start;
@@ -239,7 +316,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       if (USE_GRID) {
         const int vox = g.pos_to_idx(pos);
         if (!g.in_range(vox)) break;
-        occupied_here = occ[vox];
+        occupied_here = probe(o, cm, vox);
       }
       if (occupied_here && created < to_create) {
         zrow[created] = t;
@@ -305,11 +382,13 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // first sample at the entry of the first occupied voxel (sphere-tracing start), OccupancyGridGPU.cuh:707-814
 template <bool WRITE>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    first_hit_kernel(int nr_rays, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ origins,
+    first_hit_kernel(int nr_rays, Grid g, Occ o, const float* __restrict__ origins,
                      const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
                      int max_nr_samples, const int* __restrict__ offsets, int* __restrict__ counts,
                      float* __restrict__ s_pos, float* __restrict__ s_dirs, float* __restrict__ s_z,
                      float* __restrict__ s_dt, float* __restrict__ ray_fixed_dt, int* __restrict__ start_end) {
+  extern __shared__ uint32_t cm_lds[];
+  const uint32_t* cm = stage_coarse(o, cm_lds);
   const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (ray >= nr_rays) return;
   const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
@@ -327,7 +406,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const float d = dist_to_next_voxel(pos, dir, idir, g);
     t += d;
     t += DDA_EPS;
-    if (occ[vox]) {  // the stored z is the t AFTER the step, the position the one before it (as in the reference)
+    if (probe(o, cm, vox)) {  // the stored z is the t AFTER the step, the position the one before it (as in the reference)
       hit = true;
       hit_pos = pos;
       hit_t = t;
@@ -360,8 +439,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 
 // march a point along its direction to the next occupied voxel (OccupancyGridGPU.cuh:817-895); in place
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    advance_kernel(int count, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ dirs,
+    advance_kernel(int count, Grid g, Occ o, const float* __restrict__ dirs,
                    float* __restrict__ pts, uint8_t* __restrict__ within) {
+  extern __shared__ uint32_t cm_lds[];
+  const uint32_t* cm = stage_coarse(o, cm_lds);
   const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (i >= count) return;
   const v3 org = ld3(pts + 3 * (int64_t)i), dir = ld3(dirs + 3 * (int64_t)i);
@@ -382,7 +463,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const float d = dist_to_next_voxel(pos, dir, idir, g);
     t += d;
     t += DDA_EPS;
-    if (occ[vox]) {
+    if (probe(o, cm, vox)) {
       st3(pts + 3 * (int64_t)i, pos);
       break;
     }
@@ -397,10 +478,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // trace, so the 15-iteration loop is a fixed sequence of launches that a hipGraph can replay.
 // first hit, dense: the per-ray result of compute_first_sample_start_of_occupied_regions without packing
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    first_hit_dense_kernel(int nr_rays, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ origins,
+    first_hit_dense_kernel(int nr_rays, Grid g, Occ o, const float* __restrict__ origins,
                            const float* __restrict__ dirs, const float* __restrict__ t_entry,
                            const float* __restrict__ t_exit_p, float push, float* __restrict__ pos,
                            uint8_t* __restrict__ converged) {
+  extern __shared__ uint32_t cm_lds[];
+  const uint32_t* cm = stage_coarse(o, cm_lds);
   const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (ray >= nr_rays) return;
   const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
@@ -417,7 +500,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const float d = dist_to_next_voxel(pos_, dir, idir, g);
     t += d;
     t += DDA_EPS;
-    if (occ[vox]) {
+    if (probe(o, cm, vox)) {
       hit = true;
       hp = pos_;
       break;
@@ -434,9 +517,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // sdf*multiplier, mark converged when |sdf| < threshold, march to the next occupied voxel, mark converged when the
 // march leaves the grid.
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    sphere_trace_step_kernel(int count, Grid g, const uint8_t* __restrict__ occ, const float* __restrict__ dirs,
+    sphere_trace_step_kernel(int count, Grid g, Occ o, const float* __restrict__ dirs,
                              const float* __restrict__ sdf, float multiplier, float thresh, float* __restrict__ pts,
                              uint8_t* __restrict__ converged) {
+  extern __shared__ uint32_t cm_lds[];
+  const uint32_t* cm = stage_coarse(o, cm_lds);
   const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (i >= count) return;
   if (converged[i]) return;
@@ -462,7 +547,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const float d = dist_to_next_voxel(q, dir, idir, g);
     t += d;
     t += DDA_EPS;
-    if (occ[vox]) {
+    if (probe(o, cm, vox)) {
       out = q;
       break;
     }
@@ -745,6 +830,18 @@ inline Grid mk_grid(int n, float extent, const float* tr) {
   return Grid{n, extent, tr[0], tr[1], tr[2], pow2 ? 1.0f / (float)n : 0.f, extent == 1.0f ? 1 : 0};
 }
 #define GRID1(n) dim3(psdf_blocks((n), PSDF_BLOCK)), dim3(PSDF_BLOCK), 0, st
+#define GRID1C(n, oc) dim3(psdf_blocks((n), PSDF_BLOCK)), dim3(PSDF_BLOCK), (oc).coarse ? (size_t)(oc).words * 4 : 0, st
+// words of the coarse mask of an n^3 grid (0: grid too small or too large for the LDS copy -> no mask)
+inline int coarse_words(int n) {
+  const long long v = (long long)n * n * n;
+  if (v % (1ll << (COARSE_SHIFT + 5)) != 0) return 0;
+  const long long w = v >> (COARSE_SHIFT + 5);
+  return (w >= 1 && w <= 16384) ? (int)w : 0;   // <= 64 KiB of LDS (n = 512: 32 KiB)
+}
+inline Occ mk_occ(int n, const uint8_t* bytes, const uint32_t* coarse) {
+  const int w = coarse ? coarse_words(n) : 0;
+  return Occ{bytes, w ? coarse : nullptr, w};
+}
 inline unsigned wave_ray_grid(int nr_rays) {
   unsigned b = psdf_blocks(nr_rays, PSDF_BLOCK / 64);
   return b < 16384u ? (b ? b : 1u) : 16384u;
@@ -801,6 +898,19 @@ int psdf_grid_check_occupancy(int count, int nr_voxels_per_dim, float extent, co
   return PSDF_OK;
 }
 
+// Coarse mask of the occupancy (see struct Occ): psdf_occupancy_coarse_words(n) 32-bit words (0: not available for this
+// grid size, pass NULL to the marches).  Rebuild it whenever the occupancy bytes may have changed.
+int psdf_occupancy_coarse_words(int nr_voxels_per_dim) { return coarse_words(nr_voxels_per_dim); }
+int psdf_occupancy_coarse_mask(int nr_voxels_per_dim, const uint8_t* grid_occupancy, uint32_t* coarse_mask, void* stream) {
+  const int words = coarse_words(nr_voxels_per_dim);
+  if (words == 0 || !grid_occupancy || !coarse_mask) return PSDF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(occupancy_coarse_kernel, dim3((words + 3) / 4), dim3(PSDF_BLOCK), 0, st, words, grid_occupancy,
+                     coarse_mask);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
 // use_grid=1: OccupancyGrid::compute_samples_in_occupied_regions; use_grid=0: RaySampler::compute_samples_fg.
 // scratch: nr_rays * (3 + max_nr_samples_per_ray) 4-byte words.  cur_nr_samples (device int) receives the exact total.
 int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
@@ -808,10 +918,12 @@ int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float e
                        const float* ray_t_entry, const float* ray_t_exit, float min_dist_between_samples,
                        int max_nr_samples_per_ray, int max_nr_samples, uint64_t rng_state, uint64_t rng_inc, int jitter,
                        float* samples_pos, float* samples_dirs, float* samples_z, float* samples_dt, float* ray_fixed_dt,
-                       int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream) {
+                       int* ray_start_end_idx, int* cur_nr_samples, int* scratch, const uint32_t* coarse_mask,
+                       void* stream) {
   if (nr_rays <= 0) return PSDF_OK;
   if (max_nr_samples_per_ray < 0 || !scratch) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, use_grid ? coarse_mask : nullptr);
   Grid g = use_grid ? mk_grid(nr_voxels_per_dim, extent, grid_translation) : Grid{1, 1.f, 0.f, 0.f, 0.f, 1.f, 1};
   Pcg rng{rng_state, rng_inc};
   int* counts = scratch;
@@ -819,7 +931,7 @@ int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float e
   float* spacings = reinterpret_cast<float*>(scratch + 2 * (int64_t)nr_rays);
   float* ztemp = reinterpret_cast<float*>(scratch + 3 * (int64_t)nr_rays);
 #define MARCH(G_)                                                                                                     \
-  hipLaunchKernelGGL((march_kernel<G_>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs, ray_t_entry, \
+  hipLaunchKernelGGL((march_kernel<G_>), GRID1C(nr_rays, oc), nr_rays, g, oc, ray_origins, ray_dirs, ray_t_entry, \
                      ray_t_exit, min_dist_between_samples, max_nr_samples_per_ray, rng, jitter, counts, spacings, ztemp)
   if (use_grid)
     MARCH(true);
@@ -838,17 +950,19 @@ int psdf_first_hit_samples(int nr_rays, int nr_voxels_per_dim, float extent, con
                            const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs,
                            const float* ray_t_entry, const float* ray_t_exit, int max_nr_samples, float* samples_pos,
                            float* samples_dirs, float* samples_z, float* samples_dt, float* ray_fixed_dt,
-                           int* ray_start_end_idx, int* cur_nr_samples, int* scratch, void* stream) {
+                           int* ray_start_end_idx, int* cur_nr_samples, int* scratch, const uint32_t* coarse_mask,
+                           void* stream) {
   if (nr_rays <= 0) return PSDF_OK;
   hipStream_t st = (hipStream_t)stream;
   Grid g = mk_grid(nr_voxels_per_dim, extent, grid_translation);
+  const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
   int* counts = scratch;
   int* offsets = scratch + nr_rays;
-  hipLaunchKernelGGL((first_hit_kernel<false>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs,
+  hipLaunchKernelGGL((first_hit_kernel<false>), GRID1C(nr_rays, oc), nr_rays, g, oc, ray_origins, ray_dirs,
                      ray_t_entry, ray_t_exit, max_nr_samples, offsets, counts, samples_pos, samples_dirs, samples_z,
                      samples_dt, ray_fixed_dt, ray_start_end_idx);
   hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, counts, offsets, cur_nr_samples);
-  hipLaunchKernelGGL((first_hit_kernel<true>), GRID1(nr_rays), nr_rays, g, grid_occupancy, ray_origins, ray_dirs,
+  hipLaunchKernelGGL((first_hit_kernel<true>), GRID1C(nr_rays, oc), nr_rays, g, oc, ray_origins, ray_dirs,
                      ray_t_entry, ray_t_exit, max_nr_samples, offsets, counts, samples_pos, samples_dirs, samples_z,
                      samples_dt, ray_fixed_dt, ray_start_end_idx);
   PSDF_LAUNCH_CHECK();
@@ -858,11 +972,12 @@ int psdf_first_hit_samples(int nr_rays, int nr_voxels_per_dim, float extent, con
 // samples_pos is updated IN PLACE (the reference aliases input and output, src/OccupancyGrid.cu:311)
 int psdf_advance_to_next_occupied_voxel(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
                                         const uint8_t* grid_occupancy, const float* samples_dirs, float* samples_pos,
-                                        uint8_t* is_within_bounds, void* stream) {
+                                        uint8_t* is_within_bounds, const uint32_t* coarse_mask, void* stream) {
   if (count <= 0) return PSDF_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(advance_kernel, GRID1(count), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
-                     grid_occupancy, samples_dirs, samples_pos, is_within_bounds);
+  const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
+  hipLaunchKernelGGL(advance_kernel, GRID1C(count, oc), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     oc, samples_dirs, samples_pos, is_within_bounds);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -871,12 +986,14 @@ int psdf_advance_to_next_occupied_voxel(int count, int nr_voxels_per_dim, float 
 // voxel pushed half a voxel inside, converged[ray] = 1 for rays that meet no occupied voxel.
 int psdf_first_hit_dense(int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
                          const uint8_t* grid_occupancy, const float* ray_origins, const float* ray_dirs,
-                         const float* ray_t_entry, const float* ray_t_exit, float* pos, uint8_t* converged, void* stream) {
+                         const float* ray_t_entry, const float* ray_t_exit, float* pos, uint8_t* converged,
+                         const uint32_t* coarse_mask, void* stream) {
   if (nr_rays <= 0) return PSDF_OK;
   hipStream_t st = (hipStream_t)stream;
   const float voxel = (float)(1.0 / nr_voxels_per_dim);
-  hipLaunchKernelGGL(first_hit_dense_kernel, GRID1(nr_rays), nr_rays, mk_grid(nr_voxels_per_dim, extent, grid_translation),
-                     grid_occupancy, ray_origins, ray_dirs, ray_t_entry, ray_t_exit, voxel, pos, converged);
+  const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
+  hipLaunchKernelGGL(first_hit_dense_kernel, GRID1C(nr_rays, oc), nr_rays, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     oc, ray_origins, ray_dirs, ray_t_entry, ray_t_exit, voxel, pos, converged);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -884,11 +1001,13 @@ int psdf_first_hit_dense(int nr_rays, int nr_voxels_per_dim, float extent, const
 // One iteration of the fixed-shape sphere tracer; sdf[count] is the SDF at pts before the step.
 int psdf_sphere_trace_step(int count, int nr_voxels_per_dim, float extent, const float* grid_translation,
                            const uint8_t* grid_occupancy, const float* dirs, const float* sdf, float sdf_multiplier,
-                           float sdf_converged_thresh, float* pts, uint8_t* converged, void* stream) {
+                           float sdf_converged_thresh, float* pts, uint8_t* converged, const uint32_t* coarse_mask,
+                           void* stream) {
   if (count <= 0) return PSDF_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(sphere_trace_step_kernel, GRID1(count), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
-                     grid_occupancy, dirs, sdf, sdf_multiplier, sdf_converged_thresh, pts, converged);
+  const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
+  hipLaunchKernelGGL(sphere_trace_step_kernel, GRID1C(count, oc), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
+                     oc, dirs, sdf, sdf_multiplier, sdf_converged_thresh, pts, converged);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

@@ -337,3 +337,66 @@ def test_against_committed_golden_vectors(dev):
     Tr, bg2 = VR.cumprod_alpha2transmittance(c, om)
     assert np.abs(Tr.cpu().numpy() - gold["T"]).max() < 2e-6
     assert np.abs(VR.integrate_with_weights(c, T(rgb, dev), alpha.clamp(0, 1) * Tr).cpu().numpy() - gold["integ"]).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------- coarse occupancy mask
+def test_coarse_mask_words_and_marches_unchanged(world, dev):
+    """The coarse mask (one bit per 8x8x8 Morton block, csrc/sampling.hip struct Occ) is what it says, and the four DDA
+    entry points return the SAME bits with and without it (they are compared with the oracle, mask on, elsewhere in
+    this file)."""
+    from permuto_sdf import OccupancyGrid
+    from permuto_sdf_amd import _lib as L
+    g = world["grid"]
+    n = world["n"]
+    words = L.lib().psdf_occupancy_coarse_words(n)
+    assert words == n ** 3 // (512 * 32)
+    assert L.lib().psdf_occupancy_coarse_words(16) == 0          # too small for a word of blocks: no mask
+    assert g._coarse(100) is None                                   # small batches march without it
+    mask = g._coarse(1 << 20).cpu().numpy().view(np.uint32)
+    blocks = world["occ"].reshape(-1, 512).any(axis=1).reshape(-1, 32)
+    ref = (blocks.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(mask, ref)
+    assert 0 < blocks.mean() < 0.6                                 # the shell leaves most blocks empty
+
+    o, d, te, tx = (T(world[k], dev) for k in ("o", "d", "te", "tx"))
+
+    def run():
+        out = []
+        for jitter in (False, True):
+            OccupancyGrid._rng.__init__()
+            rs = g.compute_samples_in_occupied_regions(o, d, te, tx, 1e-3, 64, jitter)
+            m = int(rs.cur_nr_samples)      # the pool beyond the samples is uninitialised memory
+            out += [rs.samples_z[:m].clone(), rs.samples_pos[:m].clone(), rs.samples_dt[:m].clone(), rs.ray_start_end_idx.clone()]
+        rs = g.compute_first_sample_start_of_occupied_regions(o, d, te, tx)
+        m = int(rs.cur_nr_samples)
+        out += [rs.samples_pos[:m].clone(), rs.samples_z[:m].clone(), rs.ray_start_end_idx.clone()]
+        p = (o + d * te).contiguous()
+        p2, within = g.advance_sample_to_next_occupied_voxel(d, p)
+        out += [p2.clone(), within.clone()]
+        return out
+
+    keep = OccupancyGrid.COARSE_MIN_RAYS
+    try:
+        OccupancyGrid.COARSE_MIN_RAYS = 0                           # the 2000 rays of this world march with the mask ...
+        a = run()
+        OccupancyGrid.use_coarse_mask = False                       # ... and without
+        b = run()
+    finally:
+        OccupancyGrid.use_coarse_mask = True
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)
+
+    # the mask follows the occupancy: a grid edited in place is re-read on the next call
+    occ = g.get_grid_occupancy()
+    saved = occ.clone()
+    try:
+        occ.zero_()
+        rs = g.compute_samples_in_occupied_regions(o, d, te, tx, 1e-3, 64, False)
+        assert int(rs.cur_nr_samples) == 0
+        occ.copy_(saved)
+        rs = g.compute_samples_in_occupied_regions(o, d, te, tx, 1e-3, 64, False)
+        assert torch.equal(rs.samples_z[:int(rs.cur_nr_samples)], a[0])
+    finally:
+        occ.copy_(saved)
+        OccupancyGrid.COARSE_MIN_RAYS = keep
