@@ -325,13 +325,29 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   const int64_t ntiles = (N + 15) / 16;
   const int stage_floats = rows4 * 16 + 64;
   float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED) + wave * (DOUBLE ? 2 : 1) * stage_floats;
-  // The inputs of the NEXT tile are requested with global_load_lds while this one is computed: instruction i brings rows
-  // 4 i + g (clamped to the last real row) of the 16 samples of the tile to buf[(4 i + g) * 16 + c], the last one dY.
+  // The inputs of the NEXT tile are requested with global_load_lds while this one is computed.  16-byte form (N % 4 == 0):
+  // one instruction brings 16 rows x 16 samples (lane = row 16 j + (lane >> 2), samples 4 (lane & 3) .. + 3) to
+  // buf[row * 16 + sample]; the rows past the last multiple of 16 and dY come with the 4-byte form (lane = row 4 i + g,
+  // sample c).  For K0 = 36 that is 2 + 1 + 1 instructions instead of 10 (each LDS-DMA instruction costs the wave ~100
+  // cycles of issue).  Rows are clamped to the last real row, samples to the end of the batch.
+  const bool wide_dma = (N & 3) == 0 && N >= 4;
   auto prefetch = [&](int64_t t, float* buf) {
     const int c = lane_k & 15, g = lane_k >> 4;
     int64_t nn = t * 16 + c;
     nn = nn < N ? nn : N - 1;
-    for (int i = 0; i < (rows4 >> 2); i++) {
+    int i0 = 0;
+    if (wide_dma) {
+      int64_t n4 = t * 16 + 4 * (lane_k & 3);
+      n4 = n4 + 3 < N ? n4 : N - 4;
+      const int n16 = rows4 >> 4;
+      for (int j = 0; j < n16; j++) {
+        const int k = 16 * j + (lane_k >> 2);   // < rows4; rows4 - K0 < 4 of them are padding
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)(k < K0 ? k : K0 - 1) * N + n4),
+                                         (__attribute__((address_space(3))) void*)(buf + j * 256), 16, 0, 0);
+      }
+      i0 = n16 * 4;
+    }
+    for (int i = i0; i < (rows4 >> 2); i++) {
       int k = 4 * i + g;
       k = k < K0 ? k : K0 - 1;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)k * N + nn),
