@@ -101,6 +101,26 @@ int psdf_l1_loss(int64_t R, int C, const float* pred, const float* gt, const uns
     float* loss, float* grad_pred, void* stream);
 /* replaces: eikonal_loss, permuto_sdf_utils.py:49-51: loss[0] += scale * sum (|g| - 1)^2, grad (optional) [N,3] */
 int psdf_eikonal_loss(int64_t N, const float* gradients, float scale, float* loss, float* grad_gradients, void* stream);
+/* replaces: F.normalize(x, dim=-1) and its autograd backward (torch), used on the SDF gradients at
+   permuto_sdf_py/models/models.py:272,280,367: grad_y == NULL -> out = x / max(|x|, 1e-12); else out = d/dx applied to grad_y */
+int psdf_normalize3(int64_t N, const float* x, const float* grad_y, float* out, void* stream);
+/* replaces: the shifted points of the curvature loss, models.py:266-277: out = points + epsilon * cross(normalize(gradients),
+   normalize(rand_directions)) (grad_shifted == NULL), or the gradient of that w.r.t. `gradients` applied to grad_shifted */
+int psdf_curvature_shift(int64_t N, const float* points, const float* gradients, const float* rand_directions, float
+    epsilon, const float* grad_shifted, float* out, void* stream);
+/* replaces: models.py:280-289 + the mean at train_permuto_sdf.py:363: loss[0] += scale * sum acos(clamp(n(g) . n(g_shifted),
+   -1+1e-6, 1-1e-6)) / pi; the two gradient outputs are optional (both or none) */
+int psdf_curvature_loss(int64_t N, const float* gradients, const float* gradients_shifted, float scale, float* loss,
+    float* grad_gradients, float* grad_gradients_shifted, void* stream);
+/* replaces: the off-surface loss, train_permuto_sdf.py:372-375: loss[0] += scale * sum exp(-sharpness |sdf|) */
+int psdf_offsurface_loss(int64_t N, const float* sdf, float sharpness, float scale, float* loss, float* grad_sdf, void*
+    stream);
+/* replaces: NerfHash density activation + VolumeRenderingNerf alpha, models.py:520 (softplus) and
+   volume_rendering_modules.py:72-86: alpha = 1 - exp(-softplus(raw) dt), one_minus_alpha = 1 - alpha + 1e-7 */
+int psdf_nerf_alpha_forward(int64_t N, const float* raw_density, const float* dt, float* alpha, float* one_minus_alpha,
+    void* stream);
+int psdf_nerf_alpha_backward(int64_t N, const float* raw_density, const float* dt, const float* grad_alpha, const float*
+    grad_one_minus_alpha, float* grad_raw_density, void* stream);
 
 /* ---- mlp.hip ---- */
 /* replaces: torch.nn.Sequential(Linear,GELU,...) evaluators, permuto_sdf_py/models/models.py:153-161,451-470 */

@@ -138,14 +138,32 @@ __device__ __forceinline__ void apply_gelu(f32x16 (&acc)[T]) {
     }
 }
 
+// gelu from ONE exponential and ONE reciprocal (tools/gelu_fit_rational.py): Phi(-|z|) = t P6(t) exp(-z^2/2) with
+// t = 1 / (1 + 0.39 |z|), gelu(z) = max(z, 0) - |z| Phi(-|z|).  14 instructions against ~26 for the erf form; error
+// against float64 1.8e-7 |z| (torch's fp32 formula 0.5 z (1 + erf(z / sqrt 2)) itself: 1.1e-7 |z|) -- both are rounding
+// noise of an fp32 evaluation, and the GPU tests hold the kernels to a multiple of torch's own fp32 error.
+__device__ __forceinline__ float gelu_rational(float z) {
+  const float E = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(z), 0.39f, 1.0f));
+  float q = 5.384693295e-02f;
+  q = fmaf(q, t, -2.582434118e-01f);
+  q = fmaf(q, t, 3.751679361e-01f);
+  q = fmaf(q, t, -1.663514599e-02f);
+  q = fmaf(q, t, 1.944366544e-01f);
+  q = fmaf(q, t, 1.514270604e-01f);
+  const float tail = q * t * E;
+  return fmaf(-fabsf(z), tail, fmaxf(z, 0.f));
+}
+
 // One element per instruction: the form to use beside bf16 MFMAs (packed fp32 arithmetic does not hide in the shadow of
-// the matrix pipe, plain VALU does: tools/mfma_valu_overlap.hip).  Same operations as the packed form, same bits.
+// the matrix pipe, plain VALU does: tools/mfma_valu_overlap.hip).  The split-bf16 forward is VALU bound (gelu + operand
+// splitting against 156 MFMAs per tile), so it takes the cheaper evaluator: 0.799 -> 0.759 ms for the forward of the bench.
 template <int T>
 __device__ __forceinline__ void apply_gelu_scalar(f32x16 (&acc)[T]) {
 #pragma unroll
   for (int to = 0; to < T; to++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[to][r] = gelu_exact(acc[to][r]);
+    for (int r = 0; r < 16; r++) acc[to][r] = gelu_rational(acc[to][r]);
 }
 
 // out^T = W * in^T for register-resident activations (chained layout, see header).

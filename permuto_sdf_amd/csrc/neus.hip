@@ -119,6 +119,125 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   if (lane_id() == 0 && loss) atomicAdd(loss, acc * scale);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// More elementwise chains of the training step, one launch per direction each (the torch forms are 5-25 launches forward
+// and about twice that backward; the step is host bound, csrc/../train_step.py):
+//   normalize3      F.normalize(x, dim=-1) (eps 1e-12)                                       models.py:272,367 ...
+//   curvature shift points + eps * cross(normalize(g), normalize(rand))                      models.py:266-277
+//   curvature loss  scale * sum acos(clamp(n(g) . n(g2), -1+1e-6, 1-1e-6)) / pi              models.py:282-289, train_permuto_sdf.py:363
+//   offsurface loss scale * sum exp(-100 |sdf|)                                              train_permuto_sdf.py:372-375
+//   nerf alpha      alpha = 1 - exp(-softplus(raw) dt), one_minus = 1 - alpha + 1e-7        models.py:520, volume_rendering_modules.py:72-86
+// All fp32, expressions in the order torch evaluates them.
+struct Nrm {
+  v3 y;
+  float norm, denom;
+};
+__device__ __forceinline__ Nrm normalize_eps(v3 x) {
+  Nrm r;
+  r.norm = sqrtf(dot3(x, x));
+  r.denom = fmaxf(r.norm, 1e-12f);
+  r.y = v3{x.x / r.denom, x.y / r.denom, x.z / r.denom};
+  return r;
+}
+// gradient of y = x / max(|x|, eps) for an upstream gy
+__device__ __forceinline__ v3 normalize_bwd(const Nrm& n, v3 gy) {
+  const float inv = 1.0f / n.denom;
+  v3 g = inv * gy;
+  if (n.norm > 1e-12f) {   // the clamp passes the gradient of the norm only above eps
+    const float s = dot3(gy, n.y) * inv;
+    g = g - s * n.y;
+  }
+  return g;
+}
+__device__ __forceinline__ v3 cross3(v3 a, v3 b) {
+  return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    normalize3_kernel(int64_t N, const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ out) {
+  // gy == NULL: out = normalize(x); else out = d normalize / dx applied to gy
+  for (int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * PSDF_BLOCK) {
+    const Nrm r = normalize_eps(ld3(x + 3 * n));
+    st3(out + 3 * n, gy ? normalize_bwd(r, ld3(gy + 3 * n)) : r.y);
+  }
+}
+
+// forward (g_shifted == NULL): out = points + eps * cross(normalize(g), normalize(rnd));  backward: out = d / d g applied
+// to g_shifted (points and rnd carry no gradient)
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    curvature_shift_kernel(int64_t N, const float* __restrict__ points, const float* __restrict__ g,
+                           const float* __restrict__ rnd, float eps, const float* __restrict__ g_shifted,
+                           float* __restrict__ out) {
+  for (int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * PSDF_BLOCK) {
+    const Nrm a = normalize_eps(ld3(g + 3 * n));
+    const v3 r = normalize_eps(ld3(rnd + 3 * n)).y;
+    if (!g_shifted) {
+      const v3 t = cross3(a.y, r);
+      st3(out + 3 * n, ld3(points + 3 * n) + eps * t);
+    } else {
+      const v3 gt = eps * ld3(g_shifted + 3 * n);
+      st3(out + 3 * n, normalize_bwd(a, cross3(r, gt)));   // d (a x r) . gt / d a = r x gt
+    }
+  }
+}
+
+// loss += scale * sum acos(clamp(n(a) . n(b))) / pi;  ga, gb (optional) = its gradients
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    curvature_loss_kernel(int64_t N, const float* __restrict__ a, const float* __restrict__ b, float scale,
+                          float* __restrict__ loss, float* __restrict__ ga, float* __restrict__ gb) {
+  float acc = 0.f;
+  const float lo = -1.0f + 1e-6f, hi = 1.0f - 1e-6f, inv_pi = (float)(1.0 / 3.14159265358979323846);
+  for (int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * PSDF_BLOCK) {
+    const Nrm na = normalize_eps(ld3(a + 3 * n)), nb = normalize_eps(ld3(b + 3 * n));
+    const float dot = dot3(na.y, nb.y);
+    const float u = fminf(fmaxf(dot, lo), hi);
+    acc += acosf(u) * inv_pi;
+    if (ga) {
+      const float gu = (dot >= lo && dot <= hi) ? -(scale * inv_pi) / sqrtf((1.0f - u) * (1.0f + u)) : 0.0f;
+      st3(ga + 3 * n, normalize_bwd(na, gu * nb.y));
+      st3(gb + 3 * n, normalize_bwd(nb, gu * na.y));
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane_id() == 0 && loss) atomicAdd(loss, acc * scale);
+}
+
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    offsurface_loss_kernel(int64_t N, const float* __restrict__ sdf, float sharp, float scale, float* __restrict__ loss,
+                           float* __restrict__ g_sdf) {
+  float acc = 0.f;
+  for (int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * PSDF_BLOCK) {
+    const float s = sdf[n];
+    const float e = expf(-sharp * fabsf(s));
+    acc += e;
+    if (g_sdf) g_sdf[n] = scale * e * (s > 0.f ? -sharp : (s < 0.f ? sharp : 0.f));
+  }
+  acc = wave_sum(acc);
+  if (lane_id() == 0 && loss) atomicAdd(loss, acc * scale);
+}
+
+__device__ __forceinline__ float softplus20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// forward (g_alpha == NULL): alpha, one_minus;  backward: g_raw = d / d raw of (alpha . g_alpha + one_minus . g_one_minus)
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    nerf_alpha_kernel(int64_t N, const float* __restrict__ raw, const float* __restrict__ dt, float* __restrict__ alpha,
+                      float* __restrict__ one_minus, const float* __restrict__ g_alpha,
+                      const float* __restrict__ g_one_minus, float* __restrict__ g_raw) {
+  for (int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * PSDF_BLOCK) {
+    const float x = raw[n], d = dt[n];
+    const float dens = softplus20(x);
+    const float e = expf(-dens * d);
+    if (!g_raw) {
+      const float a = 1.0f - e;
+      alpha[n] = a;
+      one_minus[n] = (1.0f - a) + 1e-7f;
+    } else {
+      const float ga = (g_alpha ? g_alpha[n] : 0.f) - (g_one_minus ? g_one_minus[n] : 0.f);   // one_minus = 1 - alpha + 1e-7
+      const float g_dens = ga * e * d;                                                         // alpha = 1 - exp(-dens dt)
+      g_raw[n] = g_dens * (x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)));                       // softplus' = sigmoid
+    }
+  }
+}
+
 inline unsigned stream_grid(int64_t n) {
   const unsigned b = psdf_blocks(n, PSDF_BLOCK);
   return b < 4096u ? (b ? b : 1u) : 4096u;     // >= 16 workgroups per CU on 256 CUs, grid-stride beyond
@@ -165,6 +284,64 @@ int psdf_eikonal_loss(int64_t N, const float* gradients, float scale, float* los
   if (N < 0 || !gradients) return PSDF_ERR_ARG;
   hipLaunchKernelGGL(eikonal_loss_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, gradients,
                      scale, loss, grad_gradients);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_normalize3(int64_t N, const float* x, const float* grad_y, float* out, void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !x || !out) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(normalize3_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, x, grad_y, out);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_curvature_shift(int64_t N, const float* points, const float* gradients, const float* rand_directions, float epsilon,
+                         const float* grad_shifted, float* out, void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !gradients || !rand_directions || !out || (!grad_shifted && !points)) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(curvature_shift_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, points,
+                     gradients, rand_directions, epsilon, grad_shifted, out);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_curvature_loss(int64_t N, const float* gradients, const float* gradients_shifted, float scale, float* loss,
+                        float* grad_gradients, float* grad_gradients_shifted, void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !gradients || !gradients_shifted || (!grad_gradients) != (!grad_gradients_shifted)) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(curvature_loss_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, gradients,
+                     gradients_shifted, scale, loss, grad_gradients, grad_gradients_shifted);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_offsurface_loss(int64_t N, const float* sdf, float sharpness, float scale, float* loss, float* grad_sdf,
+                         void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !sdf) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(offsurface_loss_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, sdf,
+                     sharpness, scale, loss, grad_sdf);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_nerf_alpha_forward(int64_t N, const float* raw_density, const float* dt, float* alpha, float* one_minus_alpha,
+                            void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !raw_density || !dt || !alpha || !one_minus_alpha) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(nerf_alpha_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, raw_density, dt,
+                     alpha, one_minus_alpha, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_nerf_alpha_backward(int64_t N, const float* raw_density, const float* dt, const float* grad_alpha,
+                             const float* grad_one_minus_alpha, float* grad_raw_density, void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !raw_density || !dt || !grad_raw_density) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(nerf_alpha_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, raw_density, dt,
+                     (float*)nullptr, (float*)nullptr, grad_alpha, grad_one_minus_alpha, grad_raw_density);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

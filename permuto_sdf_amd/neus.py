@@ -113,3 +113,134 @@ class _EikonalLoss(torch.autograd.Function):
 def l1_loss(pred, gt, mask=None):
     """((gt - pred).abs() * mask).mean() -- rgb_loss of permuto_sdf_py/utils/permuto_sdf_utils.py:43-47"""
     return _L1Loss.apply(pred, gt, mask)
+
+
+def eikonal_loss(gradients):
+    """((gradients.norm(dim=-1) - 1) ** 2).mean() -- eikonal_loss of permuto_sdf_py/utils/permuto_sdf_utils.py:49-51 (first-order
+    autograd: one launch forward, one multiply backward)"""
+    return _EikonalLoss.apply(gradients)
+
+
+# ---- more fused elementwise chains of the training step (csrc/neus.hip, second block); all first-order autograd
+def _c3(t):
+    return _c(t).view(-1, 3)
+
+
+class _Normalize3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c3(x)
+        y = torch.empty_like(x)
+        L.call("psdf_normalize3", L.c_l(x.shape[0]), L.ptr(x), None, L.ptr(y), L.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        L.call("psdf_normalize3", L.c_l(x.shape[0]), L.ptr(x), L.ptr(_c3(gy)), L.ptr(gx), L.stream())
+        return gx
+
+
+def normalize3(x):
+    """F.normalize(x, dim=-1) for [N,3] (models.py:272,280,367)"""
+    return _Normalize3.apply(x)
+
+
+class _CurvatureShift(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, gradients, rand_directions, eps):
+        p, g, r = _c3(points), _c3(gradients), _c3(rand_directions)
+        out = torch.empty_like(p)
+        L.call("psdf_curvature_shift", L.c_l(p.shape[0]), L.ptr(p), L.ptr(g), L.ptr(r), L.c_f(eps), None, L.ptr(out), L.stream())
+        ctx.save_for_backward(g, r)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, gs):
+        g, r = ctx.saved_tensors
+        gg = torch.empty_like(g)
+        L.call("psdf_curvature_shift", L.c_l(g.shape[0]), None, L.ptr(g), L.ptr(r), L.c_f(ctx.eps), L.ptr(_c3(gs)), L.ptr(gg),
+               L.stream())
+        return None, gg, None, None
+
+
+def curvature_shift(points, gradients, rand_directions, eps=1e-4):
+    """points + eps * cross(normalize(gradients), normalize(rand_directions)) -- models.py:266-277; the gradient flows to
+    `gradients` only (as in the reference, where points and the random directions are constants)"""
+    return _CurvatureShift.apply(points, gradients, rand_directions, eps)
+
+
+class _CurvatureLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c3(a), _c3(b)
+        N = a.shape[0]
+        loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+        ga, gb = torch.empty_like(a), torch.empty_like(b)
+        L.call("psdf_curvature_loss", L.c_l(N), L.ptr(a), L.ptr(b), L.c_f(1.0 / max(1, N)), L.ptr(loss), L.ptr(ga), L.ptr(gb),
+               L.stream())
+        ctx.save_for_backward(ga, gb)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        ga, gb = ctx.saved_tensors
+        return ga * go, gb * go
+
+
+def curvature_loss(gradients, gradients_shifted):
+    """mean of acos(clamp(n(g) . n(g_shifted), -1+1e-6, 1-1e-6)) / pi -- models.py:280-289 and the .mean() of
+    train_permuto_sdf.py:363"""
+    return _CurvatureLoss.apply(gradients, gradients_shifted)
+
+
+class _OffsurfaceLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf, sharpness):
+        s = _c(sdf).reshape(-1)
+        N = s.shape[0]
+        loss = torch.zeros(1, dtype=torch.float32, device=s.device)
+        g = torch.empty_like(s)
+        L.call("psdf_offsurface_loss", L.c_l(N), L.ptr(s), L.c_f(sharpness), L.c_f(1.0 / max(1, N)), L.ptr(loss), L.ptr(g),
+               L.stream())
+        ctx.save_for_backward(g)
+        ctx.shape = sdf.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        return (g * go).view(ctx.shape), None
+
+
+def offsurface_loss(sdf, sharpness=1e2):
+    """torch.exp(-sharpness * sdf.abs()).mean() -- train_permuto_sdf.py:372-375"""
+    return _OffsurfaceLoss.apply(sdf, float(sharpness))
+
+
+class _NerfAlpha(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw_density, dt):
+        x, d = _c(raw_density).reshape(-1), _c(dt).reshape(-1)
+        alpha, om = torch.empty_like(x), torch.empty_like(x)
+        L.call("psdf_nerf_alpha_forward", L.c_l(x.shape[0]), L.ptr(x), L.ptr(d), L.ptr(alpha), L.ptr(om), L.stream())
+        ctx.save_for_backward(x, d)
+        ctx.shape = raw_density.shape
+        return alpha.view(ctx.shape), om.view(ctx.shape)
+
+    @staticmethod
+    def backward(ctx, ga, gom):
+        x, d = ctx.saved_tensors
+        g = torch.empty_like(x)
+        L.call("psdf_nerf_alpha_backward", L.c_l(x.shape[0]), L.ptr(x), L.ptr(d), L.ptr(None if ga is None else _c(ga).reshape(-1)),
+               L.ptr(None if gom is None else _c(gom).reshape(-1)), L.ptr(g), L.stream())
+        return g.view(ctx.shape), None
+
+
+def nerf_alpha(raw_density, dt):
+    """alpha = 1 - exp(-softplus(raw_density) * dt) and 1 - alpha + 1e-7 (shaped like raw_density) -- NerfHash's density activation
+    (models.py:520) followed by VolumeRenderingNerf.compute_weights' first lines (volume_rendering_modules.py:72-86)"""
+    return _NerfAlpha.apply(raw_density, dt)

@@ -35,7 +35,8 @@ from .bridge import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRenderi
 from .encoding import Coarse2Fine, PermutoEncoding
 from .fused import encode_mlp_forward_raw
 from .mlp import FusedMLP, LipshitzMLP, input_gradient_only, pack_params
-from .neus import l1_loss, neus_alpha
+from .neus import (curvature_loss, curvature_shift, eikonal_loss, l1_loss, nerf_alpha, neus_alpha, normalize3,
+                   offsurface_loss)
 from .optim import FusedAdamW
 
 
@@ -153,19 +154,20 @@ class SdfNet(torch.nn.Module):
 
     def sdf_and_gradient(self, points, it):  # models.py:236-251
         with torch.enable_grad():
-            points = points.detach().requires_grad_(True)
+            if not points.requires_grad:   # the shifted points of the curvature term arrive WITH their graph (models.py:277)
+                points = points.detach().requires_grad_(True)
             sdf, feat = self.forward(points, it)
             # autograd would compute the lattice and the MLP parameter gradients here and drop them
             with self.encoding.positions_gradient_only(), input_gradient_only():
                 (grad,) = torch.autograd.grad(sdf, points, torch.ones_like(sdf), create_graph=True, retain_graph=True)
         return sdf, grad, feat
 
-    def curvature(self, points, sdf_gradients, it):  # models.py:261-296
-        normals = F.normalize(sdf_gradients, dim=-1)
-        tangent = torch.cross(normals, F.normalize(torch.randn_like(points), dim=-1), dim=-1)
-        _, g2, _ = self.sdf_and_gradient(points.detach() + tangent * 1e-4, it)
-        dot = (normals * F.normalize(g2, dim=-1)).sum(-1, keepdim=True)
-        return torch.acos(torch.clamp(dot, -1.0 + 1e-6, 1.0 - 1e-6)) / math.pi
+    def curvature(self, points, sdf_gradients, it):  # models.py:257-291, and the .mean() of train_permuto_sdf.py:363
+        """mean angle (over pi) between the normal and the normal at a point shifted 1e-4 along a random tangent; the
+        shifted point keeps its dependence on the normal, as in the reference (no detach at models.py:272-277)"""
+        shifted = curvature_shift(points, sdf_gradients, torch.randn_like(points), 1e-4)
+        _, g2, _ = self.sdf_and_gradient(shifted, it)
+        return curvature_loss(sdf_gradients, g2)
 
 
 class RgbNet(torch.nn.Module):
@@ -183,7 +185,7 @@ class RgbNet(torch.nn.Module):
         win = torch.ones(24, device=points.device)  # rgb_nr_iters_for_c2f = 1: window is 1 from the first step
         with torch.no_grad():
             sh = PermutoSDF.spherical_harmonics(dirs, 5)
-        x = torch.cat([self.encoding(points, win), sh, F.normalize(sdf_gradients.view(-1, 3), dim=1), geom_feat], 1)
+        x = torch.cat([self.encoding(points, win), sh, normalize3(sdf_gradients), geom_feat], 1)
         return torch.sigmoid(self.mlp(x))
 
     def neus_weights(self, rs, sdf, gradients, cos_anneal_ratio, forced_variance):  # volume_rendering_modules.py:129-174
@@ -216,12 +218,12 @@ class BgNet(torch.nn.Module):
             sh = PermutoSDF.spherical_harmonics(dirs, 4)
         fd = self.mlp_feat_and_density(self.encoding(pos4d, win))
         rgb = self.mlp_rgb(torch.cat([F.gelu(fd[:, 1:65]), sh], 1))
-        return torch.sigmoid(rgb), F.softplus(fd[:, 0:1])
+        return torch.sigmoid(rgb), fd[:, 0:1]     # colour, RAW density: softplus (models.py:520) is fused into nerf_weights
 
     @staticmethod
-    def nerf_weights(rs, density):  # volume_rendering_modules.py:72-86
-        alpha = 1.0 - torch.exp(-density * rs.samples_dt)
-        T, bg = _Cumprod.apply(rs, 1 - alpha + 1e-7)
+    def nerf_weights(rs, raw_density):  # models.py:520 + volume_rendering_modules.py:72-86
+        alpha, one_minus = nerf_alpha(raw_density, rs.samples_dt)
+        T, bg = _Cumprod.apply(rs, one_minus)
         return (alpha * T).view(-1, 1)
 
 
@@ -336,13 +338,13 @@ class Trainer:
         loss = l1_loss(pred, gt, hit)                                                          # rgb_loss, one launch
         n_fg = fg.samples_pos.shape[0]
         if n_fg:
-            loss = loss + ((torch.linalg.norm(sdf_grad, ord=2, dim=-1) - 1.0) ** 2).mean() * hp.eikonal_weight
+            loss = loss + eikonal_loss(sdf_grad) * hp.eikonal_weight
             gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
             if gw > 0.0:
-                loss = loss + self.sdf.curvature(fg.samples_pos, sdf_grad, it).mean() * hp.curvature_weight * gw
+                loss = loss + self.sdf.curvature(fg.samples_pos, sdf_grad, it) * (hp.curvature_weight * gw)
         off = self.sphere.rand_points_inside(1024)
         sdf_off, _ = self.sdf(off, it)
-        loss = loss + torch.exp(-1e2 * sdf_off.abs()).mean() * hp.offsurface_weight
+        loss = loss + offsurface_loss(sdf_off, 1e2) * hp.offsurface_weight
         if it >= hp.iter_start_reduce_curv:
             loss = loss + self.rgb.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
         # ---- backward, all-reduce, optimiser

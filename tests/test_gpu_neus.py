@@ -96,3 +96,97 @@ def test_hot_path_true_gradient_matches_oracle_autograd(dev):
     L1 radiance loss w.r.t. lattice and every MLP parameter against torch autograd through the oracles"""
     import __graft_entry__ as ge
     assert ge.smoke()
+
+
+# ---- second block of csrc/neus.hip: the remaining elementwise chains of the training step, against the torch expressions the
+# reference writes (float64 on the CPU, autograd for the gradients)
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_normalize3_and_curvature_terms_match_torch(dev):
+    import math
+    import torch.nn.functional as F
+    from permuto_sdf_amd.neus import curvature_loss, curvature_shift, normalize3
+    g = torch.Generator().manual_seed(5)
+    N = 5001
+    x = torch.randn(N, 3, generator=g) * torch.rand(N, 1, generator=g) * 3
+    x[7] = 0.0                                   # |x| below eps: the clamp of F.normalize is active
+    g2 = x + 0.3 * torch.randn(N, 3, generator=g)
+    g2[11] = x[11]                               # dot = 1: clamped, zero gradient
+    g2[12] = -x[12]                              # dot = -1
+    pts = torch.rand(N, 3, generator=g) - 0.5
+    rnd = torch.randn(N, 3, generator=g)
+    up = torch.randn(N, 3, generator=g)
+
+    # reference expressions (models.py:266-289), float64
+    xd, g2d = x.double().requires_grad_(True), g2.double().requires_grad_(True)
+    n_ref = F.normalize(xd, dim=-1)
+    (gx_ref,) = torch.autograd.grad(n_ref, xd, up.double(), retain_graph=True)
+    shifted_ref = pts.double() + torch.cross(n_ref, F.normalize(rnd.double(), dim=-1), dim=-1) * 1e-4
+    (gs_ref,) = torch.autograd.grad(shifted_ref, xd, up.double(), retain_graph=True)
+    dot = (n_ref * F.normalize(g2d, dim=-1)).sum(-1, keepdim=True)
+    curv_ref = (torch.acos(torch.clamp(dot, -1.0 + 1e-6, 1.0 - 1e-6)) / math.pi).mean()
+    ga_ref, gb_ref = torch.autograd.grad(curv_ref, [xd, g2d])
+
+    xg, g2g = x.to(dev).requires_grad_(True), g2.to(dev).requires_grad_(True)
+    n = normalize3(xg)
+    assert _rel(n, n_ref) < 1e-6
+    (gx,) = torch.autograd.grad(n, xg, up.to(dev))
+    ok = torch.ones(N, dtype=torch.bool); ok[7] = False        # the zero vector: gradient 1/eps = 1e12 either way
+    assert _rel(gx.cpu()[ok], gx_ref[ok]) < 1e-5
+    sh = curvature_shift(pts.to(dev), xg, rnd.to(dev), 1e-4)
+    assert float((sh.cpu().double() - shifted_ref.detach()).abs().max()) < 1e-7
+    (gs,) = torch.autograd.grad(sh, xg, up.to(dev))
+    assert _rel(gs.cpu()[ok], gs_ref[ok]) < 1e-5
+    curv = curvature_loss(xg, g2g)
+    # acos is ill-conditioned near +-1 (the clamped rows): compare the mean with an absolute tolerance
+    assert abs(float(curv) - float(curv_ref)) < 2e-6
+    ga, gb = torch.autograd.grad(curv, [xg, g2g])
+    keep = ok.clone(); keep[11] = keep[12] = False
+    d = dot.detach().view(-1).abs()
+    keep &= d < 0.999                            # fp32 cancellation in 1 - u^2 next to the clamp; the rest to 1e-4
+    assert _rel(ga.cpu()[keep], ga_ref[keep]) < 1e-4 and _rel(gb.cpu()[keep], gb_ref[keep]) < 1e-4
+    assert float(ga[11].abs().max()) == 0.0 and float(gb[12].abs().max()) == 0.0   # clamped: no gradient
+
+
+def test_offsurface_and_nerf_alpha_match_torch(dev):
+    import torch.nn.functional as F
+    from permuto_sdf_amd.neus import eikonal_loss, nerf_alpha, offsurface_loss
+    g = torch.Generator().manual_seed(6)
+    N = 4097
+    s = torch.randn(N, 1, generator=g) * 0.02
+    s[3] = 0.0
+    sd = s.double().requires_grad_(True)
+    ref = torch.exp(-1e2 * sd.abs()).mean()                      # train_permuto_sdf.py:372-375
+    (gref,) = torch.autograd.grad(ref, sd)
+    sg = s.to(dev).requires_grad_(True)
+    out = offsurface_loss(sg, 1e2)
+    assert abs(float(out) - float(ref)) < 1e-6
+    (gg,) = torch.autograd.grad(out, sg)
+    assert gg.shape == sg.shape and _rel(gg, gref) < 1e-5
+
+    raw = torch.randn(N, 1, generator=g) * 6
+    raw[5] = 25.0                                                # beyond softplus' linear threshold
+    dt = torch.rand(N, 1, generator=g) * 0.05
+    dt[9] = 1e10                                                 # the last background sample (RaySamplerGPU.cuh:150)
+    rd = raw.double().requires_grad_(True)
+    a_ref = 1.0 - torch.exp(-F.softplus(rd) * dt.double())       # models.py:520, volume_rendering_modules.py:72-86
+    om_ref = 1 - a_ref + 1e-7
+    ua, uo = torch.randn(N, 1, generator=g).double(), torch.randn(N, 1, generator=g).double()
+    (gr_ref,) = torch.autograd.grad((a_ref * ua).sum() + (om_ref * uo).sum(), rd)
+    rg = raw.to(dev).requires_grad_(True)
+    a, om = nerf_alpha(rg, dt.to(dev))
+    assert a.shape == (N, 1) and _rel(a, a_ref) < 1e-6 and _rel(om, om_ref) < 1e-6
+    (gr,) = torch.autograd.grad((a * ua.float().to(dev)).sum() + (om * uo.float().to(dev)).sum(), rg)
+    assert gr.shape == rg.shape and _rel(gr, gr_ref) < 1e-5
+
+    gr3 = torch.randn(N, 3, generator=g)
+    g3 = gr3.double().requires_grad_(True)
+    e_ref = ((g3.norm(dim=-1) - 1.0) ** 2).mean()                # permuto_sdf_utils.py:49-51
+    (ge_ref,) = torch.autograd.grad(e_ref, g3)
+    gd = gr3.to(dev).requires_grad_(True)
+    e = eikonal_loss(gd)
+    (ge,) = torch.autograd.grad(e * 0.04, gd)
+    assert abs(float(e) - float(e_ref)) < 1e-5 and _rel(ge, ge_ref * 0.04) < 1e-5
