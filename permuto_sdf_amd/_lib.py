@@ -73,3 +73,30 @@ def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise PsdfError("permuto_sdf_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)
+
+
+# ---- small device constants without a launch each -------------------------------------------------------------------
+_zero_scalars = {}
+_scalar_pools = {}
+
+
+def zero_scalar(device):
+    """A 0-dim fp32 zero on `device` (placeholder outputs of autograd Functions).  One fill per device and process; every
+    caller gets its own tensor object (detach() is a host-side view), never write into it."""
+    key = str(device)
+    z = _zero_scalars.get(key)
+    if z is None:
+        z = _zero_scalars[key] = torch.zeros((), dtype=torch.float32, device=device)
+    return z.detach()
+
+
+def zeroed_scalar(device):
+    """A fresh [1] fp32 accumulator that is already zero (loss values and other wave-sum + atomic targets): slices of a
+    pooled buffer, one fill per 1024 of them instead of one fill each."""
+    key = str(device)
+    pool = _scalar_pools.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _scalar_pools[key] = [torch.zeros(1024, dtype=torch.float32, device=device), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]

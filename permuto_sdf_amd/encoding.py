@@ -160,10 +160,10 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.save_for_backward(scale_factor, shifts, lattice, positions, window, g)
         if g_lat is None:
-            g_lat = torch.zeros((), device=positions.device)
+            g_lat = L.zero_scalar(positions.device)
             ctx.mark_non_differentiable(g_lat)
         if g_pos is None:
-            g_pos = torch.zeros((), device=positions.device)
+            g_pos = L.zero_scalar(positions.device)
             ctx.mark_non_differentiable(g_pos)
         return g_lat, g_pos
 
@@ -281,9 +281,14 @@ class Coarse2Fine(torch.nn.Module):
 
     def forward(self, t):
         self.last_t = float(t)
-        alpha = float(t) * self.nr_levels
-        x = torch.clamp(alpha - self.level_idx, 0.0, 1.0)
-        return 0.5 * (1.0 + torch.cos(math.pi * x + math.pi))
+        # a training step asks for the window of the same t half a dozen times: five elementwise launches once, not each time
+        key = (self.last_t, self.level_idx.device)
+        if getattr(self, "_cached_key", None) != key:
+            alpha = float(t) * self.nr_levels
+            x = torch.clamp(alpha - self.level_idx, 0.0, 1.0)
+            self._cached = 0.5 * (1.0 + torch.cos(math.pi * x + math.pi))
+            self._cached_key = key
+        return self._cached
 
     def get_last_t(self):
         return self.last_t

@@ -242,7 +242,7 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         ctx.set_materialize_grads(False)      # unused outputs (dW, db are never differentiated) arrive as None in backward
         ctx.save_for_backward(x_fm, gy_fm, *weights, *biases)
         if dx is None:
-            dx_out = torch.zeros((), device=x.device)
+            dx_out = L.zero_scalar(x.device)
             ctx.mark_non_differentiable(dx_out)
         else:
             dx_out = dx.t()

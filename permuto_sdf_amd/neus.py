@@ -23,7 +23,7 @@ def neus_alpha_backward_raw(g_alpha, sdf, dirs, gradients, dt, inv_s, cos_anneal
     N = sdf.shape[0]
     g_sdf = torch.empty((N, 1), dtype=torch.float32, device=sdf.device)
     g_grad = torch.empty((N, 3), dtype=torch.float32, device=sdf.device) if need_grad else None
-    g_inv_s = torch.zeros(1, dtype=torch.float32, device=sdf.device) if need_inv_s else None
+    g_inv_s = L.zeroed_scalar(sdf.device) if need_inv_s else None
     L.call("psdf_neus_alpha_backward", L.c_l(N), L.ptr(g_alpha), L.ptr(sdf), L.ptr(dirs), L.ptr(gradients), L.ptr(dt),
            L.ptr(inv_s), L.c_f(float(cos_anneal_ratio)), L.ptr(g_sdf), L.ptr(g_grad), L.ptr(g_inv_s), L.stream())
     return g_sdf, g_grad, g_inv_s
@@ -64,7 +64,7 @@ def l1_loss_raw(pred, gt, mask=None, scale=None, want_grad=True):
     L.require_cuda(pred, gt)
     R, C = pred.shape
     scale = 1.0 / max(1, R * C) if scale is None else float(scale)
-    loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    loss = L.zeroed_scalar(pred.device)
     g = torch.empty_like(pred) if want_grad else None
     m = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
     L.call("psdf_l1_loss", L.c_l(R), L.c_i(C), L.ptr(pred.contiguous()), L.ptr(gt.contiguous()), L.ptr(m), L.c_f(scale),
@@ -75,7 +75,7 @@ def l1_loss_raw(pred, gt, mask=None, scale=None, want_grad=True):
 def eikonal_loss_raw(gradients, scale=None, want_grad=True):
     N = gradients.shape[0]
     scale = 1.0 / max(1, N) if scale is None else float(scale)
-    loss = torch.zeros(1, dtype=torch.float32, device=gradients.device)
+    loss = L.zeroed_scalar(gradients.device)
     g = torch.empty_like(gradients) if want_grad else None
     L.call("psdf_eikonal_loss", L.c_l(N), L.ptr(gradients.contiguous()), L.c_f(scale), L.ptr(loss), L.ptr(g), L.stream())
     return loss, g
@@ -178,7 +178,7 @@ class _CurvatureLoss(torch.autograd.Function):
     def forward(ctx, a, b):
         a, b = _c3(a), _c3(b)
         N = a.shape[0]
-        loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+        loss = L.zeroed_scalar(a.device)
         ga, gb = torch.empty_like(a), torch.empty_like(b)
         L.call("psdf_curvature_loss", L.c_l(N), L.ptr(a), L.ptr(b), L.c_f(1.0 / max(1, N)), L.ptr(loss), L.ptr(ga), L.ptr(gb),
                L.stream())
@@ -202,7 +202,7 @@ class _OffsurfaceLoss(torch.autograd.Function):
     def forward(ctx, sdf, sharpness):
         s = _c(sdf).reshape(-1)
         N = s.shape[0]
-        loss = torch.zeros(1, dtype=torch.float32, device=s.device)
+        loss = L.zeroed_scalar(s.device)
         g = torch.empty_like(s)
         L.call("psdf_offsurface_loss", L.c_l(N), L.ptr(s), L.c_f(sharpness), L.c_f(1.0 / max(1, N)), L.ptr(loss), L.ptr(g),
                L.stream())

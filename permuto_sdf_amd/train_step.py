@@ -180,9 +180,10 @@ class RgbNet(torch.nn.Module):
         self.mlp = LipshitzMLP(self.encoding.output_dims() + 25 + 3 + hp.sdf_geom_feat_size, [128, 128, 64, 3], True)
         self.variance = torch.nn.Parameter(torch.tensor(0.3))  # SingleVarianceNetwork, volume_rendering_modules.py:96-115
         self.last_inv_s = None
+        self.register_buffer("_win", torch.ones(24), persistent=False)  # rgb_nr_iters_for_c2f = 1: window is 1 from the first step
 
     def forward(self, points, dirs, sdf_gradients, geom_feat):
-        win = torch.ones(24, device=points.device)  # rgb_nr_iters_for_c2f = 1: window is 1 from the first step
+        win = self._win
         with torch.no_grad():
             sh = PermutoSDF.spherical_harmonics(dirs, 5)
         x = torch.cat([self.encoding(points, win), sh, normalize3(sdf_gradients), geom_feat], 1)
@@ -211,9 +212,10 @@ class BgNet(torch.nn.Module):
         self.mlp_feat_and_density = FusedMLP([self.encoding.output_dims(), 64, 64, 64, 65], reference_init=True,
                                              last_layer_linear_init=False)
         self.mlp_rgb = FusedMLP([64 + 16, 64, 64, 3], reference_init=True)
+        self.register_buffer("_win", torch.ones(24), persistent=False)
 
     def forward(self, pos4d, dirs):
-        win = torch.ones(24, device=pos4d.device)
+        win = self._win
         with torch.no_grad():
             sh = PermutoSDF.spherical_harmonics(dirs, 4)
         fd = self.mlp_feat_and_density(self.encoding(pos4d, win))

@@ -1,5 +1,5 @@
-"""Which Python line issues which GPU kernels in a cfg-4 training step?  torch.profiler with stacks over 5 steps; kernels are
-attributed to the innermost frame inside this repository.  Prints (launches/step, GPU us/step, kernel, source line)."""
+"""Which torch ops launch kernels in a cfg-4 training step, and on what shapes?  torch.profiler over 5 steps (Python stacks
+are not recorded by this build, the shapes identify the call sites).  python tools/trace_train_launches.py"""
 import collections
 import os
 import sys
@@ -18,27 +18,20 @@ for _ in range(12):
     tr.step(reel)
 torch.cuda.synchronize()
 STEPS = 5
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
-             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for _ in range(STEPS):
         tr.step(reel)
     torch.cuda.synchronize()
 
 agg = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.key_averages(group_by_stack_n=12):
+for ev in prof.key_averages(group_by_input_shape=True):
     dt = getattr(ev, "self_device_time_total", 0.0)
-    if dt <= 0:
+    if dt <= 0 or not ev.key.startswith("aten::"):
         continue
-    where = "?"
-    for fr in ev.stack or []:
-        if ROOT in fr and "tools/" not in fr:
-            where = fr.replace(ROOT + "/", "")
-            break
-    k = (ev.key[:40], where[:110])
+    k = (ev.key[:28], str(ev.input_shapes)[:120])
     agg[k][0] += ev.count
     agg[k][1] += dt
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-tot = sum(v[1] for v in agg.values())
-print("device time of torch ops %.1f us/step (ctypes launches are not torch ops and do not appear)" % (tot / STEPS))
-for (name, where), (n, t) in rows[:90]:
-    print("%5.1f/step %8.1f us/step  %-40s %s" % (n / STEPS, t / STEPS, name, where))
+rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+print("torch ops that launch kernels, by input shapes (launches/step, GPU us/step)")
+for (name, shapes), (n, t) in rows[:110]:
+    print("%5.1f/step %8.1f us/step  %-28s %s" % (n / STEPS, t / STEPS, name, shapes))
