@@ -53,24 +53,46 @@ def mlp_forward_raw(dims, x_fm, packed, skip=None, out=None):
     return y
 
 
-def _zero_grads(dims, dev):
-    """dW_l [d_{l+1}, d_l] and db_l [d_{l+1}] as views of ONE zero-filled buffer (one fill launch instead of 2 per layer;
-    every slice starts on a 16-byte boundary)"""
+def _grad_views(dims, flat=None, dev=None):
+    """dW_l [d_{l+1}, d_l] and db_l [d_{l+1}] as views of ONE buffer (every slice starts on a 16-byte boundary); allocates
+    it zero-filled when `flat` is None"""
     n_layers = len(dims) - 1
     sizes = [dims[l + 1] * dims[l] for l in range(n_layers)] + [dims[l + 1] for l in range(n_layers)]
     offs, tot = [], 0
     for sz in sizes:
         offs.append(tot)
         tot += (sz + 3) & ~3
-    flat = torch.zeros(tot, dtype=torch.float32, device=dev)
+    if flat is None:
+        flat = torch.zeros(tot, dtype=torch.float32, device=dev)
     dWs = [flat[offs[l]:offs[l] + sizes[l]].view(dims[l + 1], dims[l]) for l in range(n_layers)]
     dbs = [flat[offs[n_layers + l]:offs[n_layers + l] + sizes[n_layers + l]] for l in range(n_layers)]
+    return flat, dWs, dbs
+
+
+def _zero_grads(dims, dev):
+    """one fill launch instead of 2 per layer"""
+    _, dWs, dbs = _grad_views(dims, dev=dev)
     return dWs, dbs
 
 
-def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True, need_dw=True):
+class GradBuffer:
+    """Persistent parameter-gradient buffer of a FusedMLP (FusedMLP.enable_grad_buffer): every PLAIN backward of a step --
+    the backward of each evaluation and of each analytic input gradient (double backward) -- accumulates into the same
+    dW / db views (the kernels accumulate anyway), instead of returning fresh tensors that autograd then sums with one add
+    per parameter and contribution.  The owner zeroes it after the optimiser step (`zero()`, one fill).  A backward under
+    create_graph never touches it (its parameter gradients are dropped by the caller, see input_gradient_only)."""
+
+    def __init__(self, dims, device):
+        self.flat, self.dWs, self.dbs = _grad_views(dims, dev=device)
+
+    def zero(self):
+        self.flat.zero_()
+
+
+def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True, need_dw=True, into=None):
     """weights/biases: the torch-layout parameters (the backward kernel builds its own LDS image from them)
-    -> (dx_fm [dims[0], N] or None, [dW_l], [db_l]); need_dw=False: data gradient only (lighter kernel, empty lists)"""
+    -> (dx_fm [dims[0], N] or None, [dW_l], [db_l]); need_dw=False: data gradient only (lighter kernel, empty lists);
+    into = (dWs, dbs): accumulate into these instead of fresh zero-filled tensors"""
     N = x_fm.shape[1]
     n_layers = len(dims) - 1
     dev = x_fm.device
@@ -80,7 +102,7 @@ def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True, need_dw=T
     Wp = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
     Bp = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
     if need_dw:
-        dWs, dbs = _zero_grads(dims, dev)
+        dWs, dbs = into if into is not None else _zero_grads(dims, dev)
         W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
         B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
     else:
@@ -208,6 +230,10 @@ class _FusedMLPFunc(torch.autograd.Function):
         if _InputGradOnly.active:      # the caller only wants d/dx from this pass
             outs = _FusedMLPBackFunc.apply(ctx.module, (ctx.needs_input_grad[1], False), x, gy, *params)
             return (None, outs[0] if ctx.needs_input_grad[1] else None, *([None] * len(params)))
+        gb = getattr(ctx.module, "grad_buffer", None)
+        if gb is not None and not torch.is_grad_enabled():   # plain backward: parameter gradients go to the module's buffer
+            outs = _FusedMLPBackFunc.apply(ctx.module, (ctx.needs_input_grad[1], True, True), x, gy, *params)
+            return (None, outs[0] if ctx.needs_input_grad[1] else None, *([None] * len(params)))
         outs = _FusedMLPBackFunc.apply(ctx.module, ctx.needs_input_grad[1], x, gy, *params)
         dx = outs[0] if ctx.needs_input_grad[1] else None
         return (None, dx, *outs[1:])
@@ -219,9 +245,9 @@ class _FusedMLPBackFunc(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, need_dx, x, gy, *params):
-        need_dw = True
+        need_dw, buffered = True, False
         if isinstance(need_dx, tuple):
-            need_dx, need_dw = need_dx
+            need_dx, need_dw, buffered = (tuple(need_dx) + (False,))[:3]
         n_layers = module.n_layers
         weights, biases = params[:n_layers], params[n_layers:]
         x_fm = x.t()
@@ -233,11 +259,18 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         if not need_dw and dx_only_supported(module.dims):
             dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=need_dx, need_dw=False)
         elif backward_supported(module.dims):
-            dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=need_dx)
-            if not need_dw:
+            gb = module.grad_buffer if buffered else None
+            dx, dWs, dbs = mlp_backward_raw(module.dims, x_fm, weights, biases, gy_fm, need_dx=need_dx,
+                                            into=(gb.dWs, gb.dbs) if gb is not None else None)
+            if not need_dw or buffered:
                 dWs, dbs = [], []
         else:
             dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, need_dx)
+            if buffered:
+                gb = module.grad_buffer
+                for dst, src in zip(gb.dWs + gb.dbs, list(dWs) + list(dbs)):
+                    dst.add_(src)
+                dWs, dbs = [], []
         ctx.module, ctx.n_layers = module, n_layers
         ctx.set_materialize_grads(False)      # unused outputs (dW, db are never differentiated) arrive as None in backward
         ctx.save_for_backward(x_fm, gy_fm, *weights, *biases)
@@ -266,6 +299,10 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         v_fm = g_dx.t()
         if not v_fm.is_contiguous():
             v_fm = v_fm.contiguous()
+        gb = getattr(ctx.module, "grad_buffer", None)
+        if gb is not None and not torch.is_grad_enabled():
+            dX, _, _ = mlp_double_backward(ctx.module.dims, x_fm, weights, biases, gy_fm, v_fm, into=(gb.dWs, gb.dbs))
+            return (None, None, dX.t(), None, *([None] * (2 * n_layers)))
         dX, dWs, dbs = mlp_double_backward(ctx.module.dims, x_fm, weights, biases, gy_fm, v_fm)
         return (None, None, dX.t(), None, *dWs, *dbs)
 
@@ -280,17 +317,24 @@ def double_backward_supported(dims):
                    (2, 2, 2, 2, 1, True), (3, 4, 4, 4, 1, True), (4, 4, 4, 4, 1, True)}
 
 
-def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
-    """-> (dX [C,N], [dW_l], [db_l]) of <dx(x, params; gy), v>; fused kernel where one is built, torch (GPU) otherwise"""
+def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None):
+    """-> (dX [C,N], [dW_l], [db_l]) of <dx(x, params; gy), v>; fused kernel where one is built, torch (GPU) otherwise;
+    into = (dWs, dbs): accumulate the parameter gradients there"""
     if not double_backward_supported(dims):
-        return _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm)
+        dX, dWs, dbs = _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm)
+        if into is not None:
+            for dst, src in zip(list(into[0]) + list(into[1]), list(dWs) + list(dbs)):
+                if src is not None:
+                    dst.add_(src)
+            dWs, dbs = into
+        return dX, dWs, dbs
     N = x_fm.shape[1]
     n_layers = len(dims) - 1
     dev = x_fm.device
     ws = [w.detach().contiguous() for w in weights]
     bs = [b.detach().contiguous() for b in biases]
     dx2 = torch.empty((dims[0], N), dtype=torch.float32, device=dev)
-    dWs, dbs = _zero_grads(dims, dev)
+    dWs, dbs = into if into is not None else _zero_grads(dims, dev)
     Wp = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
     Bp = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
     W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
@@ -314,6 +358,19 @@ class FusedMLP(torch.nn.Module):
         if reference_init:
             for i, l in enumerate(self.layers):
                 leaky_relu_init_(l, 1.0 if (i == self.n_layers - 1 and last_layer_linear_init) else 0.0)
+        self.grad_buffer = None
+
+    def enable_grad_buffer(self):
+        """-> GradBuffer: from now on plain backward passes ADD this net's parameter gradients into it (and return None to
+        autograd); the caller hands its views to the optimiser (`assign_grads`) and zeroes it after the step"""
+        self.grad_buffer = GradBuffer(self.dims, self.layers[0].weight.device)
+        return self.grad_buffer
+
+    def assign_grads(self):
+        """point every parameter's .grad at its view of the buffer (no copy)"""
+        gb = self.grad_buffer
+        for l, dW, db in zip(self.layers, gb.dWs, gb.dbs):
+            l.weight.grad, l.bias.grad = dW, db
 
     @classmethod
     def from_sequential(cls, seq):

@@ -269,6 +269,9 @@ class Trainer:
                 tr = m.encoding.enable_touched_rows()
                 self.opt.attach(m.encoding.lattice_values, tr)
                 self.touched.append(tr)
+        # the SDF net is differentiated four times per step (two evaluations, two analytic input gradients): its parameter
+        # gradients accumulate in one persistent buffer instead of four tensors per parameter summed by autograd
+        self.grad_buffers = [self.sdf.mlp_sdf.enable_grad_buffer()] if touched_rows else []
         self.nr_rays = self.hp.nr_rays
         self.iter = 0
         self.last = {}
@@ -353,6 +356,8 @@ class Trainer:
         for p in self.params:
             p.grad = None
         loss.backward()
+        if self.grad_buffers:
+            self.sdf.mlp_sdf.assign_grads()
         buffered = {id(m.encoding.lattice_values) for m in (self.sdf, self.rgb, self.bg)} if self.touched else set()
         dense = [p for p in self.params if id(p) not in buffered]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in dense]
@@ -369,6 +374,8 @@ class Trainer:
                 parallel.all_reduce_max_(tr.touched)
             buckets.finish()
         self.opt.step(grad_scale=1.0 / parallel.world_size())
+        for gb in self.grad_buffers:
+            gb.zero()
         # ---- occupancy refresh, every 8th step, same random voxels on every rank (train_permuto_sdf.py:386-391)
         with torch.no_grad():
             if it % 8 == 0:

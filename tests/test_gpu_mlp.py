@@ -356,3 +356,39 @@ def test_gradient_only_contexts_leave_the_training_gradients_unchanged(dev):
     assert abs(l0 - l1) <= 1e-6 * abs(l0)      # the create_graph pass runs the data-gradient-only kernel: last-bit differences
     for a, b in zip(g0, g1):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-12
+
+
+def test_grad_buffer_accumulates_what_autograd_would_sum(dev):
+    """FusedMLP.enable_grad_buffer: the parameter gradients of a loss that differentiates the net four times (two
+    evaluations + their analytic input gradients, the training step's pattern) land in the buffer and equal the .grad
+    autograd builds without it; a create_graph pass leaves the buffer untouched."""
+    import copy
+    from permuto_sdf_amd.mlp import FusedMLP, input_gradient_only
+    torch.manual_seed(3)
+    net = FusedMLP([52, 32, 32, 32, 33], reference_init=True).to(dev)
+    ref = copy.deepcopy(net)
+    gb = net.enable_grad_buffer()
+    xs = [torch.randn(3000, 52, device=dev), torch.randn(2000, 52, device=dev)]
+
+    def loss_of(m):
+        total = 0.0
+        for x0 in xs:
+            x = x0.clone().requires_grad_(True)
+            y = m(x)
+            with input_gradient_only():
+                (g,) = torch.autograd.grad(y[:, 0:1], x, torch.ones_like(y[:, 0:1]), create_graph=True)
+            total = total + (g ** 2).mean() + (y[:, 1:] ** 2).mean() + y[:, 0].abs().mean()
+        return total
+
+    loss_of(ref).backward()
+    assert float(gb.flat.abs().max()) == 0.0
+    l = loss_of(net)
+    assert float(gb.flat.abs().max()) == 0.0                  # the create_graph passes did not write into it
+    l.backward()
+    assert all(p.grad is None for p in net.parameters())
+    net.assign_grads()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert a.grad.shape == b.grad.shape
+        assert float((a.grad - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()) + 1e-9
+    gb.zero()
+    assert float(net.layers[0].weight.grad.abs().max()) == 0.0   # views of the buffer
