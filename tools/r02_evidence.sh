@@ -18,5 +18,12 @@ python tools/cfg2_matrix.py > $O/cfg2_matrix.jsonl 2> $O/cfg2_matrix.err
 python tools/cfg3_render.py > $O/cfg3.json 2> $O/cfg3.err
 python tools/sphere_trace_bench.py > $O/cfg5.json 2> $O/cfg5.err
 python tools/train_bench.py > $O/cfg4_final.json 2> $O/cfg4_final.err
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_cfg4 -- python $R/tools/train_bench.py > $O/cfg4_under_rocprof.json 2> $O/cfg4_under_rocprof.err
+cd $R
+python tools/rocpd_summary.py $O/prof_cfg4 $O/cfg4_kernel_stats.txt > /dev/null 2>&1
+rm -rf $O/prof_cfg4
+python tools/dda_march_bench.py > $O/dda_march_bench.json 2> $O/dda_march_bench.err
+python tools/trace_train_launches.py > $O/train_launch_sources.txt 2>&1
 rm -rf $R/gpurun_out/pmc_hbm_r02/FETCH_SIZE $R/gpurun_out/pmc_hbm_r02/WRITE_SIZE $R/gpurun_out/pmc_sq_mlpbwdsplit/pass*
 tail -c 600 $O/bench_final.json; echo; head -12 $O/bench_kernel_stats.txt | cut -c1-170; cat $R/gpurun_out/pmc_hbm_r02.json | head -60; cat $R/gpurun_out/pmc_sq_mlpbwdsplit/summary.txt; tail -3 $O/cfg2_matrix.jsonl | cut -c1-300; cat $O/cfg3.json $O/cfg5.json $O/cfg4_final.json | cut -c1-400
