@@ -220,9 +220,9 @@ def main():
                         "avg_launch_ms": ms["mlp_bwd"], "algorithmic_flops_per_launch": mlp_flops,
                         "note": "fp32-equivalent arithmetic priced against the fp32 matrix peak (157.3 TF): every fp32 product "
                                 "is evaluated as six bf16 MFMA products (v_mfma_f32_16x16x32_bf16, three bf16 pieces per operand) "
-                                "because fp32 MFMAs do not overlap with VALU work on gfx950; the forward recomputation, the "
-                                "operand transposes on the matrix pipe and the half-filled k of the dW products are extra, "
-                                "uncounted work; the event bracket also holds the two small pack / reduce launches"},
+                                "because fp32 MFMAs do not overlap with VALU work on gfx950; the forward recomputation and the "
+                                "operand transposes on the matrix pipe are extra, uncounted work (a dW MFMA carries two piece "
+                                "products in its two K halves); the event bracket also holds the two small pack / reduce launches"},
         }
         dom = max(cand, key=lambda k: ms[k])
         roof = cand[dom]
