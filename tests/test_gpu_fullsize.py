@@ -116,3 +116,54 @@ def test_level_split_backward_equals_single_launch(dev):
     for l in range(16):     # per level, not only globally
         s = float(a[l].abs().max())
         assert float((a[l] - b[l]).abs().max()) <= 5e-5 * max(s, 1e-12), l
+
+
+def test_cfg2_fullsize_backward_conservation_and_linearity(dev):
+    """Size-independent properties of the two backward kernels at BASELINE's full batch (2 097 152 samples, 16 levels,
+    36-64-64-64-1), where no oracle finishes in seconds:
+      * encoding: the barycentric weights of a sample sum to 1, so per level and feature the lattice gradient summed
+        over the table rows equals window_l * sum_n g[l, f, n] (a checksum of the whole scatter-add, LDS cache, queues
+        and reduce launch included); and the gradient is linear in the upstream gradient;
+      * MLP (split-bf16 backward): the last bias gradient is sum(dY), dW / db / dX are linear in dY."""
+    from permuto_sdf_amd import FusedMLP, PermutoEncoding
+    from permuto_sdf_amd.encoding import encode_backward_raw
+    from permuto_sdf_amd.mlp import mlp_backward_raw
+    torch.manual_seed(1)
+    N, L_ = 2 * 1024 * 1024, 16
+    enc = PermutoEncoding(3, 2 ** 18, L_, 2, np.geomspace(1.0, 1e-4, L_), concat_points=True, concat_points_scaling=1e-3,
+                          init_scale=1e-2).to(dev)
+    pts = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=1) * torch.rand(N, 1, device=dev) ** (1 / 3) * 0.5
+    win = torch.linspace(0.2, 1.0, L_, device=dev)
+    C = enc.output_dims()
+    assert C == 36
+
+    def lattice_grad(g_fm):
+        g_lat = torch.zeros_like(enc.lattice_values)
+        encode_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(),
+                            win, g_fm, g_lat, None)
+        return g_lat
+
+    u = torch.randn(C, N, device=dev)
+    v = torch.randn(C, N, device=dev)
+    gu, gv = lattice_grad(u), lattice_grad(v)
+    want = (u[:2 * L_].double().view(L_, 2, N).sum(-1) * win.double().view(L_, 1)).cpu()       # [L, F]
+    got = gu.double().sum(dim=1).cpu()                                                           # sum over the T rows
+    scale = float((u[:2 * L_].abs().double().view(L_, 2, N).sum(-1) * win.double().view(L_, 1)).max())
+    assert float((got - want).abs().max()) <= 2e-6 * scale       # fp32 partial sums of up to 2M terms per row
+    guv = lattice_grad(0.5 * u - 2.0 * v)
+    ref = 0.5 * gu - 2.0 * gv
+    for l in range(L_):
+        s = float(ref[l].abs().max())
+        assert float((guv[l] - ref[l]).abs().max()) <= 3e-5 * s, l
+
+    mlp = FusedMLP([C, 64, 64, 64, 1], reference_init=True).to(dev)
+    ws, bs = [l.weight for l in mlp.layers], [l.bias for l in mlp.layers]
+    x = torch.randn(C, N, device=dev) * 0.5
+    dy1, dy2 = torch.randn(1, N, device=dev), torch.randn(1, N, device=dev)
+    dx1, dW1, db1 = mlp_backward_raw(mlp.dims, x, ws, bs, dy1)
+    dx2, dW2, db2 = mlp_backward_raw(mlp.dims, x, ws, bs, dy2)
+    dx3, dW3, db3 = mlp_backward_raw(mlp.dims, x, ws, bs, (dy1 - 3.0 * dy2).contiguous())
+    assert abs(float(db1[-1]) - float(dy1.double().sum())) <= 1e-5 * float(dy1.abs().double().sum())
+    for a, b, c in zip([dx1] + dW1 + db1, [dx2] + dW2 + db2, [dx3] + dW3 + db3):
+        ref = a.double() - 3.0 * b.double()
+        assert float((c.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9
