@@ -23,7 +23,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics
 # per-file extra flags.  mlp_bwd_split.hip: let MFMAs write plain VGPRs, so that only the persistent accumulators live in
 # AGPRs (otherwise every chain / transpose result is copied out with v_accvgpr_read and the kernel spills; the flag crashes
 # this compiler on mlp_bwd.hip, hence per file)
-EXTRA = {"mlp_bwd_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA = {"mlp_bwd_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+         # the BASELINE net's instantiation alone: ILP-first scheduling (the others spill under it, see the file)
+         "mlp_bwd_split_double.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# .hip files that include another .hip file (rebuilt when that one changes)
+INCLUDES = {"mlp_bwd_split_double.hip": ["mlp_bwd_split.hip"]}
 
 
 def _hipcc():
@@ -51,7 +55,8 @@ def build(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(OBJDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        stale = force or _newer(s, o) or any(_newer(h, o) for h in headers) or _newer(__file__, o)
+        deps = headers + [os.path.join(CSRC, d) for d in INCLUDES.get(os.path.basename(s), [])]
+        stale = force or _newer(s, o) or any(_newer(h, o) for h in deps) or _newer(__file__, o)
         if stale:
             jobs.append([hipcc] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-I", CSRC, "-c", s, "-o", o])
 
