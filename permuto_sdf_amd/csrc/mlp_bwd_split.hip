@@ -120,20 +120,22 @@ struct BP {  // the three bf16 pieces of one 8-element operand
 __device__ __forceinline__ uint32_t top_pair(float hi, float lo) {  // {top half of hi, top half of lo}
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
-// eight fp32 -> three bf16x8 pieces by truncation of the running remainder
+// eight fp32 -> three bf16x8 pieces by truncation of the running remainder.  The remainders are formed on PAIRS
+// (v_pk_add_f32: one issue slot for two subtractions -- with one wave per SIMD a packed instruction costs what a plain one does)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 trunc_pair(f32x2 v) {
+  return f32x2{__uint_as_float(__float_as_uint(v.x) & 0xFFFF0000u), __uint_as_float(__float_as_uint(v.y) & 0xFFFF0000u)};
+}
 __device__ __forceinline__ void split8(const float (&x)[8], BP& o) {
-  float r1[8], r2[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    r1[j] = x[j] - __uint_as_float(__float_as_uint(x[j]) & 0xFFFF0000u);
-    r2[j] = r1[j] - __uint_as_float(__float_as_uint(r1[j]) & 0xFFFF0000u);
-  }
   u32x4 q0, q1, q2;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    q0[i] = top_pair(x[2 * i + 1], x[2 * i]);
-    q1[i] = top_pair(r1[2 * i + 1], r1[2 * i]);
-    q2[i] = top_pair(r2[2 * i + 1], r2[2 * i]);
+    const f32x2 v = {x[2 * i], x[2 * i + 1]};
+    const f32x2 r1 = v - trunc_pair(v);
+    const f32x2 r2 = r1 - trunc_pair(r1);
+    q0[i] = top_pair(v.y, v.x);
+    q1[i] = top_pair(r1.y, r1.x);
+    q2[i] = top_pair(r2.y, r2.x);
   }
   o.p[0] = __builtin_bit_cast(bf16x8, q0);
   o.p[1] = __builtin_bit_cast(bf16x8, q1);
@@ -155,15 +157,12 @@ __device__ __forceinline__ bf16x8 halves(uint32_t a0, uint32_t a1, uint32_t b0, 
 }
 // four fp32 (a feature-lane tile: samples 4 g + r) -> H-side operands
 __device__ __forceinline__ void split4(const f32x4& t, BT& o) {
-  float r1[4], r2[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    r1[j] = t[j] - __uint_as_float(__float_as_uint(t[j]) & 0xFFFF0000u);
-    r2[j] = r1[j] - __uint_as_float(__float_as_uint(r1[j]) & 0xFFFF0000u);
-  }
-  const uint32_t p0a = top_pair(t[1], t[0]), p0b = top_pair(t[3], t[2]);
-  const uint32_t p1a = top_pair(r1[1], r1[0]), p1b = top_pair(r1[3], r1[2]);
-  const uint32_t p2a = top_pair(r2[1], r2[0]), p2b = top_pair(r2[3], r2[2]);
+  const f32x2 va = {t[0], t[1]}, vb = {t[2], t[3]};
+  const f32x2 r1a = va - trunc_pair(va), r1b = vb - trunc_pair(vb);
+  const f32x2 r2a = r1a - trunc_pair(r1a), r2b = r1b - trunc_pair(r1b);
+  const uint32_t p0a = top_pair(va.y, va.x), p0b = top_pair(vb.y, vb.x);
+  const uint32_t p1a = top_pair(r1a.y, r1a.x), p1b = top_pair(r1b.y, r1b.x);
+  const uint32_t p2a = top_pair(r2a.y, r2a.x), p2b = top_pair(r2b.y, r2b.x);
   o.t20 = halves(p2a, p2b, p0a, p0b);
   o.t01 = halves(p0a, p0b, p1a, p1b);
 }
