@@ -97,12 +97,16 @@ class SdfHotPath:
         if split_levels is None:
             split_levels = reduce and parallel.world_size() > 1
         if split_levels:
-            # Data parallel: the lattice gradient (4*L*T*F bytes) is the only large message of the step.  The levels
-            # are independent, so the backward runs as two launches over level ranges of about equal cost (fine levels
-            # are the expensive ones) and the all-reduce of the first range travels over xGMI while the second range is
-            # still being computed.
+            # Data parallel: the lattice gradient (4*L*T*F bytes, the same 2 MiB for every level) is the only large message
+            # of the step.  The levels are independent, so the backward runs as two launches over level ranges and the
+            # all-reduce of the first range travels over xGMI while the second range is still being computed.  Where to
+            # cut (tools/enc_bwd_ranges.py, 2 M points, 16 levels; one launch 1.14 ms): the binning kernel needs many levels
+            # in flight to fill the chip, so two equal halves cost +0.26 ms, a 9/7 cut +0.25 ms, but a 6/10 cut only
+            # +0.06 ms -- the first six levels are the cheap, coarse ones (0.15 ms), and the 10 expensive ones that hide
+            # their 12.6 MB of traffic still run as one launch.  With the all-reduce at B GB/s the step pays
+            # 0.06 ms + 21 MB / B instead of 33.5 MB / B unsplit: ahead for every B below ~200 GB/s.
             L_ = cfg.nr_levels
-            cut = max(1, min(L_ - 1, (9 * L_ + 15) // 16))
+            cut = max(1, min(L_ - 1, (3 * L_ + 4) // 8))
             for l0, l1 in ((0, cut), (cut, L_)):
                 self._encode_backward_levels(rs.samples_pos, d_feat, g_lat, l0, l1)
                 if reduce:
