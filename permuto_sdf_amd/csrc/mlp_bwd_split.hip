@@ -4,16 +4,19 @@
 // VALU work do not overlap on gfx950 (profiles/r01_mfma_valu_overlap.txt), and the fp32 kernel (mlp_bwd.hip) spends 49 %
 // of its time in them.  Structure (tools/mlp_bwd_split_bf16_v3.hip is the standalone prototype with its history):
 //   * 16-sample tiles on v_mfma_f32_16x16x32_bf16, one wave per SIMD, dW accumulators persistent in registers (176);
-//   * forward recomputed from X; gelu and gelu' from one erf + one exp;
+//   * forward recomputed from X; gelu and gelu' from one exponential and one reciprocal (gelu_rational below);
 //   * the sample<->feature transposes that the dW products need are MFMAs against a 0/1 operand (no LDS, no VALU);
-//   * a dW MFMA (K = samples, only 16 of 32 slots filled by a tile) carries two piece products in its two K halves;
+//   * a dW MFMA (K = samples, only 16 of 32 slots filled by a tile) carries two piece products in its two K halves
+//     (480 instead of 612 MFMAs per tile);
 //   * both weight orientations as pre-split pieces in LDS (142 KB), built per call by mlp_split_pack_kernel;
-//   * the next tile's inputs arrive by LDS-DMA (global_load_lds) while the current tile is computed (SQ counters of the
-//     version without it: 39 % of the wave's time in s_waitcnt), and loop-invariant lane arithmetic is re-materialised
-//     per tile because a scratch reload would wait (vmcnt) for the DMA in flight;
+//   * the next tile's inputs arrive by LDS-DMA (global_load_lds, 16-byte form) while the current tile is computed (SQ
+//     counters of the version without it: 39 % of the wave's time in s_waitcnt), and loop-invariant lane arithmetic is
+//     re-materialised per tile because a scratch reload would wait (vmcnt) for the DMA in flight;
 //   * one gradient image per workgroup, summed by a second launch into the torch-layout dW / db.
-// Measured (2 M samples, 36-64-64-64-1): 1.44 ms against 1.83 ms for the fp32 kernel; gradients within 1e-6 relative of a
-// float64 evaluation.  Built with -mllvm -amdgpu-mfma-vgpr-form=1 (only the accumulators live in AGPRs).
+// Measured (2 M samples, 36-64-64-64-1): 1.20 ms against 1.83 ms for the fp32 kernel (history: DESIGN.md section 9,
+// profiles/r02_mlp_bwd_prototype_timings.txt); gradients within 1e-6 relative of a float64 evaluation.  Built with
+// -mllvm -amdgpu-mfma-vgpr-form=1 (only the accumulators live in AGPRs); the K0 <= 36 instantiation in its own translation
+// unit (mlp_bwd_split_double.hip).
 #include "psdf_common.h"
 
 namespace {
