@@ -279,6 +279,12 @@ int psdf_first_hit_dense(int nr_rays, int nr_voxels_per_dim, float extent, const
 int psdf_sphere_trace_step(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const
     uint8_t* grid_occupancy, const float* dirs, const float* sdf, float sdf_multiplier, float sdf_converged_thresh,
     float* pts, uint8_t* converged, const uint32_t* coarse_mask, void* stream);
+/* the same iteration with the long marches compacted into a second, densely packed launch (same results): work_flags
+   [count] bytes, work_list [count] ints, work_count [1] int that the caller has zeroed; coarse_mask optional (the marches) */
+int psdf_sphere_trace_step_compacted(int count, int nr_voxels_per_dim, float extent, const float* grid_translation, const
+    uint8_t* grid_occupancy, const float* dirs, const float* sdf, float sdf_multiplier, float sdf_converged_thresh,
+    float* pts, uint8_t* converged, uint8_t* work_flags, int* work_list, int* work_count, const uint32_t* coarse_mask,
+    void* stream);
 
 /* ---- volume_rendering.hip ---- */
 /* replaces: (helper) replaces the atomicAdd slot counters, e.g. kernels/permuto_sdf/OccupancyGridGPU.cuh:599 */

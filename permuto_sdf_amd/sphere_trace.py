@@ -20,6 +20,10 @@ class SphereTracer:
         dev = encoding.lattice_values.device
         self.window = window if window is not None else torch.ones(encoding.nr_levels, device=dev)
         self._graph = None
+        # step + march as two launches, the (few) long marches densely packed in the second one (csrc/sampling.hip,
+        # sphere_trace_step_a_kernel); False: the single kernel, where a marching lane holds its whole wave
+        self.compact_marches = True
+        self.coarse_mask_for_marches = True
 
     # ---- building blocks -----------------------------------------------------------------------------------
     def _sdf(self, pts, dims, packed, skip=None, out=None, feat_buf=None):
@@ -61,10 +65,22 @@ class SphereTracer:
         packed = pack_params(dims, ws, bs)
         sdf = torch.zeros((1, R), dtype=torch.float32, device=dev)
         feat_buf = torch.zeros((self.enc.cfg.channels, R), dtype=torch.float32, device=dev)
-        for _ in range(nr_sphere_traces):
+        if self.compact_marches:   # work buffers of the two-launch step: flags, list, one counter per iteration (one fill)
+            flags = torch.empty(R, dtype=torch.uint8, device=dev)
+            todo = torch.empty(R, dtype=torch.int32, device=dev)
+            counts = torch.zeros(max(1, nr_sphere_traces), dtype=torch.int32, device=dev)
+            # the compacted marches are the long ones through empty space: there the coarse mask pays (one mask per trace,
+            # the grid does not change during it)
+            coarse_b = self.grid._coarse(1 << 30) if self.coarse_mask_for_marches else None
+        for it in range(nr_sphere_traces):
             self._sdf(pts, dims, packed, skip=conv.view(-1), out=sdf, feat_buf=feat_buf)   # converged rays are skipped
-            L.call("psdf_sphere_trace_step", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf),
-                   L.c_f(sdf_multiplier), L.c_f(sdf_converged_tresh), L.ptr(pts), L.ptr(conv), L.ptr(coarse), L.stream())
+            if self.compact_marches:
+                L.call("psdf_sphere_trace_step_compacted", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf),
+                       L.c_f(sdf_multiplier), L.c_f(sdf_converged_tresh), L.ptr(pts), L.ptr(conv), L.ptr(flags), L.ptr(todo),
+                       L.ptr(counts[it:it + 1]), L.ptr(coarse_b), L.stream())
+            else:
+                L.call("psdf_sphere_trace_step", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf),
+                       L.c_f(sdf_multiplier), L.c_f(sdf_converged_tresh), L.ptr(pts), L.ptr(conv), L.ptr(coarse), L.stream())
         feat, sdf = self._sdf(pts, dims, packed)
         grads = None
         if return_gradients:

@@ -81,6 +81,13 @@ def test_fixed_shape_trace_equals_reference_style_loop(dev):
     cnt = (rs.ray_start_end_idx[:, 1] - rs.ray_start_end_idx[:, 0]).bool()      # rays that met an occupied voxel
     assert int(cnt.sum()) == ref_pts.shape[0] > 5000
     assert torch.equal(pts[cnt], ref_pts)                                          # bit-identical end points
+    # the three forms of the iteration agree bit for bit: one kernel / step + compacted marches / the latter with the LDS mask
+    assert tracer.compact_marches and tracer.coarse_mask_for_marches
+    for compact, coarse in ((False, False), (True, False)):
+        other = SphereTracer(enc, mlp, grid, sphere, win)
+        other.compact_marches, other.coarse_mask_for_marches = compact, coarse
+        p2, s2, _, c2 = other.trace(o, d, 15, 0.9, 2e-4, False)
+        assert torch.equal(p2, pts) and torch.equal(c2, conv) and torch.equal(s2, sdf), (compact, coarse)
     # converged rays that hit the sphere lie on it, and the analytic normal points outwards with unit length
     on_surface = cnt & (sdf.view(-1).abs() < 2e-4)
     assert int(on_surface.sum()) > 3000
