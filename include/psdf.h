@@ -145,6 +145,15 @@ int psdf_encode_forward_masked(int pos_dim, int nr_feat, int64_t N, int nr_level
     points_scaling, const uint8_t* skip, float* sliced, void* stream);
 int psdf_mlp_forward_masked(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, const uint8_t*
     skip, float* Y, void* stream);
+/* the analytic normal of the same callers (reference: get_sdf_and_gradient on the traced end points,
+   permuto_sdf_py/utils/sdf_utils.py:203-208, which in the reference holds only the rays that met occupancy): data gradient
+   of the MLP and position gradient of the encoding under the same mask; masked samples keep the contents of their outputs */
+int psdf_mlp_backward_data_masked(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+    const float* const* biases, const float* dY, const uint8_t* skip, float* dX, void* stream);
+int psdf_encode_backward_positions_masked(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float*
+    positions, const float* lattice, const float* scale_factor, const float* shifts, const float* window, int
+    concat_points, float points_scaling, const float* grad_sliced, const uint8_t* skip, float* grad_positions, void*
+    stream);
 
 /* ---- mlp_bwd.hip ---- */
 /* replaces: autograd backward of the same evaluators (dX, dW_l, db_l in one launch; forward recomputed from X).

@@ -526,9 +526,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, const float* __restrict__ positions,
                           const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                           const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
-                          int pad_points, const float* __restrict__ grad_sliced, float* __restrict__ grad_positions) {
+                          int pad_points, const float* __restrict__ grad_sliced, const unsigned char* __restrict__ skip,
+                          float* __restrict__ grad_positions) {
   const int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
   if (n >= N) return;
+  if (skip && skip[n]) return;     // masked sample: its gradient stays as it is
   float pos[P];
   load_pos<P>(positions, n, pos);
   float gp[P];
@@ -930,7 +932,8 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     else                                                                                                         \
       hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, \
                          st, N, nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, \
-                         points_scaling, pad_points(concat_points), grad_sliced, grad_positions);                \
+                         points_scaling, pad_points(concat_points), grad_sliced, (const unsigned char*)nullptr,  \
+                         grad_positions);                                                                          \
     if (use_queue) {                                                                                             \
       const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                          \
       hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                              \
@@ -963,6 +966,39 @@ int psdf_encode_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int
   return psdf_encode_backward_ws(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts,
                                  window, concat_points, points_scaling, grad_sliced, grad_lattice, grad_positions,
                                  nullptr, 0, stream);
+}
+
+// Position gradient only, with a per-sample mask (masked samples: no gathers, their rows of grad_positions keep their
+// contents).  grad_positions is ACCUMULATED INTO, as in psdf_encode_backward.
+int psdf_encode_backward_positions_masked(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity,
+                                          const float* positions, const float* lattice, const float* scale_factor,
+                                          const float* shifts, const float* window, int concat_points, float points_scaling,
+                                          const float* grad_sliced, const unsigned char* skip, float* grad_positions,
+                                          void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !grad_sliced || !grad_positions ||
+      !concat_ok(concat_points))
+    return PSDF_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
+  const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
+#define POS(P_, F_)                                                                                                  \
+  hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, st, N,   \
+                     nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling, \
+                     pad_points(concat_points), grad_sliced, skip, grad_positions)
+  if (pos_dim == 3 && nr_feat == 2)
+    POS(3, 2);
+  else if (pos_dim == 4 && nr_feat == 2)
+    POS(4, 2);
+  else if (pos_dim == 2 && nr_feat == 2)
+    POS(2, 2);
+  else if (pos_dim == 3 && nr_feat == 4)
+    POS(3, 4);
+  else
+    return PSDF_ERR_UNSUPPORTED;
+#undef POS
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
 }
 
 // grad_lattice must be zero-initialised (or NULL to skip); grad_grad_sliced is fully overwritten.

@@ -151,6 +151,7 @@ struct BwdPtrs {
   float* dW[MAXL];
   float* db[MAXL];
   float* partial;  // [gridDim.x][p.total] workgroup gradient images (summed by mlp_grad_reduce_kernel), or NULL: atomics
+  const unsigned char* skip = nullptr;  // [N] or NULL: 16-sample tiles whose samples are all masked are not evaluated
 };
 
 // Workgroup gradient image -> global.  With a scratch buffer every workgroup stores its image (coalesced, no atomics:
@@ -512,6 +513,7 @@ __global__ void __launch_bounds__(NW * 64)
     if (tile + tstride < ntiles) prefetch(tile + tstride, xbuf + (cur ^ 1) * (SX * 64));
     const int64_t n = tile * 16 + c;
     const bool live = n < N;
+    if (a.skip && __ballot(live && !a.skip[n]) == 0) continue;   // a fully masked tile (its dX stays as it is)
     // ---------------------------------------------------------------- forward: activations and their derivatives
     f32x4 h1[T1], d1[T1], h2[T2], d2[T2], h3[T3S], d3[T3S];
     {
@@ -1199,6 +1201,43 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
 #undef CASE
   // nets too wide for one wave's registers (the 128-wide colour network): workgroup-cooperative kernel, mlp_wide.hip
   if (dW) return psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
+  return PSDF_ERR_UNSUPPORTED;
+}
+
+// psdf_mlp_backward restricted to the data gradient (dW = db = NULL) with a per-sample mask: 16-sample tiles whose samples
+// are all masked are skipped (their columns of dX keep their contents); masked samples inside a live tile are evaluated.
+int psdf_mlp_backward_data_masked(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                                  const float* const* biases, const float* dY, const unsigned char* skip, float* dX,
+                                  void* stream) {
+  Plan16 p;
+  int rc = make_plan16(n_layers, dims, p);
+  if (rc != PSDF_OK) return rc;
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || !X || !weights || !biases || !dY || !dX) return PSDF_ERR_ARG;
+  if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
+  BwdPtrs a;
+  a.partial = nullptr;
+  a.skip = skip;
+  for (int l = 0; l < MAXL; l++) {
+    a.W[l] = l < n_layers ? weights[l] : nullptr;
+    a.b[l] = l < n_layers ? biases[l] : nullptr;
+    a.dW[l] = nullptr;
+    a.db[l] = nullptr;
+    if (l < n_layers && (!a.W[l] || !a.b[l])) return PSDF_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int ti0 = p.tiles[0], t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0,
+            to = p.tiles[n_layers];
+#define CASE(I, A, B, C, O, D)                                                   \
+  if (ti0 == I && t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
+    return launch_bwd<I, A, B, C, O, D>(p, N, X, dY, dX, a, st);
+  CASE(3, 4, 4, 4, 1, true)
+  CASE(4, 4, 4, 4, 1, true)
+  CASE(2, 4, 4, 4, 1, true)
+  CASE(4, 2, 2, 2, 1, true)
+  CASE(3, 2, 2, 2, 1, true)
+  CASE(2, 2, 2, 2, 1, true)
+#undef CASE
   return PSDF_ERR_UNSUPPORTED;
 }
 

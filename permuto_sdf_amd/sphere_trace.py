@@ -7,11 +7,13 @@ no host synchronisation and can therefore be captured ONCE into a hipGraph and r
 (``SphereTracer.capture``).  Converged rays are masked out inside the step kernel; their SDF evaluation is wasted
 work, which is the price of the static shape (and is cheap: 2M-point encode + MLP is ~1.6 ms).
 """
+import ctypes
+
 import torch
 
 from . import _lib as L
 from .encoding import _head, _tail, encode_forward_raw
-from .mlp import mlp_backward_raw, mlp_forward_raw, pack_params
+from .mlp import _dims_array, mlp_forward_raw, pack_params
 
 
 class SphereTracer:
@@ -43,8 +45,10 @@ class SphereTracer:
     @torch.no_grad()
     def trace(self, ray_origins, ray_dirs, nr_sphere_traces=15, sdf_multiplier=0.9, sdf_converged_tresh=2e-4,
               return_gradients=True):
-        """-> pts [R,3], sdf [R,1], sdf_gradients [R,3] or None, converged [R,1] bool (rays that never met an
-        occupied voxel are reported converged with their point left at the ray origin)."""
+        """-> pts [R,3], sdf [R,1], sdf_gradients [R,3] or None, converged [R,1] bool.  Rays that never met an occupied voxel
+        are reported converged with their point left at the ray origin and sdf = 0, gradient = 0: the reference's trace
+        does not hold them at all (it compacts to the rays that shoot through occupancy, sdf_utils.py:127-129), and the
+        final SDF + normal evaluation skips them here too (`self.no_hit`, [R] bool, tells them apart afterwards)."""
         o, d = ray_origins.contiguous(), ray_dirs.contiguous()
         R, dev = o.shape[0], o.device
         _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
@@ -56,6 +60,8 @@ class SphereTracer:
         coarse = None
         L.call("psdf_first_hit_dense", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(o), L.ptr(d), L.ptr(te), L.ptr(tx),
                L.ptr(pts), L.ptr(conv), L.ptr(coarse), L.stream())
+        no_hit = conv.view(-1).clone()      # before the iterations `converged` means exactly "met no occupied voxel"
+        self.no_hit = no_hit
         # channel 0 of the last layer is the SDF (models.py:190-192); the geometry features are not needed to trace,
         # so the net is evaluated with a 1-row head (same arithmetic for that row, 1/33 of the output traffic)
         ws = [l.weight.detach() for l in self.mlp.layers]
@@ -81,17 +87,24 @@ class SphereTracer:
             else:
                 L.call("psdf_sphere_trace_step", L.c_i(R), *self._grid_args(), L.ptr(occ), L.ptr(d), L.ptr(sdf),
                        L.c_f(sdf_multiplier), L.c_f(sdf_converged_tresh), L.ptr(pts), L.ptr(conv), L.ptr(coarse), L.stream())
-        feat, sdf = self._sdf(pts, dims, packed)
+        # final SDF (+ analytic normal) at the end points of the rays that took part
+        sdf.zero_()
+        feat, sdf = self._sdf(pts, dims, packed, skip=no_hit, out=sdf, feat_buf=feat_buf)
         grads = None
         if return_gradients:
             # analytic normal: d sdf / d x = encode_backward_positions( mlp_backward_dX( 1 ) )
+            n_layers = len(dims) - 1
+            d_feat = torch.empty_like(feat)
             gy = torch.ones_like(sdf)
-            d_feat, _, _ = mlp_backward_raw(dims, feat, ws, bs, gy, need_dx=True, need_dw=False)
+            Wp = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
+            Bp = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
+            L.call("psdf_mlp_backward_data_masked", L.c_i(n_layers), _dims_array(dims), L.c_l(R), L.ptr(feat), Wp, Bp,
+                   L.ptr(gy), L.ptr(no_hit), L.ptr(d_feat), L.stream())
             grads = torch.zeros((R, 3), dtype=torch.float32, device=dev)
             cfg = self.enc.cfg
-            L.call("psdf_encode_backward", *_head(cfg, R), L.ptr(pts), L.ptr(self.enc.lattice_values.detach()),
+            L.call("psdf_encode_backward_positions_masked", *_head(cfg, R), L.ptr(pts), L.ptr(self.enc.lattice_values.detach()),
                    L.ptr(self.enc.scale_factor), L.ptr(self.enc.random_shift_per_level.detach()), L.ptr(self.window),
-                   *_tail(cfg), L.ptr(d_feat), None, L.ptr(grads), L.stream())
+                   *_tail(cfg), L.ptr(d_feat), L.ptr(no_hit), L.ptr(grads), L.stream())
         return pts, sdf.reshape(-1, 1), grads, conv
 
     # ---- hipGraph ------------------------------------------------------------------------------------------------

@@ -217,3 +217,60 @@ def test_fused_trace_kernels_against_cpu_oracle_trace(dev):
     assert np.median(diff) <= 1e-6
     agree = conv2 == c2.cpu().numpy().reshape(-1)[ids2]
     assert agree.mean() >= 0.995
+
+
+def test_masked_normal_kernels_equal_unmasked_on_live_samples(dev):
+    """psdf_mlp_backward_data_masked / psdf_encode_backward_positions_masked (the tracer's final normal, evaluated only for
+    the rays that took part): equal to the unmasked calls on the live samples, masked rows keep their contents; a tracer
+    reports sdf = 0 and a zero normal for the rays that met no occupied voxel."""
+    import ctypes
+    from permuto_sdf_amd import _lib as L
+    from permuto_sdf_amd import FusedMLP, PermutoEncoding
+    from permuto_sdf_amd.encoding import _head, _tail, encode_forward_raw
+    from permuto_sdf_amd.mlp import _dims_array, mlp_backward_raw
+    torch.manual_seed(4)
+    N = 20_011
+    enc = PermutoEncoding(3, 2 ** 16, 8, 2, np.geomspace(1.0, 0.02, 8), concat_points=True, concat_points_scaling=1.0,
+                          init_scale=1e-1).to(dev)
+    mlp = FusedMLP([enc.output_dims(), 32, 32, 32, 1], reference_init=True).to(dev)
+    win = torch.ones(8, device=dev)
+    pts = (torch.rand(N, 3, device=dev) - 0.5).contiguous()
+    skip = torch.rand(N, device=dev) < 0.6
+    skip[4096:4096 + 4000] = True                      # whole 16-sample tiles masked
+    skip[:64] = False
+    ws, bs = [l.weight.detach() for l in mlp.layers], [l.bias.detach() for l in mlp.layers]
+    feat = encode_forward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win)
+    gy = torch.ones(1, N, device=dev)
+    dref, _, _ = mlp_backward_raw(mlp.dims, feat, ws, bs, gy, need_dx=True, need_dw=False)
+    d_feat = torch.full_like(feat, 7.0)
+    Wp = (ctypes.c_void_p * 4)(*[w.data_ptr() for w in ws])
+    Bp = (ctypes.c_void_p * 4)(*[b.data_ptr() for b in bs])
+    L.call("psdf_mlp_backward_data_masked", L.c_i(4), _dims_array(mlp.dims), L.c_l(N), L.ptr(feat), Wp, Bp, L.ptr(gy),
+           L.ptr(skip), L.ptr(d_feat), L.stream())
+    live = ~skip
+    assert torch.equal(d_feat[:, live], dref[:, live])
+    assert bool((d_feat[:, 4096:4096 + 4000] == 7.0).all())          # fully masked tiles: untouched
+    cfg = enc.cfg
+    gref = torch.zeros(N, 3, device=dev)
+    L.call("psdf_encode_backward", *_head(cfg, N), L.ptr(pts), L.ptr(enc.lattice_values.detach()), L.ptr(enc.scale_factor),
+           L.ptr(enc.random_shift_per_level.detach()), L.ptr(win), *_tail(cfg), L.ptr(dref), None, L.ptr(gref), L.stream())
+    g = torch.full((N, 3), -3.0, device=dev)
+    g[live] = 0.0
+    L.call("psdf_encode_backward_positions_masked", *_head(cfg, N), L.ptr(pts), L.ptr(enc.lattice_values.detach()),
+           L.ptr(enc.scale_factor), L.ptr(enc.random_shift_per_level.detach()), L.ptr(win), *_tail(cfg), L.ptr(dref),
+           L.ptr(skip), L.ptr(g), L.stream())
+    # (the level groups of a sample meet in grad_positions with float atomics: same terms, order not fixed)
+    assert float((g[live] - gref[live]).abs().max()) <= 1e-6 * float(gref.abs().max()) and bool((g[skip] == -3.0).all())
+
+    from permuto_sdf import OccupancyGrid, Sphere
+    from permuto_sdf_amd.sphere_trace import SphereTracer
+    port = O.Oracle("port")
+    grid = OccupancyGrid(64, 1.0, [0, 0, 0])
+    grid.set_grid_occupancy(torch.from_numpy(scene.shell_occupancy(port, 64, r0=0.3, width=0.06, drop=0.0)).to(dev))
+    on, dn = scene.make_rays(6000, seed=8, jitter_target=0.9)            # wide: many rays miss the shell
+    tr = SphereTracer(enc, FusedMLP([enc.output_dims(), 32, 32, 32, 33], reference_init=True).to(dev), grid, Sphere(0.5, [0, 0, 0]), win)
+    p, s, gr, c = tr.trace(torch.from_numpy(on).to(dev), torch.from_numpy(dn).to(dev), 5, 0.9, 2e-4, True)
+    miss = tr.no_hit
+    assert 100 < int(miss.sum()) < 5900
+    assert bool((s[miss] == 0).all()) and bool((gr[miss] == 0).all()) and bool(c[miss].all())
+    assert bool((gr[~miss].abs().sum(1) > 0).any())
