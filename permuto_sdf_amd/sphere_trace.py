@@ -2,10 +2,11 @@
 
 Mirrors ``sphere_trace`` of the reference (permuto_sdf_py/utils/sdf_utils.py:120-218) on top of the same kernels, but
 keeps one slot per ray instead of compacting the unconverged rays with boolean masks every iteration: the whole trace
-is a fixed sequence of launches (first hit -> [encode -> fused MLP -> step] x n -> final SDF + analytic normal), has
-no host synchronisation and can therefore be captured ONCE into a hipGraph and replayed per frame
-(``SphereTracer.capture``).  Converged rays are masked out inside the step kernel; their SDF evaluation is wasted
-work, which is the price of the static shape (and is cheap: 2M-point encode + MLP is ~1.6 ms).
+is a fixed sequence of launches -- first hit -> [masked encode -> masked MLP -> step (+ compacted long marches)] x n ->
+masked final SDF + analytic normal -- has no host synchronisation and can therefore be captured ONCE into a hipGraph and
+replayed per frame (``SphereTracer.capture``).  Converged rays are masked out of the SDF evaluations (no gathers; fully
+converged 32-ray tiles no MLP), rays that met no occupied voxel also out of the final evaluation.  End points are bit
+identical to the reference-style compacting loop (tests/test_gpu_sphere_trace.py).
 """
 import ctypes
 
