@@ -107,6 +107,36 @@ __device__ __forceinline__ float dist_to_next_voxel(v3 pos, v3 dir, v3 idir, con
   const float t = fminf(fminf(fabsf(tx), fabsf(ty)), fabsf(tz));
   return fmaxf(g.div_n(t), 0.0f);
 }
+// The same grid with what the reference's grids always have folded in at compile time: extent 1 (dividing by it is the
+// identity) and a power-of-two n (dividing by it is an exact scaling).  The DDA loops are latency chains -- a step is ~150
+// instructions in the generic form, a third of them the run-time selection between the exact shortcuts and the divisions,
+// scalar bookkeeping and the re-derivation of n^3 -- so the kernels are instantiated for both types and the host picks
+// (mk_grid: `unit` and `inv_n`).  Same expressions in the same order: bit-identical results.
+struct GridFast {
+  int n;
+  float nf;       // (float)n, exact
+  int nvox;       // n^3
+  float tx, ty, tz;
+  float inv_n;    // 1 / n, exact
+  __device__ __forceinline__ int nr_voxels() const { return nvox; }
+  __device__ __forceinline__ float div_n(float x) const { return x * inv_n; }
+  __device__ __forceinline__ int pos_to_idx(v3 p) const {
+    float x = p.x - tx, y = p.y - ty, z = p.z - tz;
+    x = (x + 0.5f) * nf;
+    y = (y + 0.5f) * nf;
+    z = (z + 0.5f) * nf;
+    return (int)morton3(sat_u32(x), sat_u32(y), sat_u32(z));
+  }
+  __device__ __forceinline__ bool in_range(int idx) const { return !(idx >= nvox || idx < 0); }
+};
+__device__ __forceinline__ float dist_to_next_voxel(v3 pos, v3 dir, v3 idir, const GridFast& g) {
+  pos = g.nf * pos;
+  const float tx = (floorf(pos.x + 0.5f + 0.5f * sgn(dir.x)) - pos.x) * idir.x;
+  const float ty = (floorf(pos.y + 0.5f + 0.5f * sgn(dir.y)) - pos.y) * idir.y;
+  const float tz = (floorf(pos.z + 0.5f + 0.5f * sgn(dir.z)) - pos.z) * idir.z;
+  const float t = fminf(fminf(fabsf(tx), fabsf(ty)), fabsf(tz));
+  return fmaxf(t * g.inv_n, 0.0f);
+}
 __device__ __forceinline__ v3 safe_inverse(v3 d) {
   v3 r;
   r.x = fabsf(d.x) < 1e-16f ? 0.f : (float)(1.0 / (double)d.x);
@@ -234,9 +264,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // at the ray's exact offset with coalesced stores.  (The first version of this file ran the whole march twice, once
 // to count and once to write: the DDA loop is a chain of dependent 1-byte grid probes, the most expensive thing in a
 // volume render after the network itself.)
-template <bool USE_GRID>
+template <bool USE_GRID, typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    march_kernel(int nr_rays, Grid g, Occ o, const float* __restrict__ origins,
+    march_kernel(int nr_rays, G g, Occ o, const float* __restrict__ origins,
                  const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
                  float min_dist, int max_per_ray, Pcg rng, int jitter, int* __restrict__ counts,
                  float* __restrict__ spacings, float* __restrict__ ztemp) {
@@ -381,9 +411,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 }
 
 // first sample at the entry of the first occupied voxel (sphere-tracing start), OccupancyGridGPU.cuh:707-814
-template <bool WRITE>
+template <bool WRITE, typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    first_hit_kernel(int nr_rays, Grid g, Occ o, const float* __restrict__ origins,
+    first_hit_kernel(int nr_rays, G g, Occ o, const float* __restrict__ origins,
                      const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
                      int max_nr_samples, const int* __restrict__ offsets, int* __restrict__ counts,
                      float* __restrict__ s_pos, float* __restrict__ s_dirs, float* __restrict__ s_z,
@@ -439,8 +469,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 }
 
 // march a point along its direction to the next occupied voxel (OccupancyGridGPU.cuh:817-895); in place
+template <typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    advance_kernel(int count, Grid g, Occ o, const float* __restrict__ dirs,
+    advance_kernel(int count, G g, Occ o, const float* __restrict__ dirs,
                    float* __restrict__ pts, uint8_t* __restrict__ within) {
   extern __shared__ uint32_t cm_lds[];
   const uint32_t* cm = stage_coarse(o, cm_lds);
@@ -478,8 +509,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // masks every iteration (dynamic shapes, implicit host syncs).  These two kernels keep ONE slot per ray for the whole
 // trace, so the 15-iteration loop is a fixed sequence of launches that a hipGraph can replay.
 // first hit, dense: the per-ray result of compute_first_sample_start_of_occupied_regions without packing
+template <typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    first_hit_dense_kernel(int nr_rays, Grid g, Occ o, const float* __restrict__ origins,
+    first_hit_dense_kernel(int nr_rays, G g, Occ o, const float* __restrict__ origins,
                            const float* __restrict__ dirs, const float* __restrict__ t_entry,
                            const float* __restrict__ t_exit_p, float push, float* __restrict__ pos,
                            uint8_t* __restrict__ converged) {
@@ -517,8 +549,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // one trace iteration for every ray that has not converged (sdf_utils.py:167-185): step along the ray by
 // sdf*multiplier, mark converged when |sdf| < threshold, march to the next occupied voxel, mark converged when the
 // march leaves the grid.
+template <typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    sphere_trace_step_kernel(int count, Grid g, Occ o, const float* __restrict__ dirs,
+    sphere_trace_step_kernel(int count, G g, Occ o, const float* __restrict__ dirs,
                              const float* __restrict__ sdf, float multiplier, float thresh, float* __restrict__ pts,
                              uint8_t* __restrict__ converged) {
   extern __shared__ uint32_t cm_lds[];
@@ -565,8 +598,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // list (one atomic per wave).  Phase B marches the listed rays, densely packed, over a fixed grid (count read from device
 // memory: the launch sequence stays fixed-shape and graph-capturable).  Per ray the arithmetic is the one of
 // sphere_trace_step_kernel, so the end points are the same bit for bit.
+template <typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    sphere_trace_step_a_kernel(int count, Grid g, Occ o, const float* __restrict__ dirs, const float* __restrict__ sdf,
+    sphere_trace_step_a_kernel(int count, G g, Occ o, const float* __restrict__ dirs, const float* __restrict__ sdf,
                                float multiplier, float thresh, float* __restrict__ pts, uint8_t* __restrict__ converged,
                                uint8_t* __restrict__ done_flag, int* __restrict__ list, int* __restrict__ list_count) {
   const int i = blockIdx.x * PSDF_BLOCK + threadIdx.x;
@@ -600,9 +634,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
 }
 
-template <int AHEAD>
+template <int AHEAD, typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    sphere_trace_step_b_kernel(Grid g, Occ o, const float* __restrict__ dirs, float* __restrict__ pts,
+    sphere_trace_step_b_kernel(G g, Occ o, const float* __restrict__ dirs, float* __restrict__ pts,
                                uint8_t* __restrict__ converged, const uint8_t* __restrict__ done_flag,
                                const int* __restrict__ list, const int* __restrict__ list_count) {
   extern __shared__ uint32_t cm_lds[];
@@ -951,6 +985,8 @@ inline Grid mk_grid(int n, float extent, const float* tr) {
   const bool pow2 = n > 0 && (n & (n - 1)) == 0;
   return Grid{n, extent, tr[0], tr[1], tr[2], pow2 ? 1.0f / (float)n : 0.f, extent == 1.0f ? 1 : 0};
 }
+inline bool grid_is_fast(const Grid& g) { return g.unit && g.inv_n != 0.f; }
+inline GridFast mk_fast(const Grid& g) { return GridFast{g.n, (float)g.n, g.n * g.n * g.n, g.tx, g.ty, g.tz, g.inv_n}; }
 #define GRID1(n) dim3(psdf_blocks((n), PSDF_BLOCK)), dim3(PSDF_BLOCK), 0, st
 #define GRID1C(n, oc) dim3(psdf_blocks((n), PSDF_BLOCK)), dim3(PSDF_BLOCK), (oc).coarse ? (size_t)(oc).words * 4 : 0, st
 // words of the coarse mask of an n^3 grid (0: grid too small or too large for the LDS copy -> no mask)
@@ -1052,13 +1088,15 @@ int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float e
   int* offsets = scratch + nr_rays;
   float* spacings = reinterpret_cast<float*>(scratch + 2 * (int64_t)nr_rays);
   float* ztemp = reinterpret_cast<float*>(scratch + 3 * (int64_t)nr_rays);
-#define MARCH(G_)                                                                                                     \
-  hipLaunchKernelGGL((march_kernel<G_>), GRID1C(nr_rays, oc), nr_rays, g, oc, ray_origins, ray_dirs, ray_t_entry, \
+#define MARCH(G_, T_, g_)                                                                                                \
+  hipLaunchKernelGGL((march_kernel<G_, T_>), GRID1C(nr_rays, oc), nr_rays, g_, oc, ray_origins, ray_dirs, ray_t_entry,    \
                      ray_t_exit, min_dist_between_samples, max_nr_samples_per_ray, rng, jitter, counts, spacings, ztemp)
-  if (use_grid)
-    MARCH(true);
+  if (use_grid && grid_is_fast(g))
+    MARCH(true, GridFast, mk_fast(g));
+  else if (use_grid)
+    MARCH(true, Grid, g);
   else
-    MARCH(false);
+    MARCH(false, Grid, g);
 #undef MARCH
   hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, counts, offsets, cur_nr_samples);
   hipLaunchKernelGGL(march_fill_kernel, dim3((nr_rays + 3) / 4), dim3(PSDF_BLOCK), 0, st, nr_rays, ray_origins, ray_dirs,
@@ -1080,13 +1118,21 @@ int psdf_first_hit_samples(int nr_rays, int nr_voxels_per_dim, float extent, con
   const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
   int* counts = scratch;
   int* offsets = scratch + nr_rays;
-  hipLaunchKernelGGL((first_hit_kernel<false>), GRID1C(nr_rays, oc), nr_rays, g, oc, ray_origins, ray_dirs,
-                     ray_t_entry, ray_t_exit, max_nr_samples, offsets, counts, samples_pos, samples_dirs, samples_z,
-                     samples_dt, ray_fixed_dt, ray_start_end_idx);
+#define FIRST_HIT(W_, T_, g_)                                                                                          \
+  hipLaunchKernelGGL((first_hit_kernel<W_, T_>), GRID1C(nr_rays, oc), nr_rays, g_, oc, ray_origins, ray_dirs, ray_t_entry, \
+                     ray_t_exit, max_nr_samples, offsets, counts, samples_pos, samples_dirs, samples_z, samples_dt,       \
+                     ray_fixed_dt, ray_start_end_idx)
+  const bool fast = grid_is_fast(g);
+  if (fast)
+    FIRST_HIT(false, GridFast, mk_fast(g));
+  else
+    FIRST_HIT(false, Grid, g);
   hipLaunchKernelGGL(scan_i32_kernel, dim3(1), dim3(1024), 0, st, nr_rays, counts, offsets, cur_nr_samples);
-  hipLaunchKernelGGL((first_hit_kernel<true>), GRID1C(nr_rays, oc), nr_rays, g, oc, ray_origins, ray_dirs,
-                     ray_t_entry, ray_t_exit, max_nr_samples, offsets, counts, samples_pos, samples_dirs, samples_z,
-                     samples_dt, ray_fixed_dt, ray_start_end_idx);
+  if (fast)
+    FIRST_HIT(true, GridFast, mk_fast(g));
+  else
+    FIRST_HIT(true, Grid, g);
+#undef FIRST_HIT
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1098,8 +1144,12 @@ int psdf_advance_to_next_occupied_voxel(int count, int nr_voxels_per_dim, float 
   if (count <= 0) return PSDF_OK;
   hipStream_t st = (hipStream_t)stream;
   const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
-  hipLaunchKernelGGL(advance_kernel, GRID1C(count, oc), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
-                     oc, samples_dirs, samples_pos, is_within_bounds);
+  const Grid g = mk_grid(nr_voxels_per_dim, extent, grid_translation);
+  if (grid_is_fast(g))
+    hipLaunchKernelGGL(advance_kernel<GridFast>, GRID1C(count, oc), count, mk_fast(g), oc, samples_dirs, samples_pos,
+                       is_within_bounds);
+  else
+    hipLaunchKernelGGL(advance_kernel<Grid>, GRID1C(count, oc), count, g, oc, samples_dirs, samples_pos, is_within_bounds);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1114,8 +1164,13 @@ int psdf_first_hit_dense(int nr_rays, int nr_voxels_per_dim, float extent, const
   hipStream_t st = (hipStream_t)stream;
   const float voxel = (float)(1.0 / nr_voxels_per_dim);
   const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
-  hipLaunchKernelGGL(first_hit_dense_kernel, GRID1C(nr_rays, oc), nr_rays, mk_grid(nr_voxels_per_dim, extent, grid_translation),
-                     oc, ray_origins, ray_dirs, ray_t_entry, ray_t_exit, voxel, pos, converged);
+  const Grid g = mk_grid(nr_voxels_per_dim, extent, grid_translation);
+  if (grid_is_fast(g))
+    hipLaunchKernelGGL(first_hit_dense_kernel<GridFast>, GRID1C(nr_rays, oc), nr_rays, mk_fast(g), oc, ray_origins, ray_dirs,
+                       ray_t_entry, ray_t_exit, voxel, pos, converged);
+  else
+    hipLaunchKernelGGL(first_hit_dense_kernel<Grid>, GRID1C(nr_rays, oc), nr_rays, g, oc, ray_origins, ray_dirs, ray_t_entry,
+                       ray_t_exit, voxel, pos, converged);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1128,8 +1183,13 @@ int psdf_sphere_trace_step(int count, int nr_voxels_per_dim, float extent, const
   if (count <= 0) return PSDF_OK;
   hipStream_t st = (hipStream_t)stream;
   const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);
-  hipLaunchKernelGGL(sphere_trace_step_kernel, GRID1C(count, oc), count, mk_grid(nr_voxels_per_dim, extent, grid_translation),
-                     oc, dirs, sdf, sdf_multiplier, sdf_converged_thresh, pts, converged);
+  const Grid g = mk_grid(nr_voxels_per_dim, extent, grid_translation);
+  if (grid_is_fast(g))
+    hipLaunchKernelGGL(sphere_trace_step_kernel<GridFast>, GRID1C(count, oc), count, mk_fast(g), oc, dirs, sdf, sdf_multiplier,
+                       sdf_converged_thresh, pts, converged);
+  else
+    hipLaunchKernelGGL(sphere_trace_step_kernel<Grid>, GRID1C(count, oc), count, g, oc, dirs, sdf, sdf_multiplier,
+                       sdf_converged_thresh, pts, converged);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1147,13 +1207,23 @@ int psdf_sphere_trace_step_compacted(int count, int nr_voxels_per_dim, float ext
   const Grid g = mk_grid(nr_voxels_per_dim, extent, grid_translation);
   const Occ oc = mk_occ(nr_voxels_per_dim, grid_occupancy, nullptr);
   const Occ ocb = mk_occ(nr_voxels_per_dim, grid_occupancy, coarse_mask);   // the mask serves the long marches only
-  hipLaunchKernelGGL(sphere_trace_step_a_kernel, GRID1(count), count, g, oc, dirs, sdf, sdf_multiplier, sdf_converged_thresh,
-                     pts, converged, work_flags, work_list, work_count);
+  const bool fast = grid_is_fast(g);
+  if (fast)
+    hipLaunchKernelGGL(sphere_trace_step_a_kernel<GridFast>, GRID1(count), count, mk_fast(g), oc, dirs, sdf, sdf_multiplier,
+                       sdf_converged_thresh, pts, converged, work_flags, work_list, work_count);
+  else
+    hipLaunchKernelGGL(sphere_trace_step_a_kernel<Grid>, GRID1(count), count, g, oc, dirs, sdf, sdf_multiplier,
+                       sdf_converged_thresh, pts, converged, work_flags, work_list, work_count);
   const int blocks = count < 512 * PSDF_BLOCK ? (count + PSDF_BLOCK - 1) / PSDF_BLOCK : 512;
   // AHEAD = 1: walking ahead of the probes (2 or 4 steps) measured 1-2 % slower here, the arithmetic chain of a step is the
   // latency that counts; the LDS mask is worth 6 % of the frame (8.11 -> 7.64 ms on the sphere-initialised field)
-  hipLaunchKernelGGL(sphere_trace_step_b_kernel<1>, dim3(blocks), dim3(PSDF_BLOCK), ocb.coarse ? (size_t)ocb.words * 4 : 0, st, g,
-                     ocb, dirs, pts, converged, work_flags, work_list, work_count);
+  const size_t lds_b = ocb.coarse ? (size_t)ocb.words * 4 : 0;
+  if (fast)
+    hipLaunchKernelGGL((sphere_trace_step_b_kernel<1, GridFast>), dim3(blocks), dim3(PSDF_BLOCK), lds_b, st, mk_fast(g), ocb, dirs,
+                       pts, converged, work_flags, work_list, work_count);
+  else
+    hipLaunchKernelGGL((sphere_trace_step_b_kernel<1, Grid>), dim3(blocks), dim3(PSDF_BLOCK), lds_b, st, g, ocb, dirs, pts,
+                       converged, work_flags, work_list, work_count);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
