@@ -48,11 +48,15 @@ __host__ __device__ __forceinline__ uint32_t compact_bits10(uint32_t x) {
   x = (x | (x >> 16)) & 0x0000ffffu;
   return x;
 }
-// float -> uint32 with the device semantics the reference relies on (negative / NaN -> 0, huge -> 2^32-1)
+// float -> uint32 with the device semantics the reference relies on (negative / NaN -> 0, huge / +inf -> 2^32-1, truncation
+// otherwise): exactly what v_cvt_u32_f32 does in hardware (it saturates, NaN converts to 0), so ONE instruction instead of
+// two compares, two branches and the conversion -- three times per step of every DDA loop.  (A C cast would be undefined
+// for the out-of-range values; the instruction is named explicitly.)  tests/test_gpu_sampling.py feeds NaN / inf / huge /
+// negative coordinates through it against the oracle's explicit form.
 __device__ __forceinline__ uint32_t sat_u32(float f) {
-  if (!(f > 0.f)) return 0u;
-  if (f >= 4294967296.f) return 0xFFFFFFFFu;
-  return (uint32_t)f;
+  uint32_t r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
 }
 
 struct Grid {
@@ -634,7 +638,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
 }
 
-template <int AHEAD, typename G>
+template <typename G>
 __global__ void __launch_bounds__(PSDF_BLOCK)
     sphere_trace_step_b_kernel(G g, Occ o, const float* __restrict__ dirs, float* __restrict__ pts,
                                uint8_t* __restrict__ converged, const uint8_t* __restrict__ done_flag,
@@ -643,10 +647,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   const uint32_t* cm = stage_coarse(o, cm_lds);
   const int n = list_count[0];
   const int limit = (int)((double)g.n * sqrt(3.0)) + 1;
-  // A handful of rays, each a chain of a few hundred dependent steps: the launch lasts as long as ONE march (130 us), so
-  // what counts is the latency of a step.  Empty 8x8x8 blocks are answered by the LDS mask when there is one.  The walk
-  // does not depend on the probes until one of them hits, so it CAN run AHEAD steps ahead of them (the batch is examined in
-  // order, which keeps the result the one of the serial loop); AHEAD = 1 is what is launched, see the entry point.
+  // A handful of rays, each a chain of a few hundred dependent steps: the launch lasts as long as ONE march, so what counts
+  // is the latency of a step.  Empty 8x8x8 blocks are answered by the LDS mask when there is one (these ARE the long marches
+  // through empty space).  Walking 2 or 4 steps ahead of the probes measured 1-2 % slower: the arithmetic of a step, not
+  // the probe, is the latency that is left.
   for (int k0 = blockIdx.x * PSDF_BLOCK + threadIdx.x; k0 < n; k0 += gridDim.x * PSDF_BLOCK) {
     const int i = list[k0];
     const v3 dir = ld3(dirs + 3 * (int64_t)i);
@@ -654,59 +658,24 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const v3 idir = safe_inverse(dir);
     float t = 0.f;
     int steps = 0;
-    bool inside = true, found = false;
+    bool inside = true;
     v3 out = p;
-    while (inside && !found && steps < limit) {
-      v3 q[AHEAD];
-      int vox[AHEAD];
-#pragma unroll
-      for (int k = 0; k < AHEAD; k++) vox[k] = 0;
-      int m = 0;
-      bool left = false;
-      v3 q_left = p;
-#pragma unroll
-      for (int k = 0; k < AHEAD; k++) {
-        if (!left && m == k && steps + k < limit) {
-          const v3 qq = along(p, t, dir);
-          const int v = g.pos_to_idx(qq);
-          if (!g.in_range(v)) {
-            left = true;
-            q_left = qq;
-          } else {
-            const float d = dist_to_next_voxel(qq, dir, idir, g);
-            t += d;
-            t += DDA_EPS;
-            q[k] = qq;
-            vox[k] = v;
-            m = k + 1;
-          }
-        }
-      }
-      uint8_t byte[AHEAD];
-#pragma unroll
-      for (int k = 0; k < AHEAD; k++) {
-        bool maybe = k < m;
-        if (cm) {
-          const uint32_t c = (uint32_t)vox[k] >> COARSE_SHIFT;
-          maybe = maybe && ((cm[c >> 5] >> (c & 31u)) & 1u);
-        }
-        byte[k] = maybe ? o.bytes[vox[k]] : (uint8_t)0;
-      }
-#pragma unroll
-      for (int k = 0; k < AHEAD; k++) {
-        if (!found && k < m) {
-          if (byte[k]) {
-            found = true;
-            out = q[k];
-          } else {
-            steps++;
-          }
-        }
-      }
-      if (!found && left) {
+    while (inside && steps < limit) {
+      const v3 q = along(p, t, dir);
+      const int vox = g.pos_to_idx(q);
+      if (!g.in_range(vox)) {
         inside = false;
-        out = q_left;
+        out = q;
+        break;
       }
+      const float d = dist_to_next_voxel(q, dir, idir, g);
+      t += d;
+      t += DDA_EPS;
+      if (probe(o, cm, vox)) {
+        out = q;
+        break;
+      }
+      steps++;
     }
     st3(pts + 3 * (int64_t)i, out);
     converged[i] = done_flag[i] || !inside;
@@ -1215,14 +1184,13 @@ int psdf_sphere_trace_step_compacted(int count, int nr_voxels_per_dim, float ext
     hipLaunchKernelGGL(sphere_trace_step_a_kernel<Grid>, GRID1(count), count, g, oc, dirs, sdf, sdf_multiplier,
                        sdf_converged_thresh, pts, converged, work_flags, work_list, work_count);
   const int blocks = count < 512 * PSDF_BLOCK ? (count + PSDF_BLOCK - 1) / PSDF_BLOCK : 512;
-  // AHEAD = 1: walking ahead of the probes (2 or 4 steps) measured 1-2 % slower here, the arithmetic chain of a step is the
-  // latency that counts; the LDS mask is worth 6 % of the frame (8.11 -> 7.64 ms on the sphere-initialised field)
+  // the LDS mask is worth 6 % of the frame here (8.11 -> 7.64 ms on the sphere-initialised field)
   const size_t lds_b = ocb.coarse ? (size_t)ocb.words * 4 : 0;
   if (fast)
-    hipLaunchKernelGGL((sphere_trace_step_b_kernel<1, GridFast>), dim3(blocks), dim3(PSDF_BLOCK), lds_b, st, mk_fast(g), ocb, dirs,
+    hipLaunchKernelGGL((sphere_trace_step_b_kernel<GridFast>), dim3(blocks), dim3(PSDF_BLOCK), lds_b, st, mk_fast(g), ocb, dirs,
                        pts, converged, work_flags, work_list, work_count);
   else
-    hipLaunchKernelGGL((sphere_trace_step_b_kernel<1, Grid>), dim3(blocks), dim3(PSDF_BLOCK), lds_b, st, g, ocb, dirs, pts,
+    hipLaunchKernelGGL((sphere_trace_step_b_kernel<Grid>), dim3(blocks), dim3(PSDF_BLOCK), lds_b, st, g, ocb, dirs, pts,
                        converged, work_flags, work_list, work_count);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;

@@ -151,6 +151,12 @@ def test_grid_updates(port, dev):
 def test_check_occupancy_and_advance(port, world, dev):
     w = world
     pts = np.random.default_rng(5).uniform(-0.6, 0.6, (20000, 3)).astype(np.float32)   # includes out-of-grid points
+    # coordinates that exercise the float -> uint32 conversion of pos_to_idx (one saturating hardware instruction on the GPU,
+    # explicit compares in the oracle): NaN, infinities, values around 2^32 / n, negative zero, far outside either way
+    special = np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, 1e30, -1e30, 2.0 ** 32, 2.0 ** 31, 16777216.0, -16777216.0, 3.9, 4.1,
+                        1e-30, -1e-30, 0.49999997, 0.5, 0.50000006], dtype=np.float32)
+    sp = np.stack(np.meshgrid(special, special[:6], special[:4], indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    pts[:sp.shape[0]] = sp
     bits_equal(w["grid"].check_occupancy(T(pts, dev)), port.check_occupancy(*w["gridnp"][:3], w["occ"], pts))
     dirs = w["d"][:1000]
     start = np.clip(w["o"][:1000] + w["te"][:1000] * dirs, -0.49, 0.49).astype(np.float32)
