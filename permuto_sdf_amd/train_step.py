@@ -111,6 +111,36 @@ class _SumRay(torch.autograd.Function):  # volume_rendering_funcs.py:194-224
         return None, VolumeRendering.sum_over_each_ray_backward(g_ray.contiguous(), g_sample.contiguous(), ctx.rs, v)
 
 
+# ---- feature-major glue: the fused kernels read and write [C, N]; the reference's Python speaks [N, C]
+def cat_fm(parts):
+    """torch.cat(parts, 1) for [N, c_i] tensors, laid out FEATURE-MAJOR underneath (the result is the transposed view of a
+    contiguous [sum c_i, N] buffer): the fused MLPs consume it without the [N, C] -> [C, N] copy, and in the backward every
+    part receives a contiguous row block of the MLP's input gradient instead of a strided column slice that the next kernel
+    would have to copy."""
+    return torch.cat([p.t() for p in parts], 0).t()
+
+
+class _SplitHead(torch.autograd.Function):
+    """y [N, 1 + g] (a transposed view of the MLP's feature-major output) -> (y[:, :1], y[:, 1:]); the backward assembles the
+    gradient feature-major in ONE cat (autograd's slice backward: two zero fills, two strided copies, one add, and then the
+    MLP backward's own transposing copy)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        ctx.shape = y.shape
+        return y[:, 0:1], y[:, 1:]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        N, C = ctx.shape
+        ref = g0 if g0 is not None else g1
+        if g0 is None:
+            g0 = ref.new_zeros(N, 1)
+        if g1 is None:
+            g1 = ref.new_zeros(N, C - 1)
+        return torch.cat([g0.t(), g1.t()], 0).t()
+
+
 # --------------------------------------------------------------------------------------------------- networks
 def _lattice(pos_dim, points_scaling):
     return PermutoEncoding(pos_dim, 2 ** 18, 24, 2, np.geomspace(1.0, 1e-4, 24), appply_random_shift_per_level=True,
@@ -136,8 +166,7 @@ class SdfNet(torch.nn.Module):
         return self.c2f(map_range_val(it, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)).to(self.encoding.lattice_values.device)
 
     def forward(self, points, it):
-        y = self.mlp_sdf(self.encoding(points, self.window(it)))
-        return y[:, 0:1], y[:, 1:]
+        return _SplitHead.apply(self.mlp_sdf(self.encoding(points, self.window(it))))
 
     @torch.no_grad()
     def sdf_only(self, points, it):
@@ -186,7 +215,7 @@ class RgbNet(torch.nn.Module):
         win = self._win
         with torch.no_grad():
             sh = PermutoSDF.spherical_harmonics(dirs, 5)
-        x = torch.cat([self.encoding(points, win), sh, normalize3(sdf_gradients), geom_feat], 1)
+        x = cat_fm([self.encoding(points, win), sh, normalize3(sdf_gradients), geom_feat])
         return torch.sigmoid(self.mlp(x))
 
     def neus_weights(self, rs, sdf, gradients, cos_anneal_ratio, forced_variance):  # volume_rendering_modules.py:129-174
@@ -219,7 +248,7 @@ class BgNet(torch.nn.Module):
         with torch.no_grad():
             sh = PermutoSDF.spherical_harmonics(dirs, 4)
         fd = self.mlp_feat_and_density(self.encoding(pos4d, win))
-        rgb = self.mlp_rgb(torch.cat([F.gelu(fd[:, 1:65]), sh], 1))
+        rgb = self.mlp_rgb(cat_fm([F.gelu(fd[:, 1:65]), sh]))
         return torch.sigmoid(rgb), fd[:, 0:1]     # colour, RAW density: softplus (models.py:520) is fused into nerf_weights
 
     @staticmethod
