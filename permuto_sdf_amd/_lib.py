@@ -90,6 +90,20 @@ def zero_scalar(device):
     return z.detach()
 
 
+_int_pools = {}
+
+
+def zeroed_int(device):
+    """like zeroed_scalar, for [1] int32 counters (RaySamplesPacked.cur_nr_samples, compaction totals)"""
+    key = str(device)
+    pool = _int_pools.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _int_pools[key] = [torch.zeros(1024, dtype=torch.int32, device=device), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
+
+
 def zeroed_scalar(device):
     """A fresh [1] fp32 accumulator that is already zero (loss values and other wave-sum + atomic targets): slices of a
     pooled buffer, one fill per 1024 of them instead of one fill each."""

@@ -84,7 +84,7 @@ class RaySamplesPacked:
         if _alloc:
             M, R = self.max_nr_samples, self.m_nr_rays
             f = dict(dtype=torch.float32, device=dev)
-            self.cur_nr_samples = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.cur_nr_samples = L.zeroed_int(dev)      # a [1] int32 slice of a pooled, pre-zeroed buffer
             self.samples_pos = torch.empty((M, 3), **f)
             self.samples_pos_4d = torch.empty((M, 4), **f)
             self.samples_dirs = torch.empty((M, 3), **f)
@@ -145,7 +145,7 @@ class RaySamplesPacked:
         dev = self.samples_pos.device
         se = self.ray_start_end_idx.to(torch.int32).contiguous()
         scratch = torch.empty(2 * R, dtype=torch.int32, device=dev)
-        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        total = L.zeroed_int(dev)
         L.call("psdf_compact_offsets", L.c_i(R), L.ptr(se), L.ptr(scratch), L.ptr(total), L.stream())
         n = int(total.item())
         res = RaySamplesPacked(R, n, device=dev)
