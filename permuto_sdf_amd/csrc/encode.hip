@@ -12,6 +12,7 @@
 // Launch shape: grid (ceil(N/256), Lt), one thread per (point, level).  blockIdx.x is the fast dispatch
 // dimension, so the chip sweeps one level's 2-MiB table at a time and that table stays resident in every
 // XCD's 4-MiB L2 (the gathers are L2 hits, HBM sees positions + outputs only).
+#include <cstdlib>
 #include "encode_device.h"
 
 namespace {
@@ -893,6 +894,18 @@ int64_t psdf_encode_backward_workspace_bytes(int pos_dim, int nr_feat, int64_t N
 // grad_lattice / grad_positions must be zero-initialised by the caller (or hold a running sum to add to);
 // either may be NULL to skip that gradient.  workspace: device scratch of at least
 // psdf_encode_backward_workspace_bytes() bytes (contents undefined on entry and exit) or NULL.
+static int device_cus() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
                             const float* lattice, const float* scale_factor, const float* shifts, const float* window,
                             int concat_points, float points_scaling, const float* grad_sliced, float* grad_lattice,
@@ -909,7 +922,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   const bool use_queue = grad_lattice && workspace && queue_plan(pos_dim, nr_feat, N, nr_levels, capacity, Q, need) &&
                          workspace_bytes >= need;
   if (use_queue) {
-    grid.x = 128;  // each workgroup walks >= 16 super-tiles of 1024 points: the warm-up tile is a small share
+    grid.x = 128;  // provisional: BWD_PF sizes it to ONE resident round of workgroups (see there)
     queue_carve(workspace, nr_feat, nr_levels, Q);
     hipError_t e = hipMemsetAsync(Q.tails, 0, (size_t)nr_levels * Q.np * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
@@ -919,8 +932,29 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
                      (A_) ? ScatterCache<F_>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int) : 0, st, N, nr_levels,      \
                      (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling,        \
                      grad_sliced, grad_lattice, grad_positions, Q)
+// Queue mode: every workgroup of the launch resident at once and none left over.  The binning kernel is a long walk per
+// workgroup (LDS cache warm-up, then tens of super-tiles), so a second, partly filled round of workgroups is a tail the
+// size of a whole walk: measured on the bench batch (2 M points; 3 workgroups fit a CU, 768 in all) 16 levels x 48 = 768
+// workgroups 0.96 ms, x 40 1.09, x 56 1.26 (just over one round), x 96 (two rounds) 1.03, x 128 1.10; 24 levels x 32 best.
 #define BWD_PF(P_, F_)                                                                                           \
   do {                                                                                                           \
+    if (use_queue) {                                                                                             \
+      int per_cu = 0;                                                                                            \
+      const size_t shm = ScatterCache<F_>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                        \
+      const hipError_t eo =                                                                                      \
+          grad_positions ? hipOccupancyMaxActiveBlocksPerMultiprocessor(                                        \
+                               &per_cu, encode_bwd_kernel<P_, F_, true, true, true>, PSDF_BLOCK, shm)            \
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(                                        \
+                               &per_cu, encode_bwd_kernel<P_, F_, true, false, true>, PSDF_BLOCK, shm);          \
+      if (eo == hipSuccess && per_cu > 0) {                                                                      \
+        int64_t gx = (int64_t)per_cu * device_cus() / nr_levels;                                                 \
+        const int64_t super_tiles = (N + (int64_t)PSDF_BLOCK * 4 - 1) / ((int64_t)PSDF_BLOCK * 4);               \
+        if (gx > super_tiles) gx = super_tiles;                                                                  \
+        grid.x = (unsigned)(gx < 1 ? 1 : gx);                                                                    \
+      } else {                                                                                                   \
+        (void)hipGetLastError();                                                                                 \
+      }                                                                                                          \
+    }                                                                                                            \
     if (use_queue && grad_positions)                                                                             \
       BWD(P_, F_, true, true, true);                                                                             \
     else if (use_queue)                                                                                          \
