@@ -849,7 +849,12 @@ int psdf_encode_forward_masked(int pos_dim, int nr_feat, int64_t N, int nr_level
 static bool queue_plan(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, Queues& Q, int64_t& bytes) {
   bytes = 0;
   if (N < (int64_t)1 << 18) return false;  // below ~260k points the plain path is launch-bound anyway
-  const int shift = (nr_feat <= 2) ? 14 : (nr_feat <= 4 ? 13 : 12);   // rows/partition * F * 4 B <= 128 KiB
+  // rows per partition: the reduce kernel holds a partition's slice of the table in LDS.  64-KiB slices (two reduce
+  // workgroups per CU) instead of the 128 KiB that fit: the coarse levels' queues are nearly empty, so with one workgroup per
+  // (level, partition) and 16 partitions only half the CUs had work (16 levels: reduce + binning 0.966 -> 0.905 ms with 32).
+  const int base = (nr_feat <= 2) ? 14 : (nr_feat <= 4 ? 13 : 12);   // rows/partition * F * 4 B <= 128 KiB
+  int shift = base - 1;
+  if (((capacity + (1 << shift) - 1) >> shift) > Q_MAX_PARTS) shift = base;   // very large tables: keep the partition count
   const int rpp = 1 << shift;
   const int np = (capacity + rpp - 1) / rpp;
   if (np > Q_MAX_PARTS || rpp * nr_feat * 4 > 128 * 1024) return false;
