@@ -13,6 +13,7 @@
 // dimension, so the chip sweeps one level's 2-MiB table at a time and that table stays resident in every
 // XCD's 4-MiB L2 (the gathers are L2 hits, HBM sees positions + outputs only).
 #include <cstdlib>
+#include <cstdio>
 #include "encode_device.h"
 
 namespace {
@@ -360,6 +361,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
                       const float* __restrict__ grad_sliced, float* __restrict__ grad_lattice,
                       float* __restrict__ grad_positions, Queues Q) {
   extern __shared__ __align__(16) float lds[];
+#if defined(PSDF_ENC_PROFILE)
+  const long long psdf_prof_t0 = (long long)wall_clock64();
+#endif
   const int level = blockIdx.y;
   const int64_t ntiles = (N + PSDF_BLOCK - 1) / PSDF_BLOCK;
   if (level >= L) {
@@ -514,6 +518,15 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
   // (a cache that was switched off in queue mode has been drained and its LDS re-used: nothing to flush)
   if (LATTICE && !(QUEUE && !use_cache)) sc.flush(grad_lattice + tbase);
+#if defined(PSDF_ENC_PROFILE)
+  if (QUEUE && threadIdx.x == 0) {   // per-level duration of the workgroups (wall clock ticks), into the tail of the queue counters
+    const long long dt = (long long)wall_clock64() - psdf_prof_t0;
+    int* prof = Q.tails + L * Q.np;
+    atomicMax(&prof[level], (int)dt);
+    atomicAdd(&prof[64 + level], (int)(dt >> 6));
+    atomicAdd(&prof[128 + level], use_cache ? 1 : 0);
+  }
+#endif
 }
 
 // Position gradient ONLY (no lattice gradient: inference normals, sphere_trace.py; the reference gets them from
@@ -866,7 +879,7 @@ static bool queue_plan(int pos_dim, int nr_feat, int64_t N, int nr_levels, int c
   Q.shift = shift;
   const int64_t entries = (int64_t)nr_levels * np * cap;
   const int64_t rows_b = (entries * 2 + 255) & ~(int64_t)255, vals_b = (entries * nr_feat * 4 + 255) & ~(int64_t)255;
-  bytes = rows_b + vals_b + (((int64_t)nr_levels * np * 4 + 255) & ~(int64_t)255);
+  bytes = rows_b + vals_b + (((int64_t)nr_levels * np * 4 + 255) & ~(int64_t)255) + 1024;   // + profile slots (variant builds)
   return true;
 }
 static void queue_carve(void* ws, int nr_feat, int nr_levels, Queues& Q) {
@@ -929,7 +942,11 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   if (use_queue) {
     grid.x = 128;  // provisional: BWD_PF sizes it to ONE resident round of workgroups (see there)
     queue_carve(workspace, nr_feat, nr_levels, Q);
+#if defined(PSDF_ENC_PROFILE)
+    hipError_t e = hipMemsetAsync(Q.tails, 0, (size_t)nr_levels * Q.np * sizeof(int) + 1024, st);
+#else
     hipError_t e = hipMemsetAsync(Q.tails, 0, (size_t)nr_levels * Q.np * sizeof(int), st);
+#endif
     if (e != hipSuccess) return (int)e;
   }
 #define BWD(P_, F_, A_, B_, Q_)                                                                                  \
@@ -994,6 +1011,19 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     return PSDF_ERR_UNSUPPORTED;
 #undef BWD_PF
 #undef BWD
+#if defined(PSDF_ENC_PROFILE)
+  if (use_queue) {
+    static int calls = 0;
+    if (++calls == 8) {
+      (void)hipStreamSynchronize(st);
+      int prof[192];
+      (void)hipMemcpy(prof, Q.tails + nr_levels * Q.np, sizeof(prof), hipMemcpyDeviceToHost);
+      for (int l = 0; l < nr_levels; l++)
+        fprintf(stderr, "[enc-profile] level %2d: max %8d ticks, mean %8.0f ticks, cache kept by %d of %u workgroups\n", l, prof[l],
+                64.0 * prof[64 + l] / grid.x, prof[128 + l], grid.x);
+    }
+  }
+#endif
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
