@@ -81,6 +81,7 @@ class RaySamplesPacked:
         self.fixed_nr_of_samples_per_ray = 0
         self.has_sdf = False
         self._exact = False  # set by producers whose output is already hole-free and ray ordered
+        self._dense = False  # set by compaction: every slot of the sample tensors belongs to a ray (outputs need no zero fill)
         if _alloc:
             M, R = self.max_nr_samples, self.m_nr_rays
             f = dict(dtype=torch.float32, device=dev)
@@ -101,6 +102,7 @@ class RaySamplesPacked:
         Producers set `_exact = True` AFTER filling the container."""
         if name in ("ray_start_end_idx", "cur_nr_samples"):
             object.__setattr__(self, "_exact", False)
+            object.__setattr__(self, "_dense", False)
         object.__setattr__(self, name, value)
 
     # -- ray-index arguments shared by every per-ray kernel
@@ -141,6 +143,7 @@ class RaySamplesPacked:
                 out.ray_fixed_dt = torch.where(bad[:, None], torch.zeros_like(self.ray_fixed_dt), self.ray_fixed_dt)
             out.cur_nr_samples = torch.full((1,), n, dtype=torch.int32, device=self.samples_pos.device)
             out._exact = True
+            out._dense = cur <= self.max_nr_samples     # (an overflowing pool leaves slots of dropped rays behind)
             return out
         dev = self.samples_pos.device
         se = self.ray_start_end_idx.to(torch.int32).contiguous()
@@ -160,6 +163,7 @@ class RaySamplesPacked:
                L.ptr(res.ray_start_end_idx), L.stream())
         res.cur_nr_samples = total
         res._exact = True
+        res._dense = True
         return res
 
     def initialize_with_one_sample_per_ray(self, one_sample_per_ray, dirs):
@@ -481,6 +485,15 @@ class RaySampler:
         return rs
 
 
+def _per_sample(rs, shape, dev):
+    """Output tensor of a per-sample kernel: the kernels write every sample of every valid ray and nothing else, so a
+    container whose every slot belongs to a ray (`_dense`, set by compaction) needs no zero fill; pools with free slots
+    get the zeros the reference's torch::zeros gives them."""
+    if getattr(rs, "_dense", False):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    return torch.zeros(shape, dtype=torch.float32, device=dev)
+
+
 # ---------------------------------------------------------------------------------------------- compositing
 class VolumeRendering:
     _rng = Pcg32()
@@ -536,7 +549,7 @@ class VolumeRendering:
         rs = ray_samples_packed
         R, M, dev = rs.ray_start_end_idx.shape[0], rs.samples_z.shape[0], alpha_samples.device
         a = VolumeRendering._vals(alpha_samples, M, 1, "alpha_samples")
-        T = torch.zeros((M, 1), dtype=torch.float32, device=dev)
+        T = _per_sample(rs, (M, 1), dev)
         bg = torch.ones((R, 1), dtype=torch.float32, device=dev)
         L.call("psdf_cumprod_alpha2transmittance", *rs._ri(), L.ptr(a), L.ptr(T), L.ptr(bg), L.stream())
         return T, bg
@@ -555,7 +568,7 @@ class VolumeRendering:
     def sdf2alpha(ray_samples_packed, sdf_samples, inv_s, dynamic_inv_s, inv_s_multiplier):
         rs = ray_samples_packed
         M = rs.samples_z.shape[0]
-        alpha = torch.zeros((M, 1), dtype=torch.float32, device=sdf_samples.device)
+        alpha = torch.zeros((M, 1), dtype=torch.float32, device=sdf_samples.device)   # the last sample of a ray keeps alpha 0
         L.call("psdf_sdf2alpha", *rs._ri(), L.ptr(_f32c(rs.ray_fixed_dt)), L.ptr(_f32c(rs.samples_dt)),
                L.ptr(_f32c(sdf_samples)), L.c_f(float(inv_s)), L.c_i(int(dynamic_inv_s)), L.c_f(float(inv_s_multiplier)),
                L.ptr(alpha), L.stream())
@@ -570,7 +583,7 @@ class VolumeRendering:
         if not (C <= 3 or C == 32):
             raise ValueError("sample_values should have 1, 2, 3 or 32 channels, got %d" % C)
         s_ray = torch.zeros((R, C), dtype=torch.float32, device=v.device)
-        s_smp = torch.zeros((M, C), dtype=torch.float32, device=v.device)
+        s_smp = _per_sample(rs, (M, C), v.device)
         L.call("psdf_sum_over_each_ray", *rs._ri(), L.c_i(C), L.ptr(v), L.ptr(s_ray), L.ptr(s_smp), L.stream())
         return s_ray, s_smp
 
@@ -579,7 +592,7 @@ class VolumeRendering:
         rs = ray_samples_packed
         M = rs.samples_z.shape[0]
         v = VolumeRendering._vals(sample_values, M, 1, "sample_values")
-        out = torch.zeros((M, 1), dtype=torch.float32, device=v.device)
+        out = _per_sample(rs, (M, 1), v.device)
         L.call("psdf_cumsum_over_each_ray", *rs._ri(), L.ptr(v), L.c_i(int(inverse)), L.c_i(0), L.ptr(out), L.stream())
         return out
 
@@ -588,7 +601,7 @@ class VolumeRendering:
         rs = ray_samples_packed
         M = rs.samples_z.shape[0]
         w = VolumeRendering._vals(sample_weights, M, 1, "sample_weights")
-        out = torch.zeros((M, 1), dtype=torch.float32, device=w.device)
+        out = _per_sample(rs, (M, 1), w.device)
         L.call("psdf_cumsum_over_each_ray", *rs._ri(), L.ptr(w), L.c_i(0), L.c_i(1), L.ptr(out), L.stream())
         return out
 
@@ -642,7 +655,7 @@ class VolumeRendering:
         M = rs.samples_z.shape[0]
         if grad_transmittance.shape[0] != M:
             raise ValueError("grad_transmittance should have size nr_samples_total x 1")
-        g = torch.zeros((M, 1), dtype=torch.float32, device=alpha.device)
+        g = _per_sample(rs, (M, 1), alpha.device)
         L.call("psdf_cumprod_alpha2transmittance_backward", *rs._ri(), L.ptr(_f32c(grad_bg_transmittance)),
                L.ptr(_f32c(alpha)), L.ptr(_f32c(bg_transmittance)), L.ptr(_f32c(cumsumLV)), L.ptr(g), L.stream())
         return g
@@ -654,8 +667,8 @@ class VolumeRendering:
         if grad_pred_rgb.shape[0] != R or grad_pred_rgb.shape[1] != 3:
             raise ValueError("grad_pred_rgb should have size nr_rays x 3")
         dev = rgb_samples.device
-        g_rgb = torch.zeros((M, 3), dtype=torch.float32, device=dev)
-        g_w = torch.zeros((M, 1), dtype=torch.float32, device=dev)
+        g_rgb = _per_sample(rs, (M, 3), dev)
+        g_w = _per_sample(rs, (M, 1), dev)
         L.call("psdf_integrate_with_weights_backward", *rs._ri(), L.ptr(_f32c(grad_pred_rgb)), L.ptr(_f32c(rgb_samples)),
                L.ptr(_f32c(weights_samples)), L.ptr(g_rgb), L.ptr(g_w), L.c_i(int(VolumeRendering.reference_compat)),
                L.stream())
@@ -670,7 +683,7 @@ class VolumeRendering:
             raise ValueError("sum_over_each_ray_backward supports 1, 2 or 3 channels (reference: src/VolumeRendering.cu:621-663)")
         if grad_values_sum_per_ray.shape[0] != R or grad_values_sum_per_sample.shape[0] != M:
             raise ValueError("gradient shapes do not match the sample container")
-        g = torch.zeros((M, C), dtype=torch.float32, device=sample_values.device)
+        g = _per_sample(rs, (M, C), sample_values.device)
         L.call("psdf_sum_over_each_ray_backward", *rs._ri(), L.c_i(C), L.ptr(_f32c(grad_values_sum_per_ray)),
                L.ptr(_f32c(grad_values_sum_per_sample)), L.ptr(g), L.stream())
         return g
