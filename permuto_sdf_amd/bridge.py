@@ -489,7 +489,11 @@ def _per_sample(rs, shape, dev):
     """Output tensor of a per-sample kernel: the kernels write every sample of every valid ray and nothing else, so a
     container whose every slot belongs to a ray (`_dense`, set by compaction) needs no zero fill; pools with free slots
     get the zeros the reference's torch::zeros gives them."""
-    if getattr(rs, "_dense", False):
+    dense = getattr(rs, "_dense", False) or (
+        rs.rays_have_equal_nr_of_samples and
+        rs.fixed_nr_of_samples_per_ray * rs.ray_start_end_idx.shape[0] == shape[0] and
+        rs.max_nr_samples >= shape[0])   # equal-count mode: the implicit ranges tile the pool
+    if dense:
         return torch.empty(shape, dtype=torch.float32, device=dev)
     return torch.zeros(shape, dtype=torch.float32, device=dev)
 
