@@ -30,17 +30,20 @@ def port():
     return O.Oracle("port")
 
 
-@pytest.fixture(scope="module", params=[64, 256])
+# (n, extent, translation): the two unit grids take the kernels' compile-time specialised path (csrc/sampling.hip,
+# GridFast), the third one -- extent != 1, shifted -- the generic path with the reference's divisions
+@pytest.fixture(scope="module", params=[(64, 1.0, (0.0, 0.0, 0.0)), (256, 1.0, (0.0, 0.0, 0.0)), (64, 1.2, (0.04, -0.03, 0.02))],
+                ids=["n64", "n256", "n64-extent1.2-shifted"])
 def world(request, port, dev):
     from permuto_sdf import OccupancyGrid, Sphere
-    n = request.param
-    occ = scene.shell_occupancy(port, n)
+    n, extent, tr = request.param
+    occ = scene.shell_occupancy(port, n, extent, tr)
     o, d = scene.make_rays(2000, seed=3)
     sph = Sphere(0.5, [0, 0, 0])
-    grid = OccupancyGrid(n, 1.0, [0, 0, 0])
+    grid = OccupancyGrid(n, extent, list(tr))
     grid.set_grid_occupancy(T(occ, dev))
     _, te, _, tx, _ = port.sphere_intersect(0.5, [0, 0, 0], o, d)
-    return dict(n=n, occ=occ, gridnp=(n, 1.0, [0, 0, 0], occ), grid=grid, sphere=sph, o=o, d=d, te=te, tx=tx)
+    return dict(n=n, occ=occ, gridnp=(n, extent, list(tr), occ), grid=grid, sphere=sph, o=o, d=d, te=te, tx=tx)
 
 
 def test_sphere_intersection(port, dev):
