@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // switches the cache off for the rest of its walk (vote after its first tile: share of contributions that hit an
 // entry which already existed).
 constexpr uint32_t SC_EMPTY = 0xFFFFFFFFu;
+constexpr int QUEUE_SPT = 2;   // points per thread and super-tile in queue mode (see ScatterCache)
 
 // LDS float accumulation without ds_add_f32.  Measured on this chip (tools/atomic_bench.hip): a wave-wide ds_add_f32
 // costs ~197 cycles whatever the access pattern (1 lane per ~3 cycles), while INTEGER LDS atomics run at LDS speed
@@ -159,9 +160,14 @@ __device__ __forceinline__ bool combine_runs16(uint32_t key, bool valid, float (
   return valid && next_head != 0;
 }
 
-template <int F>
+// TOTAL = slots x F.  8192 (48 KiB for F = 2) where the cache is all there is between the contributions and global float
+// atomics (small batches); 4096 (24 KiB) in queue mode, where what the cache does not absorb goes to the queues anyway:
+// there the binning kernel was held at 3 waves per SIMD by both its LDS and its registers while it spent 48 % of its wave
+// cycles waiting (profiles/r02_pmc_sq_encode_bwd.txt) -- half the cache and 2 instead of 4 points per thread and super-tile
+// (half the per-thread contribution registers) let more waves in: binning + reduce 0.894 -> 0.828 ms on the bench batch.
+template <int F, int TOTAL = 8192>
 struct ScatterCache {
-  static constexpr int SC_SLOTS = 8192 / F;  // F=2: 16 KiB tags + 32 KiB sums
+  static constexpr int SC_SLOTS = TOTAL / F;  // F=2, TOTAL 8192: 16 KiB tags + 32 KiB sums
   uint32_t* tags;
   float* sums;
   int* stats;  // [0] = hits, [1] = tries, [2] = enabled
@@ -212,8 +218,8 @@ struct ScatterCache {
 // grad_lattice[l][row][f] += bary_r * w_l * g[l][f][n]            (LDS-privatised, then fp32 L2 atomics)
 // grad_pos[n][i]          += dL/dpos_i  (chain through barycentric -> elevated -> position)
 // Launch: grid (B, Lt), workgroup b of level l walks point tiles b, b+B, ...
-template <int F>
-__device__ __forceinline__ bool cache_vote(ScatterCache<F>& sc, int hits, int tries) {
+template <typename SC>
+__device__ __forceinline__ bool cache_vote(SC& sc, int hits, int tries) {
   // called by every thread of the workgroup after its first tile; returns the workgroup-uniform decision
   hits = (int)psdf::wave_sum((float)hits);
   tries = (int)psdf::wave_sum((float)tries);
@@ -334,10 +340,10 @@ __device__ __forceinline__ void queue_push_staged(const Queues& Q, int level, in
 
 // The scatter cache was switched off: hand its live entries to the queues too (instead of flushing them with one
 // global atomic each at the end) and empty it.
-template <int F>
-__device__ __forceinline__ void cache_drain_to_queue(ScatterCache<F>& sc, const Queues& Q, int level, int* q_cnt,
+template <int F, typename SC>
+__device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, int level, int* q_cnt,
                                                      int* q_base, float* __restrict__ table_grad) {
-  for (int base = 0; base < ScatterCache<F>::SC_SLOTS; base += PSDF_BLOCK) {
+  for (int base = 0; base < SC::SC_SLOTS; base += PSDF_BLOCK) {
     const int i = base + threadIdx.x;
     bool pending[1];
     uint32_t crow[1];
@@ -382,9 +388,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     }
     return;
   }
-  ScatterCache<F> sc;
+  using SCache = ScatterCache<F, QUEUE ? 4096 : 8192>;
+  SCache sc;
   if (LATTICE) sc.init(lds);
-  int* q_cnt = reinterpret_cast<int*>(lds + ScatterCache<F>::bytes() / 4);  // [Q_MAX_PARTS]
+  int* q_cnt = reinterpret_cast<int*>(lds + SCache::bytes() / 4);  // [Q_MAX_PARTS]
   int* q_base = q_cnt + Q_MAX_PARTS;                                          // [Q_MAX_PARTS]
   int* q_off = q_base + Q_MAX_PARTS;                                          // [Q_MAX_PARTS + 1]
   bool use_cache = LATTICE;
@@ -400,7 +407,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
   // In queue mode a thread handles SPT points per tile, so that one round of slot reservation (3 barriers and a
   // returning global atomic per partition) is amortised over SPT*256 points.
-  constexpr int SPT = QUEUE ? 4 : 1;
+  constexpr int SPT = QUEUE ? QUEUE_SPT : 1;
   constexpr int NC = SPT * (P + 1);
   const int64_t ntiles_w = (N + (int64_t)PSDF_BLOCK * SPT - 1) / ((int64_t)PSDF_BLOCK * SPT);
   for (int64_t tile = blockIdx.x; tile < ntiles_w; tile += gridDim.x, iter++) {
@@ -493,7 +500,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
         for (int c = 0; c < NC; c++) any |= pending[c];
         if (__syncthreads_or(any)) {
           // cache off (and drained): its LDS is the staging area of the coalesced hand-off
-          if constexpr (F == 2 && NC * PSDF_BLOCK * 3 * 4 <= ScatterCache<F>::SC_SLOTS * (1 + F) * 4) {
+          if constexpr (F == 2 && NC * PSDF_BLOCK * 3 * 4 <= SCache::SC_SLOTS * (1 + F) * 4) {
             if (!use_cache && iter > 0)
               queue_push_staged<NC>(Q, level, q_cnt, q_base, q_off, lds, pending, crow, cval, grad_lattice + tbase);
             else
@@ -512,7 +519,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       }
     }
     if (LATTICE && iter == 0) {
-      use_cache = cache_vote<F>(sc, hits, tries);  // re-use rate of the first tile
+      use_cache = cache_vote(sc, hits, tries);  // re-use rate of the first tile
       if (QUEUE && !use_cache) cache_drain_to_queue<F>(sc, Q, level, q_cnt, q_base, grad_lattice + tbase);
     }
   }
@@ -782,7 +789,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 #pragma unroll
       for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = gg[f];
     }
-    if (LATTICE && iter == 0) use_cache = cache_vote<F>(sc, hits, tries);  // re-use rate of the first tile
+    if (LATTICE && iter == 0) use_cache = cache_vote(sc, hits, tries);  // re-use rate of the first tile
   }
   if (LATTICE) sc.flush(grad_lattice + tbase);
 }
@@ -951,7 +958,8 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   }
 #define BWD(P_, F_, A_, B_, Q_)                                                                                  \
   hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, A_, B_, Q_>), grid, dim3(PSDF_BLOCK),                             \
-                     (A_) ? ScatterCache<F_>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int) : 0, st, N, nr_levels,      \
+                     ((A_) ? ScatterCache<F_, ((Q_) ? 4096 : 8192)>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int) : 0), st, N, \
+                     nr_levels,                                                                                    \
                      (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling,        \
                      grad_sliced, grad_lattice, grad_positions, Q)
 // Queue mode: every workgroup of the launch resident at once and none left over.  The binning kernel is a long walk per
@@ -962,7 +970,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   do {                                                                                                           \
     if (use_queue) {                                                                                             \
       int per_cu = 0;                                                                                            \
-      const size_t shm = ScatterCache<F_>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                        \
+      const size_t shm = ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                  \
       const hipError_t eo =                                                                                      \
           grad_positions ? hipOccupancyMaxActiveBlocksPerMultiprocessor(                                        \
                                &per_cu, encode_bwd_kernel<P_, F_, true, true, true>, PSDF_BLOCK, shm)            \
@@ -970,7 +978,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
                                &per_cu, encode_bwd_kernel<P_, F_, true, false, true>, PSDF_BLOCK, shm);          \
       if (eo == hipSuccess && per_cu > 0) {                                                                      \
         int64_t gx = (int64_t)per_cu * device_cus() / nr_levels;                                                 \
-        const int64_t super_tiles = (N + (int64_t)PSDF_BLOCK * 4 - 1) / ((int64_t)PSDF_BLOCK * 4);               \
+        const int64_t super_tiles = (N + (int64_t)PSDF_BLOCK * QUEUE_SPT - 1) / ((int64_t)PSDF_BLOCK * QUEUE_SPT); \
         if (gx > super_tiles) gx = super_tiles;                                                                  \
         grid.x = (unsigned)(gx < 1 ? 1 : gx);                                                                    \
       } else {                                                                                                   \
