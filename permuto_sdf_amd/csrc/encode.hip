@@ -359,8 +359,12 @@ __device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, in
   __syncthreads();
 }
 
+// Queue mode asks for 5 waves per SIMD: left alone the compiler takes 162 VGPRs (3 waves), told so it needs 96 without a
+// vector spill, and the kernel waits on LDS / gathers for half of its wave cycles (profiles/r02_pmc_sq_encode_bwd.txt), so the
+// extra residents pay: bench batch 0.835 -> 0.79 ms (4 waves: no change; 6 waves spill 13 VGPRs).  The 24-KiB cache of queue
+// mode lets 5 workgroups share a CU's LDS.  (P = 4 and F = 4 would spill a few VGPRs at 5 waves: they ask for 4.)
 template <int P, int F, bool LATTICE, bool POS, bool QUEUE>
-__global__ void __launch_bounds__(PSDF_BLOCK)
+__global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? 5 : 4) : 1)
     encode_bwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,

@@ -12,12 +12,16 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_bench -- python $R/bench
 cd $R
 python tools/rocpd_summary.py $O/prof_bench $O/bench_kernel_stats.txt > /dev/null 2>&1
 rm -rf $O/prof_bench
+# SHORT=1: only what an encode / MLP kernel change moves (bench line, its kernel trace, cfg 2 matrix, cfg 3, cfg 4)
+if [ -z "$SHORT" ]; then
 bash tools/pmc_hbm_traffic.sh r02 > $O/pmc_hbm.log 2>&1
 bash tools/pmc_sq.sh mlp_bwd_split_kernel mlpbwdsplit -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_sq_mlp_bwd_split.log 2>&1
+fi
 python tools/cfg2_matrix.py > $O/cfg2_matrix.jsonl 2> $O/cfg2_matrix.err
 python tools/cfg3_render.py > $O/cfg3.json 2> $O/cfg3.err
-python tools/sphere_trace_bench.py > $O/cfg5.json 2> $O/cfg5.err
 python tools/train_bench.py > $O/cfg4_final.json 2> $O/cfg4_final.err
+if [ -n "$SHORT" ]; then tail -c 600 $O/bench_final.json; echo; head -12 $O/bench_kernel_stats.txt | cut -c1-170; tail -3 $O/cfg2_matrix.jsonl | cut -c1-300; cat $O/cfg3.json $O/cfg4_final.json | cut -c1-400; exit 0; fi
+python tools/sphere_trace_bench.py > $O/cfg5.json 2> $O/cfg5.err
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_cfg4 -- python $R/tools/train_bench.py > $O/cfg4_under_rocprof.json 2> $O/cfg4_under_rocprof.err
 cd $R
