@@ -111,13 +111,15 @@ def test_lattice_grad_linearity_full_size(dev):
     assert (gl2 - 2 * gl).abs().max() <= 2e-5 * gl2.abs().max()      # atomic accumulation order differs run to run
 
 
-def test_binned_backward_equals_atomic_backward(dev):
+@pytest.mark.parametrize("P,F,L_,T", [(3, 2, 16, 2 ** 18), (4, 2, 8, 2 ** 16), (2, 2, 8, 2 ** 14), (3, 4, 8, 2 ** 16)])
+def test_binned_backward_equals_atomic_backward(dev, P, F, L_, T):
     """Large batches take the queue + LDS-reduction path (N >= 2^18); it must agree with the plain atomic path
-    (same kernels, workspace withheld) and with the oracle on a subset."""
+    (same kernels, workspace withheld) and with the oracle on a subset.  Every (pos_dim, features) instantiation: the
+    queue-mode kernels have their own LDS cache size and register budget."""
     from permuto_sdf_amd import _lib as L
     from permuto_sdf_amd.encoding import _head, _tail, encode_backward_raw
-    P, L_, T, N = 3, 16, 2 ** 18, 600_001
-    enc, sl, _, win = _make(P, L_, T, 2, 8, seed=44, concat=True)
+    N = 600_001
+    enc, sl, _, win = _make(P, L_, T, F, 8, seed=44, concat=True)
     enc = enc.to(dev)
     torch.manual_seed(1)
     pts = (torch.rand(N, P, device=dev) - 0.5)
