@@ -20,6 +20,10 @@ sites force (``permuto_sdf_py/models/models.py:143-149,186,408-420``) and freeze
   ``ceil(P/F)`` extra pseudo-levels, zero padded (so P=3,F=2 gives 4 extra channels, the last one 0) -- layout 1 --
   or as exactly P channels (SURVEY.md App. A.3 ``cat([sliced, scaling*points])``, 51 channels) -- layout 2.
 
+What is NOT convention -- which simplex encloses a point, which lattice points are its vertices, the interpolation weights --
+is checked against the definition of the lattice itself (vertices in A*_P, linear precision, Delaunay property by brute force,
+exact interpolation of affine functions): ``tests/test_oracle_lattice_geometry.py``.
+
 The VALUES of these conventions are not written in this file: they are parsed from the one header the HIP kernels
 include, ``permuto_sdf_amd/csrc/encode_conventions.h`` (a data file: nothing of the product is imported or executed),
 so that a change of convention there is followed by kernels, host code and oracle together
