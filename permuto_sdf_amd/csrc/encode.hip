@@ -52,8 +52,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   const float* __restrict__ table = lattice + (int64_t)level * capacity * F;
   // issue all P+1 gathers before consuming them (independent 8-B loads in flight)
   uint32_t row[P + 1];
-#pragma unroll
-  for (int r = 0; r <= P; r++) row[r] = vertex_row<P>(s, r, capacity);
+  vertex_rows<P>(s, capacity, row);
   // Training forward: remember which blocks of table rows this batch reads.  Every lattice-gradient contribution of the
   // backward / double backward at these positions lands on exactly these rows, so the optimiser can skip blocks whose
   // gradient and moments are still exactly zero (optim.hip: adamw_blocks_kernel) -- a superset is all it needs.
@@ -439,9 +438,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? 5 : 
         float dbary[P + 2];
 #pragma unroll
         for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
+        uint32_t rows[P + 1];
+        vertex_rows<P>(s, capacity, rows);
 #pragma unroll
         for (int r = 0; r <= P; r++) {
-          const uint32_t row = vertex_row<P>(s, r, capacity);
+          const uint32_t row = rows[r];
           if (LATTICE) {
             const int c = sp * (P + 1) + r;
             const float bw = s.bary[r] * w;
@@ -593,9 +594,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     float dbary[P + 2];
 #pragma unroll
     for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
+    uint32_t rows[P + 1];
+    vertex_rows<P>(s, capacity, rows);
 #pragma unroll
     for (int r = 0; r <= P; r++) {
-      const uint32_t row = vertex_row<P>(s, r, capacity);
+      const uint32_t row = rows[r];
 #pragma unroll
       for (int f = 0; f < F; f++) dbary[r] = dbary[r] + lattice[tbase + (int64_t)row * F + f] * w * g[f];
     }
@@ -767,9 +770,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
         g[f] = grad_sliced[((int64_t)level * F + f) * N + n];
         gg[f] = 0.f;
       }
+      uint32_t rows[P + 1];
+      vertex_rows<P>(s, capacity, rows);
 #pragma unroll
       for (int r = 0; r <= P; r++) {
-        const uint32_t row = vertex_row<P>(s, r, capacity);
+        const uint32_t row = rows[r];
         const float qw = q[r] * w;
         if (LATTICE) {
           float v[F];

@@ -62,15 +62,11 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
     }
   }
 #pragma unroll
-  for (int i = 0; i <= P; i++) {
-    s.rank[i] += sum;
-    if (s.rank[i] < 0) {
-      s.rank[i] += P + 1;
-      s.rem0[i] += P + 1;
-    } else if (s.rank[i] > P) {
-      s.rank[i] -= P + 1;
-      s.rem0[i] -= P + 1;
-    }
+  for (int i = 0; i <= P; i++) {   // wrap into 0..P; as selects: written as if / else-if the compiler emits a divergent branch per i
+    const int r = s.rank[i] + sum;
+    const int adj = (r < 0) ? (P + 1) : ((r > P) ? -(P + 1) : 0);
+    s.rank[i] = r + adj;
+    s.rem0[i] += adj;
   }
   // recompute d after the fix-up (rem0 may have moved by +-(P+1)); same expression as the oracle.
   // The oracle scatters: bary[P - rank_i] += delta_i; bary[P + 1 - rank_i] -= delta_i.  The ranks are a permutation,
@@ -117,6 +113,32 @@ __device__ __forceinline__ uint32_t vertex_row(const Simplex<P>& s, int remainde
   // `capacity` is wave-uniform (a kernel argument): a scalar branch instead of a ~35-instruction runtime modulo
   if ((capacity & (capacity - 1u)) == 0u) return h & (capacity - 1u);
   return h % capacity;
+}
+
+// All P+1 rows of a simplex: ONE wave-uniform branch on the kind of modulo instead of one per vertex.
+template <int P>
+__device__ __forceinline__ void vertex_rows(const Simplex<P>& s, uint32_t capacity, uint32_t (&rows)[P + 1]) {
+  uint32_t h0 = 0;
+#pragma unroll
+  for (int i = 0; i < P; i++) {
+    h0 += (uint32_t)s.rem0[i];
+    h0 *= HASH_C;
+  }
+#pragma unroll
+  for (int r = 0; r <= P; r++) {
+    uint32_t h = h0 + (uint32_t)r * hash_geom(P);
+#pragma unroll
+    for (int i = 0; i < P; i++)
+      if (s.rank[i] > P - r) h -= (uint32_t)(P + 1) * hash_pow(P - i);
+    rows[r] = h;
+  }
+  if ((capacity & (capacity - 1u)) == 0u) {
+#pragma unroll
+    for (int r = 0; r <= P; r++) rows[r] &= capacity - 1u;
+  } else {
+#pragma unroll
+    for (int r = 0; r <= P; r++) rows[r] %= capacity;
+  }
 }
 
 template <int P>

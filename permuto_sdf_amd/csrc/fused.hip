@@ -64,9 +64,11 @@ __device__ __forceinline__ void level_issue(const EncArgs& e, const float (&pos)
   Simplex<3> s;
   compute_simplex<3>(pos, sh, sf, s);
   const float* __restrict__ table = e.lattice + (int64_t)lvc * e.capacity * 2;
+  uint32_t rows[4];
+  vertex_rows<3>(s, e.capacity, rows);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const uint32_t row = vertex_row<3>(s, r, e.capacity);
+    const uint32_t row = rows[r];
     ld.v[r] = *reinterpret_cast<const float2*>(table + (int64_t)row * 2);
     ld.bw[r] = s.bary[r] * w;
   }
