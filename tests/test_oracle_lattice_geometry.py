@@ -139,3 +139,16 @@ def test_affine_functions_are_interpolated_exactly(P):
     E = _elevate(x.astype(np.float64))
     want = E @ a.T + b
     assert np.abs(out - want).max() < 5e-5 * max(1.0, np.abs(want).max())
+    # ... and the oracle's gradient with respect to the positions (torch autograd through the barycentric weights: the oracle of
+    # the HIP position-backward / double-backward kernels) is the analytic slope of that affine function: sf_j * (B^T a)_j
+    B = np.zeros((P + 1, P))
+    B[0, :] = 1.0
+    for i in range(1, P + 1):
+        B[i, i - 1] = -float(i)
+        B[i, i:] = 1.0
+    for f in range(2):
+        q = pts.clone().requires_grad_(True)
+        po.encode(q, torch.from_numpy(lat), sl, sh[:1], torch.ones(1))[:, f].sum().backward()
+        slope = (B.T @ a[f]) * sf[0].numpy().astype(np.float64)
+        got = q.grad.numpy().astype(np.float64)
+        assert np.abs(got - slope[None, :]).max() < 2e-4 * np.abs(slope).max()
