@@ -975,6 +975,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
 // workgroup (LDS cache warm-up, then tens of super-tiles), so a second, partly filled round of workgroups is a tail the
 // size of a whole walk: measured on the bench batch (2 M points; 3 workgroups fit a CU, 768 in all) 16 levels x 48 = 768
 // workgroups 0.96 ms, x 40 1.09, x 56 1.26 (just over one round), x 96 (two rounds) 1.03, x 128 1.10; 24 levels x 32 best.
+// (Those figures are from the 3-workgroups-per-CU state of the kernel; 5 fit now -- 80 per level at 16 levels -- by the same rule.)
 #define BWD_PF(P_, F_)                                                                                           \
   do {                                                                                                           \
     if (use_queue) {                                                                                             \
