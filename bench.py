@@ -122,8 +122,9 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: 200 steps of ~3 ms keep the GPU busy for ~0.6 s, long enough for an outside sampler (rocm-smi) to see the load
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra 24-level row (profiling runs: one kernel variant per name)")
     args = ap.parse_args()
