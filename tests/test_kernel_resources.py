@@ -1,0 +1,77 @@
+"""CPU guard on the register budgets the measured numbers rest on (no GPU: reads the gfx950 code objects hipcc produced).
+
+The kernels below were tuned to a residency; a source or compiler change that silently pushes one of them over its budget
+(spills, one wave less per SIMD) would cost tens of percent on the GPU and nothing would fail.  The limits are the ones
+DESIGN.md section 4 states."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernels(obj, tmp):
+    """{mangled name: {field: int}} of the gfx950 code object embedded in an object file"""
+    fat = os.path.join(tmp, "x.fatbin")
+    co = os.path.join(tmp, "x.co")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj, os.devnull])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co])
+    notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+    out = {}
+    for block in re.split(r"\n  - \.", notes):          # kernel entries sit at indentation 2 (their argument lists deeper)
+        name = re.search(r"\.name:\s+(\S+)", block)
+        if not name:
+            continue
+        out[name.group(1)] = {k: int(v) for k, v in re.findall(r"\.?(\w+):\s+(\d+)\s*$", block, flags=re.M)}
+    return out    # (.vgpr_count is the unified total on gfx950: architected VGPRs + AGPRs)
+
+
+@pytest.fixture(scope="module")
+def objdir():
+    from permuto_sdf_amd import build
+    build.build(verbose=False)
+    for tool in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"):
+        if not os.path.exists(os.path.join(LLVM, tool)):
+            pytest.skip("ROCm LLVM tools not found")
+    return build.OBJDIR
+
+
+def _one(kernels, pattern):
+    hits = [v for k, v in kernels.items() if re.search(pattern, k)]
+    assert len(hits) == 1, (pattern, [k for k in kernels if re.search(pattern, k)])
+    return hits[0]
+
+
+def test_encode_kernels_keep_their_residency(objdir, tmp_path):
+    k = _kernels(os.path.join(objdir, "encode.o"), str(tmp_path))
+    fwd = _one(k, r"encode_fwd_kernelILi3ELi2E")
+    assert fwd["vgpr_count"] <= 64 and fwd["vgpr_spill_count"] == 0 and fwd["private_segment_fixed_size"] == 0   # 8 waves / SIMD
+    # queue-mode binning kernels of the SDF lattice (pos_dim 3, 2 features): 5 waves per SIMD = at most 96 registers, no spill
+    for pat in (r"encode_bwd_kernelILi3ELi2ELb1ELb0ELb1E", r"encode_bwd_kernelILi3ELi2ELb1ELb1ELb1E"):
+        b = _one(k, pat)
+        assert b["vgpr_count"] <= 96, b
+        assert b["vgpr_spill_count"] == 0, b
+    # the other instantiations ask for 4 waves (128 registers)
+    for pat in (r"encode_bwd_kernelILi4ELi2ELb1ELb0ELb1E", r"encode_bwd_kernelILi3ELi4ELb1ELb0ELb1E"):
+        b = _one(k, pat)
+        assert b["vgpr_count"] <= 128 and b["vgpr_spill_count"] == 0, b
+    red = _one(k, r"encode_bwd_reduce_kernelILi2E")
+    assert red["vgpr_count"] <= 64 and red["vgpr_spill_count"] == 0
+
+
+def test_split_bf16_backward_of_the_baseline_net_does_not_spill(objdir, tmp_path):
+    """One wave per SIMD by design (176 persistent accumulators): the whole 512-register file, but nothing in scratch."""
+    k = _kernels(os.path.join(objdir, "mlp_bwd_split_double.o"), str(tmp_path))
+    b = _one(k, r"mlp_bwd_split_kernelILi3ELb1E")
+    assert b["vgpr_count"] <= 512 and b["agpr_count"] >= 176        # the persistent dW accumulators live in AGPRs
+    assert b["vgpr_spill_count"] == 0 and b["private_segment_fixed_size"] == 0, b
+
+
+def test_split_bf16_forward_fits_two_workgroups_per_cu(objdir, tmp_path):
+    k = _kernels(os.path.join(objdir, "mlp.o"), str(tmp_path))
+    f = _one(k, r"mlp_fwd_split_kernelILi2ELi2ELi2ELi1ELb1ELi3E")           # 36 -> 64 x 3 -> 1, the bench net
+    assert f["vgpr_count"] <= 128 and f["vgpr_spill_count"] == 0, f
