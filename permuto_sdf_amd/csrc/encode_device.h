@@ -98,24 +98,8 @@ constexpr uint32_t HASH_C = (uint32_t)PSDF_ENC_HASH_MULTIPLIER;   // encode_conv
 constexpr uint32_t hash_pow(int e) { return e == 0 ? 1u : HASH_C * hash_pow(e - 1); }
 constexpr uint32_t hash_geom(int P) { return P == 0 ? 0u : hash_pow(P) + hash_geom(P - 1); }
 
-template <int P>
-__device__ __forceinline__ uint32_t vertex_row(const Simplex<P>& s, int remainder, uint32_t capacity) {
-  uint32_t h = 0;
-#pragma unroll
-  for (int i = 0; i < P; i++) {   // H0; common to the P+1 vertices: the compiler keeps one copy after inlining
-    h += (uint32_t)s.rem0[i];
-    h *= HASH_C;
-  }
-  h += (uint32_t)remainder * hash_geom(P);
-#pragma unroll
-  for (int i = 0; i < P; i++)
-    if (s.rank[i] > P - remainder) h -= (uint32_t)(P + 1) * hash_pow(P - i);
-  // `capacity` is wave-uniform (a kernel argument): a scalar branch instead of a ~35-instruction runtime modulo
-  if ((capacity & (capacity - 1u)) == 0u) return h & (capacity - 1u);
-  return h % capacity;
-}
-
-// All P+1 rows of a simplex: ONE wave-uniform branch on the kind of modulo instead of one per vertex.
+// All P+1 rows of a simplex.  `capacity` is wave-uniform (a kernel argument): ONE scalar branch on the kind of modulo for all
+// vertices (a power of two is a mask; the general case a ~35-instruction runtime modulo per vertex).
 template <int P>
 __device__ __forceinline__ void vertex_rows(const Simplex<P>& s, uint32_t capacity, uint32_t (&rows)[P + 1]) {
   uint32_t h0 = 0;
