@@ -27,9 +27,14 @@ extern "C" {
    permuto_sdf_amd/csrc/encode_conventions.h; `concat_points` below is one of PSDF_ENC_CONCAT_NONE (0),
    PSDF_ENC_CONCAT_PSEUDO_LEVELS (1: F*(L + ceil(P/F)) channels, zero padded) or PSDF_ENC_CONCAT_APPEND (2: F*L + P channels,
    `cat([sliced, scaling * points])`, what permuto_sdf_py/models/models.py:149,154 consumes through output_dims()).
-   psdf_encode_convention(i) returns the compiled-in value of convention i (0 hash multiplier, 1 rank tie rule, 2 sqrt term
-   of scale_factor, 3 inverse-std-dev term, 4 default concatenation layout); host only. */
+   psdf_encode_convention(i) returns the value IN FORCE of convention i (0 hash multiplier, 1 rank tie rule -- the two that
+   live in device code, runtime values -- 2 sqrt term of scale_factor, 3 inverse-std-dev term, 4 default concatenation layout --
+   host-side defaults: `scale_factor` and `concat_points` are arguments of every entry point); host only.
+   psdf_encode_set_conventions() replaces the two device-side ones for the process (kernel arguments from then on), so that
+   matching an upstream build that disagrees with the recollection is a flag flip, not a rebuild (INTEGRATION.md,
+   tools/dump_upstream_encoding_vectors.py, tests/test_upstream_vectors.py).  No reference counterpart. */
 int64_t psdf_encode_convention(int which);
+int psdf_encode_set_conventions(uint32_t hash_multiplier, int rank_tie_raises_later);
 
 /* replaces: permutohedral_encoding CUDA op `forward_gpu` (un-vendored; call sites permuto_sdf_py/models/models.py:186,370,500,542) */
 int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
@@ -60,6 +65,15 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     positions, const float* lattice, const float* scale_factor, const float* shifts, const float* window, int
     concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced, float* grad_lattice,
     float* grad_grad_sliced, void* stream);
+
+/* ---- debug query (mlp_bwd.hip) ---- */
+/* Which kernel variant the LAST call of an operator family dispatched to (host only, no device work): lets a parity test
+   assert that the configuration it compares with the oracle ran the kernels the benchmark times.  No reference counterpart.
+     family 0 encode backward: 1 LDS scatter cache + atomics, 2 queue mode (binning + encode_bwd_reduce_kernel), 3 positions only
+     family 1 MLP backward   : 1 fp32-MFMA kernel, 2 split-operand kernel (mlp_bwd_split.hip), 3 wide workgroup kernel
+     family 2 MLP forward    : 1 fp32-MFMA kernel, 2 split-operand kernel
+   0 = no call yet, -1 = unknown family. */
+int psdf_last_path(int family);
 
 /* ---- mlp_bwd_split.hip ---- */
 /* same contract as psdf_mlp_backward for dims = {K0 <= 52, 64, 64, 64, 1} with dW/db requested, computed on the bf16 matrix

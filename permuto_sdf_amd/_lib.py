@@ -95,6 +95,8 @@ _int_pools = {}
 
 def zeroed_int(device):
     """like zeroed_scalar, for [1] int32 counters (RaySamplesPacked.cur_nr_samples, compaction totals)"""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(1, dtype=torch.int32, device=device)
     key = str(device)
     pool = _int_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():
@@ -107,6 +109,10 @@ def zeroed_int(device):
 def zeroed_scalar(device):
     """A fresh [1] fp32 accumulator that is already zero (loss values and other wave-sum + atomic targets): slices of a
     pooled buffer, one fill per 1024 of them instead of one fill each."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a graph capture the zero must be a node of the graph (a memset replayed every time), not a fill that happened
+        # once outside it: kernels atomicAdd into these accumulators
+        return torch.zeros(1, dtype=torch.float32, device=device)
     key = str(device)
     pool = _scalar_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():

@@ -48,3 +48,56 @@ def channels(pos_dim, nr_levels, nr_feat, mode):
     if mode == CONCAT_APPEND:
         return nr_feat * nr_levels + pos_dim
     return nr_feat * nr_levels
+
+
+# ---- runtime override (a flag flip, not a rebuild) --------------------------------------------------------------------
+# The header holds the DEFAULTS.  Someone who has the upstream CUDA package and finds a disagreement
+# (tools/dump_upstream_encoding_vectors.py -> tests/test_upstream_vectors.py names the combination that matches) flips the
+# convention for the process, either in code -- conventions.set(rank_tie_raises_later=0) -- or from the environment:
+#   PSDF_ENC_CONVENTIONS="RANK_TIE_RAISES_LATER=0,SCALE_INV_STDDEV=1,HASH_MULTIPLIER=2654435761"
+# Device-side conventions (hash multiplier, tie rule) are pushed into the library (psdf_encode_set_conventions, kernel
+# arguments from then on); host-side ones (scale_factor formula, default concatenation layout, initialisation scales) take
+# effect for every PermutoEncoding constructed afterwards.
+_KEYS = {"hash_multiplier": "PSDF_ENC_HASH_MULTIPLIER", "rank_tie_raises_later": "PSDF_ENC_RANK_TIE_RAISES_LATER",
+         "scale_sqrt_term": "PSDF_ENC_SCALE_SQRT_TERM", "scale_inv_stddev": "PSDF_ENC_SCALE_INV_STDDEV",
+         "concat_default_layout": "PSDF_ENC_CONCAT_DEFAULT_LAYOUT", "lattice_init_scale": "PSDF_ENC_LATTICE_INIT_SCALE",
+         "random_shift_scale": "PSDF_ENC_RANDOM_SHIFT_SCALE"}
+DEFAULTS = dict(C)
+
+
+def set(push_to_library=True, **kw):   # noqa: A001  (deliberately the obvious name: conventions.set(...))
+    """conventions.set(hash_multiplier=..., rank_tie_raises_later=0|1, scale_sqrt_term=0|1, scale_inv_stddev=0|1,
+    concat_default_layout=1|2, lattice_init_scale=..., random_shift_scale=...) -> dict of the values now in force"""
+    for k, v in kw.items():
+        name = _KEYS.get(k.lower(), k if k in C else "PSDF_ENC_" + k.upper())
+        if name not in C:
+            raise KeyError("unknown encoding convention %r (known: %s)" % (k, ", ".join(sorted(_KEYS))))
+        C[name] = type(DEFAULTS[name])(v)
+    if push_to_library:
+        import ctypes
+        from . import _lib as L
+        fn = L.lib().psdf_encode_set_conventions
+        fn.restype = ctypes.c_int
+        L.check(fn(ctypes.c_uint32(int(C["PSDF_ENC_HASH_MULTIPLIER"]) & 0xFFFFFFFF),
+                   ctypes.c_int(int(C["PSDF_ENC_RANK_TIE_RAISES_LATER"]))), "psdf_encode_set_conventions")
+    return dict(C)
+
+
+def reset(push_to_library=True):
+    C.update(DEFAULTS)
+    return set(push_to_library=push_to_library)
+
+
+def _from_env():
+    import os
+    spec = os.environ.get("PSDF_ENC_CONVENTIONS", "").strip()
+    if not spec:
+        return
+    kw = {}
+    for item in spec.split(","):
+        k, _, v = item.partition("=")
+        kw[k.strip()] = float(v) if any(ch in v for ch in ".eE") else int(v, 0)
+    set(**kw)
+
+
+_from_env()

@@ -21,7 +21,7 @@ namespace {
 // ------------------------------------------------------------------------------------------ forward
 template <int P, int F>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    encode_fwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
+    encode_fwd_kernel(int64_t N, int L, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                       int pad_points, const unsigned char* __restrict__ skip, float* __restrict__ sliced,
@@ -47,12 +47,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     return;
   }
   Simplex<P> s;
-  compute_simplex<P>(pos, shifts + level * P, scale_factor + level * P, s);
+  compute_simplex<P>(pos, shifts + level * P, scale_factor + level * P, s, conv.tie_later);
   const float w = window[level];
   const float* __restrict__ table = lattice + (int64_t)level * capacity * F;
   // issue all P+1 gathers before consuming them (independent 8-B loads in flight)
   uint32_t row[P + 1];
-  vertex_rows<P>(s, capacity, row);
+  vertex_rows<P>(s, capacity, row, conv.hash_c);
   // Training forward: remember which blocks of table rows this batch reads.  Every lattice-gradient contribution of the
   // backward / double backward at these positions lands on exactly these rows, so the optimiser can skip blocks whose
   // gradient and moments are still exactly zero (optim.hip: adamw_blocks_kernel) -- a superset is all it needs.
@@ -364,7 +364,7 @@ __device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, in
 // mode lets 5 workgroups share a CU's LDS.  (P = 4 and F = 4 would spill a few VGPRs at 5 waves: they ask for 4.)
 template <int P, int F, bool LATTICE, bool POS, bool QUEUE>
 __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? 5 : 4) : 1)
-    encode_bwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
+    encode_bwd_kernel(int64_t N, int L, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                       const float* __restrict__ grad_sliced, float* __restrict__ grad_lattice,
@@ -434,12 +434,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? 5 : 
         float pos[P];
         load_pos<P>(positions, n, pos);
         Simplex<P> s;
-        compute_simplex<P>(pos, shl, sfl, s);
+        compute_simplex<P>(pos, shl, sfl, s, conv.tie_later);
         float dbary[P + 2];
 #pragma unroll
         for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
         uint32_t rows[P + 1];
-        vertex_rows<P>(s, capacity, rows);
+        vertex_rows<P>(s, capacity, rows, conv.hash_c);
 #pragma unroll
         for (int r = 0; r <= P; r++) {
           const uint32_t row = rows[r];
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? 5 : 
 constexpr int POS_LPB = 4;
 template <int P, int F>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, const float* __restrict__ positions,
+    encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                           const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                           const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                           int pad_points, const float* __restrict__ grad_sliced, const unsigned char* __restrict__ skip,
@@ -590,12 +590,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     const float w = window[level];
     const int64_t tbase = (int64_t)level * capacity * F;
     Simplex<P> s;
-    compute_simplex<P>(pos, shl, sfl, s);
+    compute_simplex<P>(pos, shl, sfl, s, conv.tie_later);
     float dbary[P + 2];
 #pragma unroll
     for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
     uint32_t rows[P + 1];
-    vertex_rows<P>(s, capacity, rows);
+    vertex_rows<P>(s, capacity, rows, conv.hash_c);
 #pragma unroll
     for (int r = 0; r <= P; r++) {
       const uint32_t row = rows[r];
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(1024)
 // and for the concatenated-point channels grad_g = u_d * points_scaling.
 template <int P, int F, bool LATTICE>
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    encode_dbl_bwd_kernel(int64_t N, int L, uint32_t capacity, const float* __restrict__ positions,
+    encode_dbl_bwd_kernel(int64_t N, int L, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                           const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                           const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                           int pad_points, const float* __restrict__ dd_positions, const float* __restrict__ grad_sliced,
@@ -737,7 +737,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       load_pos<P>(dd_positions, n, u);
       load_pos<P>(positions, n, pos);
       Simplex<P> s;
-      compute_simplex<P>(pos, shl, sfl, s);
+      compute_simplex<P>(pos, shl, sfl, s, conv.tie_later);
       // adjoint of pos -> elevated
       float aE[P + 1];
 #pragma unroll
@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
         gg[f] = 0.f;
       }
       uint32_t rows[P + 1];
-      vertex_rows<P>(s, capacity, rows);
+      vertex_rows<P>(s, capacity, rows, conv.hash_c);
 #pragma unroll
       for (int r = 0; r <= P; r++) {
         const uint32_t row = rows[r];
@@ -811,20 +811,37 @@ inline bool concat_ok(int concat) { return concat >= PSDF_ENC_CONCAT_NONE && con
 
 }  // namespace
 
+namespace psdf {
+EncConv& enc_conv_state() {
+  static EncConv c{(uint32_t)PSDF_ENC_HASH_MULTIPLIER, (uint32_t)PSDF_ENC_RANK_TIE_RAISES_LATER};
+  return c;
+}
+}  // namespace psdf
+
 // ================================================================================== C ABI
 extern "C" {
 
-// The conventions this library was COMPILED with (encode_conventions.h), by index: 0 hash multiplier, 1 rank tie rule,
-// 2 sqrt term in scale_factor, 3 inverse-std-dev term, 4 default concatenation layout.  Host only (no device needed).
+// The conventions in force, by index: 0 hash multiplier, 1 rank tie rule (both RUNTIME values: the defaults of
+// encode_conventions.h until psdf_encode_set_conventions() replaces them), 2 sqrt term in scale_factor, 3 inverse-std-dev
+// term, 4 default concatenation layout (host-side conventions: scale_factor and the layout are ARGUMENTS of every entry point,
+// the values here are the defaults the Python mirror and the oracle read).  Host only (no device needed).
 int64_t psdf_encode_convention(int which) {
   switch (which) {
-    case 0: return (int64_t)PSDF_ENC_HASH_MULTIPLIER;
-    case 1: return PSDF_ENC_RANK_TIE_RAISES_LATER;
+    case 0: return (int64_t)psdf::enc_conv_state().hash_c;
+    case 1: return (int64_t)psdf::enc_conv_state().tie_later;
     case 2: return PSDF_ENC_SCALE_SQRT_TERM;
     case 3: return PSDF_ENC_SCALE_INV_STDDEV;
     case 4: return PSDF_ENC_CONCAT_DEFAULT_LAYOUT;
     default: return -1;
   }
+}
+
+// Replace the two device-side conventions for this process (every later launch uses them): hash multiplier (any odd or even
+// 32-bit value; 0 is rejected) and the rank tie rule (0 / 1).  Not thread-safe against concurrent launches.
+int psdf_encode_set_conventions(uint32_t hash_multiplier, int rank_tie_raises_later) {
+  if (hash_multiplier == 0u || (rank_tie_raises_later != 0 && rank_tie_raises_later != 1)) return PSDF_ERR_ARG;
+  psdf::enc_conv_state() = EncConv{hash_multiplier, (uint32_t)rank_tie_raises_later};
+  return PSDF_OK;
 }
 
 static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
@@ -838,7 +855,7 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);
 #define FWD(P_, F_)                                                                                            \
-  hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, \
+  hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, psdf::enc_conv_state(), \
                      positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced,  \
                      touched, touch_shift, (capacity + (1 << touch_shift) - 1) >> touch_shift)
   if (pos_dim == 3 && nr_feat == 2)
@@ -969,7 +986,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, A_, B_, Q_>), grid, dim3(PSDF_BLOCK),                             \
                      ((A_) ? ScatterCache<F_, ((Q_) ? 4096 : 8192)>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int) : 0), st, N, \
                      nr_levels,                                                                                    \
-                     (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling,        \
+                     (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, points_scaling,        \
                      grad_sliced, grad_lattice, grad_positions, Q)
 // Queue mode: every workgroup of the launch resident at once and none left over.  The binning kernel is a long walk per
 // workgroup (LDS cache warm-up, then tens of super-tiles), so a second, partly filled round of workgroups is a tail the
@@ -1005,7 +1022,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
       BWD(P_, F_, true, false, false);                                                                           \
     else                                                                                                         \
       hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, \
-                         st, N, nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, \
+                         st, N, nr_levels, Lt, (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, \
                          points_scaling, pad_points(concat_points), grad_sliced, (const unsigned char*)nullptr,  \
                          grad_positions);                                                                          \
     if (use_queue) {                                                                                             \
@@ -1029,6 +1046,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     return PSDF_ERR_UNSUPPORTED;
 #undef BWD_PF
 #undef BWD
+  psdf::g_last_path[psdf::PATH_ENCODE_BWD] = use_queue ? 2 : (grad_lattice ? 1 : 3);
 #if defined(PSDF_ENC_PROFILE)
   if (use_queue) {
     static int calls = 0;
@@ -1071,7 +1089,7 @@ int psdf_encode_backward_positions_masked(int pos_dim, int nr_feat, int64_t N, i
   const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
 #define POS(P_, F_)                                                                                                  \
   hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, st, N,   \
-                     nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling, \
+                     nr_levels, Lt, (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, points_scaling, \
                      pad_points(concat_points), grad_sliced, skip, grad_positions)
   if (pos_dim == 3 && nr_feat == 2)
     POS(3, 2);
@@ -1106,12 +1124,12 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
   do {                                                                                                           \
     if (grad_lattice)                                                                                            \
       hipLaunchKernelGGL((encode_dbl_bwd_kernel<P_, F_, true>), grid, dim3(PSDF_BLOCK), ScatterCache<F_>::bytes(), \
-                         st, N, nr_levels, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window,   \
+                         st, N, nr_levels, (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,   \
                          points_scaling, pad_points(concat_points), dd_positions, grad_sliced, grad_lattice,       \
                          grad_grad_sliced);                                                                        \
     else                                                                                                         \
       hipLaunchKernelGGL((encode_dbl_bwd_kernel<P_, F_, false>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels,      \
-                         (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling,     \
+                         (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, points_scaling,     \
                          pad_points(concat_points), dd_positions, grad_sliced, grad_lattice, grad_grad_sliced);    \
   } while (0)
   if (pos_dim == 3 && nr_feat == 2)

@@ -4,6 +4,17 @@
 #include "encode_conventions.h"
 #include "psdf_common.h"
 
+// The two conventions that live in device code (encode_conventions.h) as RUNTIME values: a kernel argument, wave-uniform.
+// Defaults are the #defines; psdf_encode_set_conventions() (C ABI) replaces them for the process, so that matching an upstream
+// build that disagrees is a flag flip and not a rebuild.
+struct EncConv {
+  uint32_t hash_c;      // PSDF_ENC_HASH_MULTIPLIER
+  uint32_t tie_later;   // PSDF_ENC_RANK_TIE_RAISES_LATER
+};
+namespace psdf {
+EncConv& enc_conv_state();   // defined in encode.hip (host)
+}
+
 namespace {
 
 template <int P>
@@ -17,7 +28,7 @@ struct Simplex {
 // array index is a compile-time constant after unrolling (runtime-indexed arrays would go to scratch).
 template <int P>
 __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, const float* __restrict__ shift,
-                                                const float* __restrict__ sf, Simplex<P>& s) {
+                                                const float* __restrict__ sf, Simplex<P>& s, uint32_t tie_later) {
   float E[P + 1];
   float sm = 0.f;
 #pragma unroll
@@ -51,14 +62,28 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
     d[i] = E[i] - (float)s.rem0[i];
     s.rank[i] = 0;
   }
+  // tie rule (encode_conventions.h): a wave-uniform value, so ONE scalar branch picks the comparison for all pairs
+  if (tie_later) {
 #pragma unroll
-  for (int i = 0; i < P; i++) {
+    for (int i = 0; i < P; i++) {
 #pragma unroll
-    for (int j = i + 1; j <= P; j++) {
-      if (PSDF_ENC_RANK_TIE_RAISES_LATER ? (d[i] < d[j]) : (d[i] <= d[j]))   // encode_conventions.h
-        s.rank[i]++;
-      else
-        s.rank[j]++;
+      for (int j = i + 1; j <= P; j++) {
+        if (d[i] < d[j])
+          s.rank[i]++;
+        else
+          s.rank[j]++;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+#pragma unroll
+      for (int j = i + 1; j <= P; j++) {
+        if (d[i] <= d[j])
+          s.rank[i]++;
+        else
+          s.rank[j]++;
+      }
     }
   }
 #pragma unroll
@@ -93,27 +118,32 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
 // Hash of the vertex with remainder r: key_i = rem0_i + r - (P+1)*[rank_i > P - r],  h = (..((key_0)*c + key_1)*c ..)*c.
 // In the ring of 32-bit integers that is  sum_i key_i c^(P-i), so with H0 = sum_i rem0_i c^(P-i) (P multiplies, ONCE per
 // simplex) every vertex is  H0 + r*(c^P + .. + c) - sum_i [rank_i > P - r] * (P+1) c^(P-i):  adds and selects only
-// (integer multiplies are quarter rate and the direct form needs P of them per vertex).
-constexpr uint32_t HASH_C = (uint32_t)PSDF_ENC_HASH_MULTIPLIER;   // encode_conventions.h
-constexpr uint32_t hash_pow(int e) { return e == 0 ? 1u : HASH_C * hash_pow(e - 1); }
-constexpr uint32_t hash_geom(int P) { return P == 0 ? 0u : hash_pow(P) + hash_geom(P - 1); }
+// (integer multiplies are quarter rate and the direct form needs P of them per vertex).  The multiplier c is a kernel argument
+// (wave-uniform): its powers and their sum are scalar-unit arithmetic, computed once per wave.
 
 // All P+1 rows of a simplex.  `capacity` is wave-uniform (a kernel argument): ONE scalar branch on the kind of modulo for all
 // vertices (a power of two is a mask; the general case a ~35-instruction runtime modulo per vertex).
 template <int P>
-__device__ __forceinline__ void vertex_rows(const Simplex<P>& s, uint32_t capacity, uint32_t (&rows)[P + 1]) {
+__device__ __forceinline__ void vertex_rows(const Simplex<P>& s, uint32_t capacity, uint32_t (&rows)[P + 1], uint32_t hash_c) {
+  uint32_t pw[P + 1];   // pw[e] = c^e
+  pw[0] = 1u;
+#pragma unroll
+  for (int e = 1; e <= P; e++) pw[e] = pw[e - 1] * hash_c;
+  uint32_t geom = 0;    // c^P + .. + c
+#pragma unroll
+  for (int e = 1; e <= P; e++) geom += pw[e];
   uint32_t h0 = 0;
 #pragma unroll
   for (int i = 0; i < P; i++) {
     h0 += (uint32_t)s.rem0[i];
-    h0 *= HASH_C;
+    h0 *= hash_c;
   }
 #pragma unroll
   for (int r = 0; r <= P; r++) {
-    uint32_t h = h0 + (uint32_t)r * hash_geom(P);
+    uint32_t h = h0 + (uint32_t)r * geom;
 #pragma unroll
     for (int i = 0; i < P; i++)
-      if (s.rank[i] > P - r) h -= (uint32_t)(P + 1) * hash_pow(P - i);
+      if (s.rank[i] > P - r) h -= (uint32_t)(P + 1) * pw[P - i];
     rows[r] = h;
   }
   if ((capacity & (capacity - 1u)) == 0u) {

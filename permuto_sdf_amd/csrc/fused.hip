@@ -28,6 +28,7 @@ struct EncArgs {
   int L;               // hashed levels
   int Lt;              // L + pseudo-levels (== in_steps0 of the net)
   uint32_t capacity;
+  EncConv conv;            // runtime conventions (encode_device.h)
   const float* positions;  // [N,3]
   const float* lattice;    // [L,T,2]
   const float* scale_factor;  // [L,3]
@@ -62,10 +63,10 @@ __device__ __forceinline__ void level_issue(const EncArgs& e, const float (&pos)
   const float w = h ? w1 : w0;
   const int lvc = h ? l1 : l0;
   Simplex<3> s;
-  compute_simplex<3>(pos, sh, sf, s);
+  compute_simplex<3>(pos, sh, sf, s, e.conv.tie_later);
   const float* __restrict__ table = e.lattice + (int64_t)lvc * e.capacity * 2;
   uint32_t rows[4];
-  vertex_rows<3>(s, e.capacity, rows);
+  vertex_rows<3>(s, e.capacity, rows, e.conv.hash_c);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const uint32_t row = rows[r];
@@ -243,7 +244,7 @@ int psdf_encode_mlp_forward(int64_t N, int nr_levels, int capacity, const float*
   if (N == 0) return PSDF_OK;
   if (N < 0 || !positions || !lattice || !scale_factor || !shifts || !window || !packed || !Y) return PSDF_ERR_ARG;
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
-  EncArgs e{nr_levels, Lt, (uint32_t)capacity, positions, lattice, scale_factor, shifts, window, points_scaling, C};
+  EncArgs e{nr_levels, Lt, (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, points_scaling, C};
   hipStream_t st = (hipStream_t)stream;
   const int t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0, to = p.tiles[n_layers];
 #define CASE(A, B, C, O, D)                                          \

@@ -417,8 +417,12 @@ static int mlp_forward_impl(int n_layers, const int* dims, int64_t N, const floa
 #define CASE(A, B, C, O, D, S)                                                   \
   if (t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) {           \
     if constexpr (S) {                                                          \
-      if (sp.ok) return launch_fwd_split<A, B, C, O, D>(p, sp, N, X, packed, skip, Y, st); \
+      if (sp.ok) {                                                              \
+        psdf::g_last_path[psdf::PATH_MLP_FWD] = 2;                              \
+        return launch_fwd_split<A, B, C, O, D>(p, sp, N, X, packed, skip, Y, st); \
+      }                                                                         \
     }                                                                           \
+    psdf::g_last_path[psdf::PATH_MLP_FWD] = 1;                                  \
     return launch_fwd<A, B, C, O, D>(p, N, X, packed, skip, Y, st);             \
   }
   CASE(2, 2, 2, 1, true, true)    // 64x3 -> 1..4      (BASELINE SDF net)

@@ -37,6 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include <vector>
 
 namespace psdf {
+int g_last_path[PATH_FAMILIES] = {};
 void* stream_scratch(size_t bytes, hipStream_t st) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
@@ -53,6 +54,11 @@ void* stream_scratch(size_t bytes, hipStream_t st) {
   };
   static std::mutex mu;
   static std::vector<Entry> entries;
+  // Buffers that were outgrown are RETIRED, not freed: a second host thread may still hold the old pointer between this call
+  // and its launch, and work already queued on the stream may still be using it; a hipFree here would also need a blocking
+  // hipStreamSynchronize on the hot path.  Growth is geometric (x1.5, 4 MiB floor), so the retired total stays below twice the
+  // live buffer; everything is released with the process.
+  static std::vector<void*> retired;
   std::lock_guard<std::mutex> lock(mu);
   Entry* e = nullptr;
   for (auto& x : entries)
@@ -66,8 +72,7 @@ void* stream_scratch(size_t bytes, hipStream_t st) {
     return nullptr;
   }
   if (e) {
-    (void)hipStreamSynchronize(st);  // the old buffer may still be in use by queued work of this stream
-    (void)hipFree(e->ptr);
+    retired.push_back(e->ptr);
     e->ptr = np;
     e->cap = cap;
   } else {
@@ -1168,7 +1173,10 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
     }();
     if (enabled) {
       const int r = psdf_mlp_backward_split(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
-      if (r != PSDF_ERR_UNSUPPORTED) return r;
+      if (r != PSDF_ERR_UNSUPPORTED) {
+        psdf::g_last_path[psdf::PATH_MLP_BWD] = 2;
+        return r;
+      }
     }
   }
   BwdPtrs a;
@@ -1183,6 +1191,7 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   hipStream_t st = (hipStream_t)stream;
   const int ti0 = p.tiles[0], t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0,
             to = p.tiles[n_layers];
+  psdf::g_last_path[psdf::PATH_MLP_BWD] = 1;
 #define CASE(I, A, B, C, O, D)                                                   \
   if (ti0 == I && t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
     return launch_bwd<I, A, B, C, O, D>(p, N, X, dY, dX, a, st);
@@ -1200,8 +1209,21 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   CASE(5, 4, 4, 0, 1, true)   // 80 -> 64x2 -> 3          (background colour head, models.py:463-469)
 #undef CASE
   // nets too wide for one wave's registers (the 128-wide colour network): workgroup-cooperative kernel, mlp_wide.hip
+  psdf::g_last_path[psdf::PATH_MLP_BWD] = 3;
   if (dW) return psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
   return PSDF_ERR_UNSUPPORTED;
+}
+
+// Which kernel variant the last call of an operator family dispatched to (debug query for the parity tests; host only).
+//   family 0, encode backward: 1 = LDS scatter cache + float atomics (small batches), 2 = queue mode (binning launch +
+//             encode_bwd_reduce_kernel), 3 = position gradient only
+//   family 1, MLP backward   : 1 = fp32-MFMA kernel (mlp_bwd_kernel), 2 = split-bf16 kernel (mlp_bwd_split_kernel),
+//             3 = workgroup-cooperative wide kernel (mlp_wide_bwd_kernel)
+//   family 2, MLP forward    : 1 = fp32-MFMA kernel (mlp_fwd_kernel), 2 = split-bf16 kernel (mlp_fwd_split_kernel)
+// 0 = no call yet; -1 = unknown family.
+int psdf_last_path(int family) {
+  if (family < 0 || family >= psdf::PATH_FAMILIES) return -1;
+  return psdf::g_last_path[family];
 }
 
 // psdf_mlp_backward restricted to the data gradient (dW = db = NULL) with a per-sample mask: 16-sample tiles whose samples

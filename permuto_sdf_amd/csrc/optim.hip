@@ -115,7 +115,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       *reinterpret_cast<float4*>(p + base + i) = P;
       *reinterpret_cast<float4*>(m + base + i) = M;
       *reinterpret_cast<float4*>(v + base + i) = V;
-      if (zero_grad && t) *reinterpret_cast<float4*>(g + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      // every processed block is cleared, touched or not: a gradient that reached an active, unmarked block (a retained graph's
+      // backward after the step that consumed its marks) is applied ONCE, not on every later step (G is in registers: free)
+      if (zero_grad) *reinterpret_cast<float4*>(g + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 }

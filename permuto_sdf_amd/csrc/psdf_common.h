@@ -129,4 +129,10 @@ __device__ __forceinline__ float wave_incl_scan_mul(float v) {
 // Returns NULL while the stream is being captured (a later growth would move the buffer under the graph) or when the
 // allocation fails: callers then take their allocation-free path.
 void* stream_scratch(size_t bytes, hipStream_t st);
+
+// Debug record of the kernel variant the LAST call of an operator family dispatched to (host side, no device work; defined in
+// mlp_bwd.hip, read through psdf_last_path()).  The parity tests use it to assert that the configuration they compare with
+// the oracle really ran the kernels the benchmark times (the split-bf16 MLP kernels, the queue-mode encode backward).
+enum { PATH_ENCODE_BWD = 0, PATH_MLP_BWD = 1, PATH_MLP_FWD = 2, PATH_FAMILIES = 8 };
+extern int g_last_path[PATH_FAMILIES];
 }  // namespace psdf

@@ -105,6 +105,37 @@ class TouchedRows:
         self.grad = torch.zeros_like(lattice)
         self.touched = torch.zeros((L_, self.blocks_per_level), dtype=torch.uint8, device=lattice.device)
         self.active = torch.zeros_like(self.touched)
+        # Accumulation into `grad` is a SIDE EFFECT of a backward pass, so it happens only while the owner says so:
+        # `with tr.accumulate(): loss.backward()`.  Any other backward through the encoding (torch.autograd.grad of an
+        # auxiliary quantity, a create_graph pass, a second .backward() outside the step) returns its dense lattice gradient to
+        # autograd as usual and leaves the buffer alone -- intent is never inferred from the grad mode.
+        self.accumulating = False
+
+    def accumulate(self):
+        """context manager: plain backward passes inside it add their lattice gradient to `self.grad` (autograd gets None)"""
+        return _Flag(self, "accumulating")
+
+
+class _Flag:
+    """`with _Flag(obj, name):` sets obj.name = True inside the block (re-entrant: restores the previous value)"""
+
+    def __init__(self, obj, name):
+        self.obj, self.name = obj, name
+
+    def __enter__(self):
+        self.prev = getattr(self.obj, self.name)
+        setattr(self.obj, self.name, True)
+        return self.obj
+
+    def __exit__(self, *exc):
+        setattr(self.obj, self.name, self.prev)
+
+
+def _buffer_open(cfg):
+    """the persistent gradient buffer of this encoding, if its owner has opened it for THIS backward pass (and the pass is a
+    plain one: a differentiable backward being recorded must stay free of side effects)"""
+    tr = getattr(cfg, "touched_rows", None)
+    return tr if (tr is not None and tr.accumulating and not torch.is_grad_enabled()) else None
 
 
 class PermutoEncodingFunc(torch.autograd.Function):
@@ -130,10 +161,11 @@ class PermutoEncodingFunc(torch.autograd.Function):
         # points, create_graph=True) (models.py:245-251) comes through here with need_lat = True and throws the lattice
         # gradient away.  (a) A caller that knows it (the trainer) says so with `positions_gradient_only()` and the lattice
         # scatter is not even launched; (b) the persistent-buffer accumulation of TouchedRows is a side effect, so it is only
-        # allowed in a plain backward (grad mode off here), never while a differentiable backward is being recorded.
+        # done inside the owner's `with tr.accumulate():` block and only in a plain backward (grad mode off here), never
+        # while a differentiable backward is being recorded.
         if getattr(ctx.cfg, "skip_lattice_grad", False):
             need_lat = False
-        buffer_ok = not torch.is_grad_enabled()
+        buffer_ok = _buffer_open(ctx.cfg) is not None
         g_lat, g_pos = PermutoEncodingBackFunc.apply(ctx.cfg, scale_factor, shifts, lattice, positions, window,
                                                      grad_out, need_lat, need_pos, buffer_ok)
         # buffered mode (TouchedRows): the lattice gradient went into the persistent buffer, autograd gets None
@@ -178,8 +210,8 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
             return (None,) * 10
         N = positions.shape[0]
         dd = dd_positions.contiguous()
-        tr = getattr(cfg, "touched_rows", None)
-        buffered = need_lat and tr is not None and not torch.is_grad_enabled()    # side effects only in a plain backward
+        tr = _buffer_open(cfg)                                      # side effects only where the owner opened the buffer
+        buffered = need_lat and tr is not None
         g_lat = tr.grad if buffered else (torch.zeros_like(lattice) if need_lat else None)
         gg = torch.empty_like(g)
         L.call("psdf_encode_double_backward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
@@ -240,8 +272,9 @@ class PermutoEncoding(torch.nn.Module):
 
     def enable_touched_rows(self, block_rows_log2=7):
         """Opt in to the touched-rows optimiser path (trainer only; the reference's Python keeps the plain autograd
-        semantics): lattice gradients accumulate in `self.touched_rows.grad`, `lattice_values.grad` stays None, and
-        `FusedAdamW.step` must be given this object (`optim.FusedAdamW.attach`)."""
+        semantics): inside `with self.touched_rows.accumulate():` lattice gradients accumulate in `self.touched_rows.grad`
+        and `lattice_values.grad` stays None; `FusedAdamW.step` must be given this object (`optim.FusedAdamW.attach`).
+        Backward passes outside that block behave like plain autograd."""
         self.touched_rows = TouchedRows(self.lattice_values, block_rows_log2)
         self.cfg.touched_rows = self.touched_rows
         return self.touched_rows
@@ -288,6 +321,12 @@ class Coarse2Fine(torch.nn.Module):
             x = torch.clamp(alpha - self.level_idx, 0.0, 1.0)
             self._cached = 0.5 * (1.0 + torch.cos(math.pi * x + math.pi))
             self._cached_key = key
+        # a copy (one launch instead of five): callers own what they get -- unmodified reference Python may write into it
+        return self._cached.clone()
+
+    def window_readonly(self, t):
+        """the cached window itself, no copy: for callers that promise not to modify it (train_step.SdfNet)"""
+        self.forward(t)
         return self._cached
 
     def get_last_t(self):

@@ -84,6 +84,13 @@ class GradBuffer:
 
     def __init__(self, dims, device):
         self.flat, self.dWs, self.dbs = _grad_views(dims, dev=device)
+        self.accumulating = False       # set by the owner around ITS backward: `with gb.accumulate(): loss.backward()`
+
+    def accumulate(self):
+        """context manager: plain backward passes of the net inside it add their parameter gradients to this buffer; outside
+        it every backward returns its gradients to autograd (no side effects for auxiliary autograd.grad / .backward calls)"""
+        from .encoding import _Flag
+        return _Flag(self, "accumulating")
 
     def zero(self):
         self.flat.zero_()
@@ -129,8 +136,21 @@ def backward_supported(dims):
 _ANNOUNCED = set()
 
 
-def _announce(kind, dims):
+def torch_fallback_allowed(module=None):
+    """Widths without a fused backward / double-backward instantiation are an ERROR by default: this package is the hand-written
+    kernel path, and a silent dispatch to a vendor BLAS would be measured and trusted as if it were that path.  Opt in per net
+    (`FusedMLP(..., allow_torch_fallback=True)` / `net.allow_torch_fallback = True`) or per process (PSDF_MLP_TORCH_FALLBACK=1)
+    to have such nets differentiated by torch autograd over rocBLAS on the GPU instead (announced once per net shape)."""
+    import os
+    return bool(getattr(module, "allow_torch_fallback", False)) or os.environ.get("PSDF_MLP_TORCH_FALLBACK") == "1"
+
+
+def _announce(kind, dims, module=None):
     """say ONCE per (operator, widths) that a net is served by torch/rocBLAS on the GPU instead of a fused kernel"""
+    if not torch_fallback_allowed(module):
+        raise L.PsdfError("permuto_sdf_amd: no fused %s kernel is instantiated for the MLP widths %s (csrc/mlp_bwd.hip lists the "
+                          "instantiated widths).  Refusing to fall back to torch/rocBLAS silently: pass allow_torch_fallback=True "
+                          "to FusedMLP or set PSDF_MLP_TORCH_FALLBACK=1 to opt in." % (kind, list(dims)))
     key = (kind, tuple(dims))
     if key not in _ANNOUNCED:
         _ANNOUNCED.add(key)
@@ -146,10 +166,10 @@ def dx_only_supported(dims):
     return backward_supported(dims) and not (len(dims) == 5 and (t[1] > 4 or t[2] > 4))
 
 
-def _torch_gpu_backward(dims, x_fm, weights, biases, gy_fm, need_dx):
+def _torch_gpu_backward(dims, x_fm, weights, biases, gy_fm, need_dx, module=None):
     """Backward for widths the fused kernel family does not cover yet (the 128-wide colour net): the same
     Linear/GELU stack re-evaluated with torch ops ON THE GPU (rocBLAS) under autograd.  Not a CPU path."""
-    _announce("backward", dims)
+    _announce("backward", dims, module)
     n_layers = len(dims) - 1
     with torch.enable_grad():
         x = x_fm.t().detach().requires_grad_(need_dx)
@@ -166,11 +186,11 @@ def _torch_gpu_backward(dims, x_fm, weights, biases, gy_fm, need_dx):
     return dx, list(outs[k:k + n_layers]), list(outs[k + n_layers:])
 
 
-def _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
+def _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, module=None):
     """VJP of the map (x, params) -> dx = J_x^T gy with the upstream gradient v (what differentiating through the
     analytic input gradient needs: eikonal / curvature losses, models.py:245-251), by torch autograd ON THE GPU.
     Generic fallback for widths without a fused double-backward kernel.  -> (dX [C,N], [dW_l], [db_l])"""
-    _announce("double backward", dims)
+    _announce("double backward", dims, module)
     n_layers = len(dims) - 1
     with torch.enable_grad():
         x = x_fm.t().detach().requires_grad_(True)
@@ -188,21 +208,34 @@ def _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm):
 
 
 class _InputGradOnly:
-    """`with input_gradient_only():` -- backward passes of FusedMLP inside it compute d/dx only (the data-gradient-only kernel:
-    no accumulators, more waves per CU).  For torch.autograd.grad(sdf, points, create_graph=True) (models.py:245-251), where
-    autograd would compute the parameter gradients too and drop them."""
-    active = False
+    """`with input_gradient_only(net, ...):` -- backward passes of THESE FusedMLP modules inside the block compute d/dx only
+    (the data-gradient-only kernel: no accumulators, more waves per CU).  For torch.autograd.grad(sdf, points,
+    create_graph=True) (models.py:245-251), where autograd would compute the parameter gradients too and drop them.  The flag
+    lives on the module (like `cfg.skip_lattice_grad` of the encoding): another net differentiated inside the block, or on
+    another thread, keeps its parameter gradients."""
+
+    def __init__(self, modules):
+        self.modules = modules
 
     def __enter__(self):
-        self.prev = _InputGradOnly.active
-        _InputGradOnly.active = True
+        self.prev = [m._input_grad_only for m in self.modules]
+        for m in self.modules:
+            m._input_grad_only = True
 
     def __exit__(self, *exc):
-        _InputGradOnly.active = self.prev
+        for m, v in zip(self.modules, self.prev):
+            m._input_grad_only = v
 
 
-def input_gradient_only():
-    return _InputGradOnly()
+def input_gradient_only(*modules):
+    if not modules:
+        raise TypeError("input_gradient_only(net, ...): name the FusedMLP modules whose parameter gradients are to be skipped")
+    return _InputGradOnly(modules)
+
+
+def _grad_buffer_open(module):
+    gb = getattr(module, "grad_buffer", None)
+    return gb if (gb is not None and gb.accumulating and not torch.is_grad_enabled()) else None
 
 
 class _FusedMLPFunc(torch.autograd.Function):
@@ -227,11 +260,11 @@ class _FusedMLPFunc(torch.autograd.Function):
     def backward(ctx, gy):
         x = ctx.saved_tensors[0]
         params = ctx.saved_tensors[1:]
-        if _InputGradOnly.active:      # the caller only wants d/dx from this pass
+        if ctx.module._input_grad_only:      # the caller only wants d/dx from this pass
             outs = _FusedMLPBackFunc.apply(ctx.module, (ctx.needs_input_grad[1], False), x, gy, *params)
             return (None, outs[0] if ctx.needs_input_grad[1] else None, *([None] * len(params)))
-        gb = getattr(ctx.module, "grad_buffer", None)
-        if gb is not None and not torch.is_grad_enabled():   # plain backward: parameter gradients go to the module's buffer
+        gb = _grad_buffer_open(ctx.module)
+        if gb is not None:   # plain backward inside the owner's accumulate(): parameter gradients go to the module's buffer
             outs = _FusedMLPBackFunc.apply(ctx.module, (ctx.needs_input_grad[1], True, True), x, gy, *params)
             return (None, outs[0] if ctx.needs_input_grad[1] else None, *([None] * len(params)))
         outs = _FusedMLPBackFunc.apply(ctx.module, ctx.needs_input_grad[1], x, gy, *params)
@@ -265,7 +298,7 @@ class _FusedMLPBackFunc(torch.autograd.Function):
             if not need_dw or buffered:
                 dWs, dbs = [], []
         else:
-            dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, need_dx)
+            dx, dWs, dbs = _torch_gpu_backward(module.dims, x_fm, weights, biases, gy_fm, need_dx, module)
             if buffered:
                 gb = module.grad_buffer
                 for dst, src in zip(gb.dWs + gb.dbs, list(dWs) + list(dbs)):
@@ -299,11 +332,12 @@ class _FusedMLPBackFunc(torch.autograd.Function):
         v_fm = g_dx.t()
         if not v_fm.is_contiguous():
             v_fm = v_fm.contiguous()
-        gb = getattr(ctx.module, "grad_buffer", None)
-        if gb is not None and not torch.is_grad_enabled():
-            dX, _, _ = mlp_double_backward(ctx.module.dims, x_fm, weights, biases, gy_fm, v_fm, into=(gb.dWs, gb.dbs))
+        gb = _grad_buffer_open(ctx.module)
+        if gb is not None:
+            dX, _, _ = mlp_double_backward(ctx.module.dims, x_fm, weights, biases, gy_fm, v_fm, into=(gb.dWs, gb.dbs),
+                                           module=ctx.module)
             return (None, None, dX.t(), None, *([None] * (2 * n_layers)))
-        dX, dWs, dbs = mlp_double_backward(ctx.module.dims, x_fm, weights, biases, gy_fm, v_fm)
+        dX, dWs, dbs = mlp_double_backward(ctx.module.dims, x_fm, weights, biases, gy_fm, v_fm, module=ctx.module)
         return (None, None, dX.t(), None, *dWs, *dbs)
 
 
@@ -317,11 +351,11 @@ def double_backward_supported(dims):
                    (2, 2, 2, 2, 1, True), (3, 4, 4, 4, 1, True), (4, 4, 4, 4, 1, True)}
 
 
-def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None):
+def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None, module=None):
     """-> (dX [C,N], [dW_l], [db_l]) of <dx(x, params; gy), v>; fused kernel where one is built, torch (GPU) otherwise;
     into = (dWs, dbs): accumulate the parameter gradients there"""
     if not double_backward_supported(dims):
-        dX, dWs, dbs = _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm)
+        dX, dWs, dbs = _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, module)
         if into is not None:
             for dst, src in zip(list(into[0]) + list(into[1]), list(dWs) + list(dbs)):
                 if src is not None:
@@ -347,10 +381,12 @@ def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None):
 class FusedMLP(torch.nn.Module):
     """Linear(d0,d1)-GELU-...-Linear(d_{n-1},d_n), GELU(erf) after every layer but the last."""
 
-    def __init__(self, dims, reference_init=False, last_layer_linear_init=True):
+    def __init__(self, dims, reference_init=False, last_layer_linear_init=True, allow_torch_fallback=False):
         """reference_init: initialise like the reference's nets (leaky_relu_init on every layer, gain 1 on the last one when
-        `last_layer_linear_init`; models.py:161-162) instead of torch.nn.Linear's default"""
+        `last_layer_linear_init`; models.py:161-162) instead of torch.nn.Linear's default.  allow_torch_fallback: see
+        `torch_fallback_allowed` (default: widths without a fused backward kernel raise)"""
         super().__init__()
+        self.allow_torch_fallback = bool(allow_torch_fallback)
         self.dims = [int(d) for d in dims]
         self.n_layers = len(self.dims) - 1
         self.layers = torch.nn.ModuleList(
@@ -359,10 +395,15 @@ class FusedMLP(torch.nn.Module):
             for i, l in enumerate(self.layers):
                 leaky_relu_init_(l, 1.0 if (i == self.n_layers - 1 and last_layer_linear_init) else 0.0)
         self.grad_buffer = None
+        self._input_grad_only = False
+
+    def input_gradient_only(self):
+        """context manager, see mlp.input_gradient_only"""
+        return _InputGradOnly((self,))
 
     def enable_grad_buffer(self):
-        """-> GradBuffer: from now on plain backward passes ADD this net's parameter gradients into it (and return None to
-        autograd); the caller hands its views to the optimiser (`assign_grads`) and zeroes it after the step"""
+        """-> GradBuffer: plain backward passes inside `with gb.accumulate():` ADD this net's parameter gradients into it (and
+        return None to autograd); the caller hands its views to the optimiser (`assign_grads`) and zeroes it after the step"""
         self.grad_buffer = GradBuffer(self.dims, self.layers[0].weight.device)
         return self.grad_buffer
 

@@ -20,6 +20,24 @@ class FusedAdamW(torch.optim.Optimizer):
         if not hasattr(self, "_touched"):
             self._touched = {}
         self._touched[param] = touched_rows
+        self._rebuild_active(param)
+
+    def _rebuild_active(self, param):
+        """`active[b]` must be 1 for every block whose moments are not exactly zero (the dense update moves those rows): after
+        an attach() that follows dense steps, and after load_state_dict(), it is rebuilt from exp_avg / exp_avg_sq -- otherwise
+        such blocks would be skipped until their next touch and the 'same result as dense AdamW' contract would not hold."""
+        tr = self._touched[param]
+        st = self.state.get(param)
+        if not st or "exp_avg" not in st:
+            tr.active.zero_()
+            return
+        nz = (st["exp_avg"] != 0) | (st["exp_avg_sq"] != 0)
+        tr.active.copy_(nz.reshape(tr.touched.numel(), tr.block_elems).any(dim=1).view_as(tr.active).to(torch.uint8))
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for p in getattr(self, "_touched", {}):
+            self._rebuild_active(p)
 
     @torch.no_grad()
     def step(self, grad_scale=1.0):
@@ -36,6 +54,11 @@ class FusedAdamW(torch.optim.Optimizer):
                         st["exp_avg"] = torch.zeros_like(p)
                         st["exp_avg_sq"] = torch.zeros_like(p)
                     st["step"] += 1
+                    if p.grad is not None:
+                        # a backward that ran OUTSIDE `tr.accumulate()` handed its lattice gradient to autograd: fold it into
+                        # the buffer (the forward marked its row blocks already), so that no gradient is ever silently lost
+                        tr.grad.add_(p.grad)
+                        p.grad = None
                     if group["weight_decay"] != 0.0:       # every row moves: dense update from the same buffer
                         L.call("psdf_adamw_step", L.c_l(p.numel()), L.ptr(p), L.ptr(tr.grad), L.ptr(st["exp_avg"]),
                                L.ptr(st["exp_avg_sq"]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),

@@ -34,7 +34,7 @@ from . import parallel
 from .bridge import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRendering
 from .encoding import Coarse2Fine, PermutoEncoding
 from .fused import encode_mlp_forward_raw
-from .mlp import FusedMLP, LipshitzMLP, input_gradient_only, pack_params
+from .mlp import FusedMLP, LipshitzMLP, pack_params
 from .neus import (curvature_loss, curvature_shift, eikonal_loss, l1_loss, nerf_alpha, neus_alpha, normalize3,
                    offsurface_loss)
 from .optim import FusedAdamW
@@ -163,7 +163,8 @@ class SdfNet(torch.nn.Module):
         self.nr_iters_for_c2f = hp.sdf_nr_iters_for_c2f
 
     def window(self, it):
-        return self.c2f(map_range_val(it, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)).to(self.encoding.lattice_values.device)
+        # read-only use: the cached window itself (no copy per call; Coarse2Fine.__call__ hands out copies)
+        return self.c2f.window_readonly(map_range_val(it, 0.0, self.nr_iters_for_c2f, 0.3, 1.0)).to(self.encoding.lattice_values.device)
 
     def forward(self, points, it):
         return _SplitHead.apply(self.mlp_sdf(self.encoding(points, self.window(it))))
@@ -187,7 +188,7 @@ class SdfNet(torch.nn.Module):
                 points = points.detach().requires_grad_(True)
             sdf, feat = self.forward(points, it)
             # autograd would compute the lattice and the MLP parameter gradients here and drop them
-            with self.encoding.positions_gradient_only(), input_gradient_only():
+            with self.encoding.positions_gradient_only(), self.mlp_sdf.input_gradient_only():
                 (grad,) = torch.autograd.grad(sdf, points, torch.ones_like(sdf), create_graph=True, retain_graph=True)
         return sdf, grad, feat
 
@@ -307,6 +308,16 @@ class Trainer:
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
         self._seed = seed + 1
 
+    def accumulate_grads(self):
+        """context manager around the step's `loss.backward()`: opens the persistent gradient buffers (the lattices'
+        TouchedRows.grad, the SDF net's GradBuffer) for accumulation.  Backward passes outside it -- an auxiliary
+        torch.autograd.grad, a diagnostic .backward() -- behave like plain autograd and cannot leak into the next optimiser step."""
+        import contextlib
+        stack = contextlib.ExitStack()
+        for b in list(self.touched) + list(self.grad_buffers):
+            stack.enter_context(b.accumulate())
+        return stack
+
     # ---- checkpoints in the reference's file layout (permuto_sdf_utils.py:222-237)
     def save_checkpoint(self, folder):
         from . import checkpoint
@@ -384,7 +395,8 @@ class Trainer:
         # ---- backward, all-reduce, optimiser
         for p in self.params:
             p.grad = None
-        loss.backward()
+        with self.accumulate_grads():      # the persistent gradient buffers are open for THIS backward only
+            loss.backward()
         if self.grad_buffers:
             self.sdf.mlp_sdf.assign_grads()
         buffered = {id(m.encoding.lattice_values) for m in (self.sdf, self.rgb, self.bg)} if self.touched else set()

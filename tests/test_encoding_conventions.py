@@ -175,3 +175,77 @@ def test_gpu_both_concat_layouts_match_oracle(dev, layout, P, L_):
         assert tuple(feat.shape) == (C, N)
         assert (feat.t().cpu() - ref.detach()).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
         assert (y1.view(-1, 1).cpu() - y_ref.detach()).abs().max() <= 2e-5 * max(1.0, float(y_ref.abs().max()))
+
+
+def test_runtime_setter_reports_and_resets():
+    """psdf_encode_set_conventions / conventions.set: the device-side conventions are runtime values of the library (host only
+    here: no launch), the host-side ones change what the Python mirror computes; reset() restores the header's defaults"""
+    from permuto_sdf_amd import conventions as CV
+    from permuto_sdf_amd._lib import LIB_PATH
+    from permuto_sdf_amd.encoding import scale_factor_tensor
+    dll = ctypes.CDLL(LIB_PATH)
+    dll.psdf_encode_convention.restype = ctypes.c_int64
+    try:
+        CV.set(hash_multiplier=2654435761, rank_tie_raises_later=0, scale_inv_stddev=1)
+        # NOTE: a second CDLL handle of the same path shares the library's globals (same mapping)
+        assert int(dll.psdf_encode_convention(0)) == 2654435761 and int(dll.psdf_encode_convention(1)) == 0
+        sl = np.geomspace(1.0, 1e-2, 4)
+        a = scale_factor_tensor(sl, 3)
+        CV.reset()
+        b = scale_factor_tensor(sl, 3)
+        assert torch.allclose(a, b * (4 * (2.0 / 3.0) ** 0.5))
+        assert dll.psdf_encode_set_conventions(ctypes.c_uint32(0), ctypes.c_int(1)) == -1     # multiplier 0 is refused
+        assert dll.psdf_encode_set_conventions(ctypes.c_uint32(5), ctypes.c_int(2)) == -1
+    finally:
+        CV.reset()
+    assert [int(dll.psdf_encode_convention(i)) for i in range(len(ORDER))] == [int(CV.C[k]) for k in ORDER]
+    with pytest.raises(KeyError):
+        CV.set(push_to_library=False, no_such_convention=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [3, 4])
+def test_gpu_runtime_flip_of_hash_and_tie_rule_follows_the_oracle(dev, monkeypatch, P):
+    """A flag flip, not a rebuild: with another hash multiplier and the other tie rule set at RUN TIME the HIP kernels (forward,
+    lattice / position gradients, double backward, fused launch) follow the oracle evaluated under the same conventions --
+    including points whose residuals tie exactly (position = -shift[l]), where the tie rule decides the position gradient."""
+    from permuto_sdf_amd import PermutoEncoding
+    from permuto_sdf_amd import conventions as CV
+    L_, T, F, N = 8, 2 ** 12, 2, 3000
+    sl = np.geomspace(1.0, 1e-3, L_)
+    try:
+        for flip in ({}, {"hash_multiplier": 2654435761, "rank_tie_raises_later": 0}):
+            torch.manual_seed(40 + P)                                          # the same parameters and points under both
+            CV.reset()
+            CV.set(**flip)
+            monkeypatch.setattr(po, "CONV", dict(CV.C))
+            enc = PermutoEncoding(P, T, L_, F, sl, concat_points=True, concat_points_scaling=0.5, init_scale=1.0)
+            pts = torch.rand(N, P) - 0.5
+            pts[:L_] = -enc.random_shift_per_level.detach()                    # tie probes, one per level
+            win = po.coarse2fine_window(0.8, L_)
+            lat = enc.lattice_values.detach().clone().requires_grad_(True)
+            sh = enc.random_shift_per_level.detach().clone()
+            p_ref = pts.clone().requires_grad_(True)
+            ref = po.encode(p_ref, lat, sl, sh, win, True, 0.5)
+            g = torch.randn(N, ref.shape[1])
+            u = torch.randn(N, P)
+            (gp_ref,) = torch.autograd.grad(ref, p_ref, g, create_graph=True)
+            (gl_ref,) = torch.autograd.grad(ref, lat, g, retain_graph=True)
+            (dl_ref,) = torch.autograd.grad((gp_ref * u).sum(), [lat])
+            enc = enc.to(dev)
+            p = pts.to(dev).requires_grad_(True)
+            out = enc(p, win.to(dev))
+            assert (out.detach().cpu() - ref.detach()).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max())), flip
+            (gp,) = torch.autograd.grad(out, p, g.to(dev), create_graph=True)
+            (gl,) = torch.autograd.grad(out, enc.lattice_values, g.to(dev), retain_graph=True)
+            (dl,) = torch.autograd.grad((gp * u.to(dev)).sum(), [enc.lattice_values])
+            assert (gp.detach().cpu() - gp_ref.detach()).abs().max() <= 2e-5 * gp_ref.abs().max(), flip
+            assert (gp.detach().cpu()[:L_] - gp_ref.detach()[:L_]).abs().max() <= 2e-5 * gp_ref.abs().max(), flip   # the probes
+            assert (gl.cpu() - gl_ref).abs().max() <= 1e-5 * gl_ref.abs().max() + 1e-7, flip
+            assert (dl.cpu() - dl_ref).abs().max() <= 2e-5 * dl_ref.abs().max(), flip
+            if not flip:
+                base = out.detach().cpu().clone()
+            else:   # the flip really changed what the kernels compute (another hash -> other table rows)
+                assert not torch.allclose(out.detach().cpu()[:, :2 * L_], base[:, :2 * L_])
+    finally:
+        CV.reset()

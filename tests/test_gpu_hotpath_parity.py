@@ -1,0 +1,145 @@
+"""GPU: ORACLE PARITY OF THE CONFIGURATION THAT IS TIMED.  bench.py times SdfHotPath.step at 2 097 152 samples, where the
+library dispatches to `mlp_fwd_split_kernel`, `mlp_bwd_split_kernel` (N >= 2^18, csrc/mlp_bwd.hip) and the queue-mode encode
+backward `encode_bwd_kernel<..,queue>` + `encode_bwd_reduce_kernel` (N >= 2^18, csrc/encode.hip queue_plan).  These tests run
+that dispatch -- asserted through psdf_last_path(), not assumed -- against the CPU oracle chain (oracle/hotpath_oracle.py:
+oracle/permuto_oracle.py + unmodified torch.nn + oracle/neus_oracle.py, torch autograd):
+
+  * the whole step at 2 048 rays x 128 = 2^18 samples, 16 and 24 levels, T = 2^18: sdf, radiance, loss, lattice gradient (global
+    and per level) and all eight MLP parameter gradients;
+  * SURVEY.md 8(d) cfg 2 literally: the 2 097 152-sample batch of BASELINE.json configs[1] goes through the kernels in one piece
+    and a 65 536-sample subset of it is compared with the oracle -- forward values directly; gradients by feeding an upstream
+    gradient that is zero outside the subset, so that the full-size backward launches produce exactly the subset's gradient.
+
+Tolerance: 1e-4 relative to the largest entry (the north_star bar for fp32 SDF / radiance), written at each assert.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hotpath_oracle as ho
+from oracle import permuto_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def last_path(family):
+    from permuto_sdf_amd import _lib as L
+    fn = L.lib().psdf_last_path
+    fn.restype = ctypes.c_int
+    return int(fn(ctypes.c_int(family)))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def mlp_params_cpu(mlp):
+    return [l.weight.detach().cpu().clone() for l in mlp.layers], [l.bias.detach().cpu().clone() for l in mlp.layers]
+
+
+@pytest.mark.parametrize("nr_levels", [16, 24])
+def test_step_on_the_benchmarked_kernels_matches_oracle(dev, nr_levels):
+    import bench
+    from permuto_sdf import VolumeRendering
+    from permuto_sdf_amd.hotpath import SdfHotPath
+    R, n = 2048, 128
+    hp = SdfHotPath(nr_levels=nr_levels, hidden=64, out_channels=1, capacity=2 ** 18, device=dev, seed=5)
+    rs, rgb, aux = bench.make_batch(dev, 21, nr_rays=R, per_ray=n)
+    normals, gt = aux[4], aux[5]
+    N = rs.samples_pos.shape[0]
+    assert N == 1 << 18
+    pred, saved, out = hp.step(rs, rgb, normals, gt, reduce=False, optimizer_step=False)
+    torch.cuda.synchronize()
+    # the kernels bench.py times ran -- not their small-batch siblings
+    assert last_path(2) == 2, "MLP forward did not run mlp_fwd_split_kernel"
+    assert last_path(1) == 2, "MLP backward did not run mlp_bwd_split_kernel"
+    assert last_path(0) == 2, "encode backward did not run the queue-mode binning + reduce kernels"
+
+    ws, bs = mlp_params_cpu(hp.mlp)
+    ref = ho.reference_step(rs.samples_pos.cpu(), rs.samples_dirs.cpu(), normals.cpu(), rs.samples_dt.cpu(), rgb.cpu(), gt.cpu(),
+                            R, n, hp.enc.lattice_values.detach().cpu(), hp.enc.scale_per_level,
+                            hp.enc.random_shift_per_level.detach().cpu(), torch.ones(nr_levels), ws, bs, hp.inv_s.cpu(),
+                            hp.cos_anneal_ratio, reference_compat=VolumeRendering.reference_compat)
+    errs = {"features": rel(saved["feat"].t(), ref["feat"]),
+            "sdf": rel(saved["sdf"].view(-1, 1), ref["sdf"]),
+            "radiance": rel(pred, ref["pred"]),
+            "loss": abs(float(out["loss"]) - ref["loss"]) / abs(ref["loss"]),
+            "lattice_grad": rel(out["grads"][0], ref["g_lattice"])}
+    for l in range(4):
+        errs["dW%d" % l] = rel(out["grads"][1 + 2 * l], ref["g_weights"][l])
+        errs["db%d" % l] = rel(out["grads"][2 + 2 * l], ref["g_biases"][l])
+    print("L=%d, 2^18 samples, split / queue kernels: " % nr_levels + " ".join("%s %.1e" % kv for kv in errs.items()))
+    assert float(ref["g_lattice"].abs().max()) > 0 and all(float(g.abs().max()) > 0 for g in ref["g_weights"])
+    assert max(errs.values()) < TOL, errs
+    # per level: a coarse level's large entries must not hide a wrong fine level
+    g, gr = out["grads"][0].cpu(), ref["g_lattice"]
+    for l in range(nr_levels):
+        s = float(gr[l].abs().max())
+        assert s > 0 and float((g[l] - gr[l]).abs().max()) <= TOL * s, (l, s)
+
+
+def test_cfg2_full_batch_subset_matches_oracle(dev):
+    """SURVEY.md 8(d) cfg 2: N = 2 097 152 points, 16 levels, 36-64-64-64-1 -- 'parity vs oracle on a 65 536-point subset'."""
+    import bench
+    from permuto_sdf_amd.encoding import encode_backward_raw, encode_forward_raw
+    from permuto_sdf_amd.hotpath import SdfHotPath
+    from permuto_sdf_amd.mlp import mlp_backward_raw, mlp_forward_raw, pack_params
+    L_ = 16
+    hp = SdfHotPath(nr_levels=L_, hidden=64, out_channels=1, capacity=2 ** 18, device=dev, seed=9)
+    rs, _, _ = bench.make_batch(dev, 33)                         # the bench batch: 16 384 rays x 128
+    pos = rs.samples_pos
+    N = pos.shape[0]
+    assert N == 2097152
+    sub = torch.arange(5, N, 32, device=dev)                     # 65 536 samples spread over every ray
+    assert sub.numel() == 65536
+    cfg, enc, mlp = hp.enc.cfg, hp.enc, hp.mlp
+    win = torch.linspace(0.3, 1.0, L_, device=dev)
+    ws_d, bs_d = [l.weight for l in mlp.layers], [l.bias for l in mlp.layers]
+    # ---- full-size launches
+    feat = encode_forward_raw(cfg, pos, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win)
+    sdf = mlp_forward_raw(mlp.dims, feat, pack_params(mlp.dims, ws_d, bs_d))
+    g = torch.Generator().manual_seed(4)
+    dy_sub = torch.randn(sub.numel(), generator=g)
+    dY = torch.zeros(1, N, device=dev)
+    dY[0, sub] = dy_sub.to(dev)
+    d_feat, dWs, dbs = mlp_backward_raw(mlp.dims, feat, ws_d, bs_d, dY, need_dx=True)
+    g_lat = torch.zeros_like(enc.lattice_values)
+    encode_backward_raw(cfg, pos, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
+                        d_feat, g_lat, None)
+    torch.cuda.synchronize()
+    assert (last_path(2), last_path(1), last_path(0)) == (2, 2, 2)
+    # ---- oracle on the subset only
+    lat = enc.lattice_values.detach().cpu().clone().requires_grad_(True)
+    f_ref = po.encode(pos[sub].cpu(), lat, enc.scale_per_level, enc.random_shift_per_level.detach().cpu(), win.cpu(), True, 1e-3)
+    ws, bs = mlp_params_cpu(mlp)
+    lins = []
+    mods = []
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        lin = torch.nn.Linear(w.shape[1], w.shape[0])
+        lin.weight.data.copy_(w)
+        lin.bias.data.copy_(b)
+        lins.append(lin)
+        mods += [lin] + ([torch.nn.GELU()] if i < 3 else [])
+    f_leaf = f_ref.detach().clone().requires_grad_(True)
+    y_ref = torch.nn.Sequential(*mods)(f_leaf)
+    y_ref.backward(dy_sub.view(-1, 1))
+    f_ref.backward(f_leaf.grad)
+    errs = {"features": rel(feat[:, sub].t(), f_ref), "sdf": rel(sdf[0, sub].view(-1, 1), y_ref),
+            "d_features": rel(d_feat[:, sub].t(), f_leaf.grad), "lattice_grad": rel(g_lat, lat.grad)}
+    for l in range(4):
+        errs["dW%d" % l] = rel(dWs[l], lins[l].weight.grad)
+        errs["db%d" % l] = rel(dbs[l], lins[l].bias.grad)
+    print("cfg 2, 65 536-sample subset of the 2 097 152 batch: " + " ".join("%s %.1e" % kv for kv in errs.items()))
+    assert max(errs.values()) < TOL, errs
+    for l in range(L_):
+        s = float(lat.grad[l].abs().max())
+        assert s > 0 and float((g_lat[l].cpu() - lat.grad[l]).abs().max()) <= TOL * s, (l, s)
+    # samples outside the subset received a zero upstream gradient: their data gradient is exactly zero
+    mask = torch.ones(N, dtype=torch.bool, device=dev)
+    mask[sub] = False
+    assert float(d_feat[:, mask].abs().max()) == 0.0

@@ -332,10 +332,10 @@ def test_gradient_only_contexts_leave_the_training_gradients_unchanged(dev):
     from permuto_sdf_amd import FusedMLP, PermutoEncoding
     from permuto_sdf_amd.mlp import input_gradient_only
     torch.manual_seed(2)
-    enc = PermutoEncoding(3, 2 ** 14, 8, 2, np.geomspace(1.0, 1e-2, 8), concat_points=True, concat_points_scaling=1e-3,
+    enc = PermutoEncoding(3, 2 ** 14, 16, 2, np.geomspace(1.0, 1e-2, 16), concat_points=True, concat_points_scaling=1e-3,
                           init_scale=1e-1).to(dev)
-    mlp = FusedMLP([enc.output_dims(), 32, 32, 32, 33], reference_init=True).to(dev)
-    win = torch.ones(8, device=dev)
+    mlp = FusedMLP([enc.output_dims(), 32, 32, 32, 33], reference_init=True).to(dev)     # 36-32-32-32-33: fused kernels
+    win = torch.ones(16, device=dev)
     pts0 = (torch.rand(4000, 3, device=dev) - 0.5) * 0.8
     params = [enc.lattice_values] + list(mlp.parameters())
 
@@ -346,7 +346,7 @@ def test_gradient_only_contexts_leave_the_training_gradients_unchanged(dev):
         y = mlp(enc(pts, win))
         sdf = y[:, 0:1]
         with (enc.positions_gradient_only() if use_ctx else contextlib.nullcontext()), \
-             (input_gradient_only() if use_ctx else contextlib.nullcontext()):
+             (input_gradient_only(mlp) if use_ctx else contextlib.nullcontext()):
             (g,) = torch.autograd.grad(sdf, pts, torch.ones_like(sdf), create_graph=True, retain_graph=True)
         loss = (sdf ** 2).mean() + ((g.norm(dim=1) - 1.0) ** 2).mean() + y[:, 1:].pow(2).mean() * 0.1
         loss.backward()
@@ -375,7 +375,7 @@ def test_grad_buffer_accumulates_what_autograd_would_sum(dev):
         for x0 in xs:
             x = x0.clone().requires_grad_(True)
             y = m(x)
-            with input_gradient_only():
+            with input_gradient_only(m):
                 (g,) = torch.autograd.grad(y[:, 0:1], x, torch.ones_like(y[:, 0:1]), create_graph=True)
             total = total + (g ** 2).mean() + (y[:, 1:] ** 2).mean() + y[:, 0].abs().mean()
         return total
@@ -384,7 +384,17 @@ def test_grad_buffer_accumulates_what_autograd_would_sum(dev):
     assert float(gb.flat.abs().max()) == 0.0
     l = loss_of(net)
     assert float(gb.flat.abs().max()) == 0.0                  # the create_graph passes did not write into it
-    l.backward()
+    # a backward OUTSIDE the owner's accumulate() block is plain autograd: .grad is populated, the buffer stays untouched
+    # (an auxiliary autograd.grad / .backward can never leak into the next optimiser step)
+    aux = net(xs[0])[:, 1:].pow(2).mean()
+    aux.backward()
+    assert float(gb.flat.abs().max()) == 0.0 and all(p.grad is not None for p in net.parameters())
+    (gw0,) = torch.autograd.grad(net(xs[1].clone().requires_grad_(True)).sum(), [net.layers[0].weight])
+    assert float(gb.flat.abs().max()) == 0.0 and float(gw0.abs().max()) > 0
+    for p in net.parameters():
+        p.grad = None
+    with gb.accumulate():
+        l.backward()
     assert all(p.grad is None for p in net.parameters())
     net.assign_grads()
     for a, b in zip(net.parameters(), ref.parameters()):
@@ -392,3 +402,21 @@ def test_grad_buffer_accumulates_what_autograd_would_sum(dev):
         assert float((a.grad - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()) + 1e-9
     gb.zero()
     assert float(net.layers[0].weight.grad.abs().max()) == 0.0   # views of the buffer
+
+
+def test_unfused_widths_raise_unless_opted_in(dev):
+    """VERDICT r2: no silent dispatch to rocBLAS.  A net whose widths have no fused backward instantiation raises in backward;
+    `allow_torch_fallback=True` opts in to torch autograd on the GPU (and says so once)."""
+    import warnings
+    from permuto_sdf_amd import FusedMLP
+    from permuto_sdf_amd._lib import PsdfError
+    dims = [20, 32, 32, 32, 33]
+    x = torch.randn(100, 20, device=dev)
+    net = FusedMLP(dims).to(dev)
+    with pytest.raises(PsdfError, match="allow_torch_fallback"):
+        net(x.clone().requires_grad_(True)).sum().backward()
+    net.allow_torch_fallback = True
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net(x.clone().requires_grad_(True)).sum().backward()
+    assert net.layers[0].weight.grad is not None and float(net.layers[0].weight.grad.abs().max()) > 0

@@ -32,7 +32,8 @@ def test_touched_map_covers_every_written_row(dev):
     win = torch.ones(12, device=dev)
     w1 = torch.randn(enc.output_dims(), 3, device=dev)
     pts = (torch.rand(3000, 3, device=dev) - 0.5) * 0.6
-    _loss(enc, w1, pts, win).backward()
+    with tr.accumulate():
+        _loss(enc, w1, pts, win).backward()
     assert enc.lattice_values.grad is None                       # the gradient went to the persistent buffer
     g = tr.grad
     assert float(g.abs().max()) > 0
@@ -69,8 +70,9 @@ def test_block_adamw_is_bit_identical_to_dense_torch_adamw(dev):
         # batches move: rows touched in one step are NOT touched in a later one, their moments must keep decaying
         centre = torch.tensor([[0.3 * np.cos(it), 0.3 * np.sin(it), 0.0]])
         pts = ((torch.rand(2000, 3, generator=g) - 0.5) * 0.25 + centre).to(dev)
-        _loss(ours, w1, pts, win).backward()
-        _loss(ours, w1, pts * 0.5, win).backward()                # two backward calls accumulate into the one buffer
+        with tr.accumulate():
+            _loss(ours, w1, pts, win).backward()
+            _loss(ours, w1, pts * 0.5, win).backward()            # two backward calls accumulate into the one buffer
         grad = tr.grad.clone()
         ref.lattice_values.grad = grad.clone()
         dense_fused.step()
@@ -115,3 +117,93 @@ def test_trainer_steps_with_and_without_touched_rows_agree(dev):
     assert got[0] <= 3 * noise[0] + 1e-3, (got, noise)
     assert got[1] <= 3 * noise[1] + 1e-4, (got, noise)
     assert got[2] <= 3 * noise[2] + 1e-3, (got, noise)
+
+
+def test_backward_outside_accumulate_is_plain_autograd(dev):
+    """the persistent buffer accumulates only inside the owner's `with tr.accumulate():`.  An auxiliary
+    torch.autograd.grad(out, positions) or a stray .backward() behaves like plain autograd (dense gradient returned, buffer
+    untouched), so nothing can leak into the next optimiser step; a gradient that did land in `.grad` is folded into the buffer
+    by FusedAdamW.step instead of being lost."""
+    from permuto_sdf_amd.optim import FusedAdamW
+    enc = _enc(dev, seed=4)
+    tr = enc.enable_touched_rows()
+    win = torch.ones(12, device=dev)
+    w1 = torch.randn(enc.output_dims(), 3, device=dev)
+    pts = ((torch.rand(2000, 3, device=dev) - 0.5) * 0.6).requires_grad_(True)
+    out = torch.tanh(enc(pts, win) @ w1).sum()
+    (gp,) = torch.autograd.grad(out, pts, retain_graph=True)          # auxiliary: positions only
+    assert float(tr.grad.abs().max()) == 0.0 and float(gp.abs().max()) > 0
+    out.backward()                                                    # stray backward outside the block
+    assert float(tr.grad.abs().max()) == 0.0
+    dense = enc.lattice_values.grad.clone()
+    assert float(dense.abs().max()) > 0
+    # the same gradient through the buffer
+    enc.lattice_values.grad = None
+    with tr.accumulate():
+        torch.tanh(enc(pts.detach(), win) @ w1).sum().backward()
+    assert enc.lattice_values.grad is None
+    assert float((tr.grad - dense).abs().max()) <= 2e-5 * float(dense.abs().max())
+    # step(): a stray .grad is folded in, not lost
+    opt = FusedAdamW([enc.lattice_values], lr=1e-3)
+    opt.attach(enc.lattice_values, tr)
+    enc.lattice_values.grad = dense.clone()
+    before = enc.lattice_values.detach().clone()
+    g_total = (tr.grad + dense).clone()
+    opt.step()
+    assert enc.lattice_values.grad is None and float(tr.grad.abs().max()) == 0.0
+    moved = (enc.lattice_values.detach() != before)
+    has_g = g_total != 0
+    assert not bool((moved & ~has_g).any())                           # first step: only entries with a gradient move ...
+    assert float((moved & has_g).sum()) >= 0.99 * float(has_g.sum())  # ... and (up to underflowing ones) all of them do
+
+
+def test_block_adamw_clears_unmarked_gradients_and_rebuilds_active(dev):
+    """ADVICE r2, csrc/optim.hip + optim.py: (1) a gradient written into an ACTIVE block whose touched byte is not set (a
+    retained graph's backward after the step that consumed its marks) is applied once and cleared, not re-applied on every
+    later step; (2) attach() after dense steps and load_state_dict() rebuild `active` from the moments, so that blocks with
+    non-zero moments keep moving exactly as the dense update moves them."""
+    from permuto_sdf_amd.optim import FusedAdamW
+    win = torch.ones(12, device=dev)
+    a, b = _enc(dev, seed=6), _enc(dev, seed=6)
+    w1 = torch.randn(a.output_dims(), 3, device=dev)
+    pts = (torch.rand(1500, 3, device=dev) - 0.5) * 0.3
+    opt_a = FusedAdamW([a.lattice_values], lr=1e-3)
+    opt_b = FusedAdamW([b.lattice_values], lr=1e-3)
+    # two dense steps on both (no touched-rows state yet)
+    for _ in range(2):
+        for enc, opt in ((a, opt_a), (b, opt_b)):
+            enc.lattice_values.grad = None
+            _loss(enc, w1, pts, win).backward()
+            opt.step()
+    assert torch.equal(a.lattice_values, b.lattice_values)
+    tr = b.enable_touched_rows()
+    opt_b.attach(b.lattice_values, tr)                                # after dense steps: active must come from the moments
+    st = opt_b.state[b.lattice_values]
+    want = ((st["exp_avg"] != 0) | (st["exp_avg_sq"] != 0)).view(tr.touched.numel(), tr.block_elems).any(1).view_as(tr.active)
+    assert torch.equal(tr.active.bool(), want) and bool(want.any())
+    # steps WITHOUT new gradients: the dense update keeps moving rows with decaying moments; the block update must follow
+    for _ in range(2):
+        a.lattice_values.grad = torch.zeros_like(a.lattice_values)
+        opt_a.step()
+        opt_b.step()
+    assert torch.equal(a.lattice_values, b.lattice_values)
+    # state_dict round trip into a fresh optimiser / TouchedRows
+    c = _enc(dev, seed=6)
+    with torch.no_grad():
+        c.lattice_values.copy_(b.lattice_values)
+    opt_c = FusedAdamW([c.lattice_values], lr=1e-3)
+    tr_c = c.enable_touched_rows()
+    opt_c.attach(c.lattice_values, tr_c)
+    assert int(tr_c.active.sum()) == 0
+    opt_c.load_state_dict(opt_b.state_dict())
+    assert torch.equal(tr_c.active, tr.active)
+    a.lattice_values.grad = torch.zeros_like(a.lattice_values)
+    opt_a.step()
+    opt_c.step()
+    assert torch.equal(a.lattice_values, c.lattice_values)
+    # (1) gradient in an active but unmarked block: applied once, then gone
+    blk = int(torch.nonzero(tr_c.active.view(-1))[0])
+    tr_c.grad.view(-1)[blk * tr_c.block_elems] = 1.0
+    assert int(tr_c.touched.sum()) == 0
+    opt_c.step()
+    assert float(tr_c.grad.abs().max()) == 0.0
