@@ -159,11 +159,11 @@ def main():
     # per-kernel HIP events on the launch stream (torch's current stream == the stream the kernels are launched on)
     K = args.steps
     ev = {k: [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-          for k in ("enc_bwd", "mlp_bwd", "fwd")}
+          for k in ("enc_bwd", "mlp_bwd", "fwd", "comm_wait")}
     barrier()
     t0 = time.perf_counter()
     for i in range(K):
-        hp.events = {"enc_bwd": ev["enc_bwd"][i], "mlp_bwd": ev["mlp_bwd"][i]}
+        hp.events = {"enc_bwd": ev["enc_bwd"][i], "mlp_bwd": ev["mlp_bwd"][i], "comm_wait": ev["comm_wait"][i]}
         ev["fwd"][i][0].record()
         pred, saved = hp.forward(rs, rgb, normals)
         ev["fwd"][i][1].record()
@@ -192,8 +192,17 @@ def main():
             del hp24
         except Exception as e:  # the extra row must never take the headline down
             extra["L24_52-64-64-64-1"] = {"error": repr(e)}
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if (world == 1 or torch.distributed.get_backend() == "nccl") else "cpu")
+    cdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    per_rank = None
     if world > 1:
+        # self-diagnosing N > 1 line: every rank's own wall time per step and the time its step waited for communication
+        # (HIP events around GradientBuckets.finish()), gathered on rank 0; the headline uses the MAX over ranks
+        comm_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["comm_wait"]]))
+        mine = torch.tensor([elapsed / K * 1e3, comm_ms], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [float(x[0]) for x in allr], "comm_wait_ms": [float(x[1]) for x in allr]}
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -270,6 +279,13 @@ def main():
             "fwd_only_samples_per_s": N / (ms["fwd"] * 1e-3),
             "extra": extra,
         }
+        if world > 1:
+            from permuto_sdf_amd.parallel import _mode_default
+            out["dp"] = {"per_rank": per_rank, "reduce": _mode_default() + (" (reduce-scatter + all-gather per bucket)" if _mode_default() == "reduce_scatter" else ""),
+                         "bucket_bytes": getattr(hp, "last_bucket_bytes", None), "backend": torch.distributed.get_backend(),
+                         "note": "buckets: MLP gradients first (overlap the encode backward), then the lattice gradient in two level "
+                                 "ranges (the first range travels while the second is computed); comm_wait_ms = what the step still "
+                                 "waits for after its last backward kernel"}
         if not args.no_cpu_baseline and world == 1:
             # The vectorised torch-CPU restatement gets SLOWER beyond ~8 threads on the 256-core host (measured:
             # 8 thr 0.7 s, 32 thr 1.1 s, 64 thr 2.2 s per 32k samples), so the baseline uses 8 threads and says so.

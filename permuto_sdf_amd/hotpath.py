@@ -119,7 +119,14 @@ class SdfHotPath:
         if self.events is not None:
             self.events["enc_bwd"][1].record()
         if reduce:
+            # what the step WAITS for communication: from the end of the last backward kernel to the last bucket's arrival
+            # (0 when the all-reduce is hidden behind the encode backward; bench.py reports it per rank)
+            if self.events is not None and "comm_wait" in self.events:
+                self.events["comm_wait"][0].record()
             buckets.finish()
+            if self.events is not None and "comm_wait" in self.events:
+                self.events["comm_wait"][1].record()
+            self.last_bucket_bytes = list(buckets.bytes)
         grads = [g_lat] + [t for pair in zip(dWs, dbs) for t in pair]
         if optimizer_step:
             for p, g in zip(self.params, grads):

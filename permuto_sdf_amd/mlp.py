@@ -260,7 +260,7 @@ class _FusedMLPFunc(torch.autograd.Function):
     def backward(ctx, gy):
         x = ctx.saved_tensors[0]
         params = ctx.saved_tensors[1:]
-        if ctx.module._input_grad_only:      # the caller only wants d/dx from this pass
+        if getattr(ctx.module, "_input_grad_only", False):      # the caller only wants d/dx from this pass
             outs = _FusedMLPBackFunc.apply(ctx.module, (ctx.needs_input_grad[1], False), x, gy, *params)
             return (None, outs[0] if ctx.needs_input_grad[1] else None, *([None] * len(params)))
         gb = _grad_buffer_open(ctx.module)

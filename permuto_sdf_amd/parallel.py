@@ -6,7 +6,10 @@ grid, and the only exchange is one sum all-reduce of the gradients per step (SUR
 Gradients are reduced in buckets that are launched as soon as they are final, so the reduction of bucket k overlaps
 the backward kernels that produce bucket k+1: the small MLP gradients go first (they are ready before the encoding
 backward starts), then one bucket per lattice (50 MB each at L=24).  MI355X nodes are fully connected by 7 xGMI links
-per GPU; RCCL picks the algorithm, large fp32 buckets keep every link busy.
+per GPU (point to point): every bucket is reduced as reduce-scatter + all-gather so that all links carry 1/world of it
+(GradientBuckets, PSDF_DP_REDUCE), and a touched-blocks variant sends only the table blocks some rank's batch read
+(GradientBuckets.reduce_blocks).  `Loopback` is a single-GPU test double of an asynchronous backend: the overlap schedule of
+hotpath.backward can be checked for races without a second device.
 """
 import os
 
@@ -31,6 +34,8 @@ def init(backend=None):
 
 
 def world_size():
+    if _loopback is not None:
+        return _loopback.world
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
@@ -66,7 +71,7 @@ def step_seed(base_seed, rank, iteration, world=None):
 
 def all_reduce_max_(t):
     """in-place MAX all-reduce of a small tensor (the touched-block byte maps); no-op for one process"""
-    if world_size() == 1:
+    if world_size() == 1 or _loopback is not None:      # identical replicas: the maximum over the ranks is the value itself
         return t
     import torch.distributed as dist
     if dist.get_backend() == "gloo" and t.is_cuda:      # test-only path, as in GradientBuckets
@@ -78,11 +83,118 @@ def all_reduce_max_(t):
     return t
 
 
-class GradientBuckets:
-    """Async sum all-reduce of gradient tensors, bucket by bucket; `finish()` waits for all of them."""
+def _mode_default():
+    """PSDF_DP_REDUCE = all_reduce | reduce_scatter (default): see GradientBuckets"""
+    return os.environ.get("PSDF_DP_REDUCE", "reduce_scatter")
 
-    def __init__(self):
+
+class Loopback:
+    """TEST DOUBLE of an asynchronous collective backend on ONE GPU (two ranks of RCCL cannot share a device, and gloo's
+    device path is synchronous, so neither can show a scheduling race).  It behaves like ProcessGroupNCCL where it matters for
+    correctness of the SCHEDULE: a collective is enqueued on a side stream that first waits for what the caller's current stream
+    has enqueued so far, runs for a while (`delay_cycles` of device sleep, so that a consumer that forgot to wait reads stale
+    data), and `wait()` makes the caller's current stream wait for it.  The 'sum over `world` ranks' of identical replicas is
+    t * world.  Activate with `parallel.set_loopback(Loopback(world=2))`; world_size() then reports `world`."""
+
+    def __init__(self, world=2, delay_cycles=2_000_000):
+        self.world, self.delay = int(world), int(delay_cycles)
+        self.stream = torch.cuda.Stream()
+        self.launched = []      # (kind, numel) log for the tests
+
+    class _Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def _run(self, fn, kind, numel):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            torch.cuda._sleep(self.delay)
+            fn()
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.launched.append((kind, numel))
+        return Loopback._Work(ev)
+
+    def all_reduce(self, t, op="sum"):
+        return self._run((lambda: t.mul_(self.world)) if op == "sum" else (lambda: None), "all_reduce", t.numel())
+
+    def reduce_scatter(self, shard, flat, rank=0):
+        n = shard.numel()
+        return self._run(lambda: shard.copy_(flat[rank * n:(rank + 1) * n] * self.world), "reduce_scatter", flat.numel())
+
+    def all_gather(self, flat, shard, rank=0):
+        # the other ranks' shards of identical replicas are this rank's own values of those ranges, summed the same way
+        n = shard.numel()
+
+        def fn():
+            keep = shard.clone()
+            flat.mul_(self.world)
+            flat[rank * n:(rank + 1) * n].copy_(keep)
+        return self._run(fn, "all_gather", flat.numel())
+
+
+_loopback = None
+
+
+def set_loopback(lb):
+    """install / remove (None) the single-GPU test double; returns the previous one"""
+    global _loopback
+    prev, _loopback = _loopback, lb
+    return prev
+
+
+class GradientBuckets:
+    """Async SUM reduction of gradient tensors over the ranks, bucket by bucket; `finish()` waits for all of them.
+
+    mode "reduce_scatter" (default): every bucket is reduced as reduce-scatter + all-gather.  On the fully
+    connected xGMI topology of an MI355X node (7 links per GPU, point to point) each rank then receives 1/world of the bucket
+    from every peer over that peer's own link and sends its reduced shard back the same way: all links busy, 2 (w-1)/w of the
+    bucket per link direction, instead of a single ring that is bound by one link.  RCCL may well pick the same algorithm for a
+    plain all_reduce -- issuing the two halves explicitly does not depend on its tuning tables, and lets the optimiser run on
+    the owned shard between the two (not done here: the update is replicated).  mode "all_reduce": one all_reduce per bucket.
+    Buckets are padded to a multiple of the world size inside a flat staging buffer when they are multi-tensor or ragged."""
+
+    def __init__(self, mode=None):
         self.pending = []
+        self.mode = mode or _mode_default()
+        self.bytes = []          # per bucket, for the bench line
+
+    # -- backends ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _gloo_device(tensors):
+        return dist.is_initialized() and dist.get_backend() == "gloo" and tensors[0].is_cuda
+
+    def _launch(self, flat):
+        """-> list of work handles for the SUM reduction of the 1-D contiguous `flat` (numel % world == 0), in place"""
+        w = world_size()
+        if _loopback is not None:
+            if self.mode == "all_reduce":
+                return [_loopback.all_reduce(flat)]
+            shard = torch.empty(flat.numel() // w, dtype=flat.dtype, device=flat.device)
+            return [_loopback.reduce_scatter(shard, flat), _loopback.all_gather(flat, shard)]
+        if self.mode == "all_reduce":
+            return [dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)]
+        r = dist.get_rank()
+        n = flat.numel() // w
+        shard = torch.empty(n, dtype=flat.dtype, device=flat.device)
+        if dist.get_backend() == "nccl":
+            # both enqueue on the process group's stream, in order: the gather starts when the scatter's result is there
+            a = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)
+            b = dist.all_gather_into_tensor(flat, shard, async_op=True)
+            return [a, b, shard]
+        # gloo (CPU tests) has no reduce_scatter: one reduce per owner, then the gather
+        for o in range(w):
+            part = flat[o * n:(o + 1) * n]
+            dist.reduce(part, dst=o, op=dist.ReduceOp.SUM)
+            if o == r:
+                shard.copy_(part)
+        parts = [torch.empty_like(shard) for _ in range(w)]
+        dist.all_gather(parts, shard)
+        flat.copy_(torch.cat(parts))
+        return []
 
     def reduce(self, tensors):
         """Launch the reduction of one bucket (a list of gradient tensors that are final).  No-op on one rank."""
@@ -91,28 +203,69 @@ class GradientBuckets:
         tensors = [t for t in tensors if t is not None]
         if not tensors:
             return
-        if dist.get_backend() == "gloo" and tensors[0].is_cuda:
+        self.bytes.append(sum(t.numel() * t.element_size() for t in tensors))
+        if _loopback is None and self._gloo_device(tensors):
             # test-only path (gloo has no device collectives here): stage through host memory, synchronously
+            host = [t.detach().cpu().reshape(-1) for t in tensors]
+            flat, pad = self._flatten(host)
+            for wk in self._launch(flat):
+                if hasattr(wk, "wait"):
+                    wk.wait()
+            off = 0
             for t in tensors:
-                h = t.detach().cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                t.copy_(h)
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
             return
-        if len(tensors) == 1:
-            self.pending.append((dist.all_reduce(tensors[0], op=dist.ReduceOp.SUM, async_op=True), None, None))
+        w = world_size()
+        if len(tensors) == 1 and tensors[0].is_contiguous() and tensors[0].numel() % w == 0:
+            self.pending.append((self._launch(tensors[0].view(-1)), None, None))
             return
-        flat = torch.cat([t.reshape(-1) for t in tensors])
-        self.pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, tensors))
+        flat, _ = self._flatten([t.reshape(-1) for t in tensors])
+        self.pending.append((self._launch(flat), flat, tensors))
+
+    @staticmethod
+    def _flatten(parts):
+        w = world_size()
+        n = sum(p.numel() for p in parts)
+        pad = (-n) % w
+        if pad:
+            parts = list(parts) + [torch.zeros(pad, dtype=parts[0].dtype, device=parts[0].device)]
+        return torch.cat(parts), pad
+
+    def reduce_blocks(self, grad, touched, block_elems):
+        """Touched-blocks (sparse) reduction of a lattice gradient: `touched` [n_blocks] bytes has ALREADY been OR-reduced over
+        the ranks (all_reduce_max_), so every rank holds the same set; only those blocks of `grad` (viewed [n_blocks,
+        block_elems]) travel.  Blocks nobody touched carry an all-zero gradient on every rank: skipping them changes nothing.
+        Costs one host sync (the number of touched blocks sizes the message).  Worth it when a batch touches a small part of
+        the table: the coarse levels always, the hashed levels only for small batches."""
+        if world_size() == 1:
+            return
+        idx = torch.nonzero(touched.reshape(-1), as_tuple=False).reshape(-1)
+        if idx.numel() == 0:
+            return
+        g2 = grad.view(-1, block_elems)
+        if idx.numel() == g2.shape[0]:
+            return self.reduce([grad])
+        compact = g2.index_select(0, idx)
+        self.reduce([compact])
+        # the staging buffer of reduce() is written back into `compact` at finish(); scatter it home afterwards
+        self.pending.append(([], None, None, (g2, idx, compact)))
 
     def finish(self):
-        for work, flat, tensors in self.pending:
-            work.wait()
+        for item in self.pending:
+            works, flat, tensors = item[:3]
+            for wk in works:
+                if hasattr(wk, "wait"):
+                    wk.wait()
             if flat is not None:
                 off = 0
                 for t in tensors:
                     n = t.numel()
                     t.copy_(flat[off:off + n].view_as(t))
                     off += n
+            if len(item) == 4:
+                g2, idx, compact = item[3]
+                g2.index_copy_(0, idx, compact)
         self.pending = []
 
 

@@ -37,7 +37,7 @@ def _grads(po, lat, sh, pts, w1, sl, win):
     return lat.grad, w.grad
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, mode, sparse):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from permuto_sdf_amd import parallel
     r, w, _ = parallel.init(backend="gloo")
@@ -45,25 +45,43 @@ def _worker(rank, world, port, ret):
     po, lat, sh, pts, w1, sl, win = _problem()
     s, e = parallel.shard_rays(pts.shape[0], rank, world)
     g_lat, g_w = _grads(po, lat, sh, pts[s:e], w1, sl, win)
-    b = parallel.GradientBuckets()
-    b.reduce([g_w, torch.zeros(3)])     # small multi-tensor bucket (flattened)
-    b.reduce([g_lat])                   # one bucket per lattice
+    b = parallel.GradientBuckets(mode=mode)
+    b.reduce([g_w, torch.zeros(3)])     # small multi-tensor bucket (flattened, padded to a multiple of the world size)
+    if sparse:
+        # touched-blocks reduction: blocks of 16 table rows; a block is touched where THIS rank's gradient is non-zero, the
+        # byte maps are OR-reduced (MAX) first so that every rank sends the same set of blocks
+        block_elems = 16 * 2
+        touched = (g_lat.view(-1, block_elems) != 0).any(1).to(torch.uint8)
+        parallel.all_reduce_max_(touched)
+        ret["touched_frac_%d" % rank] = float(touched.float().mean())
+        b.reduce_blocks(g_lat, touched, block_elems)
+    else:
+        b.reduce([g_lat])                   # one bucket per lattice
     b.finish()
+    ret["bytes_%d" % rank] = list(b.bytes)
     if rank == 0:
         ret["g_lat"], ret["g_w"] = g_lat.numpy(), g_w.numpy()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ray_sharded_gradients_equal_full_batch():
+@pytest.mark.parametrize("mode,sparse", [("all_reduce", False), ("reduce_scatter", False), ("reduce_scatter", True),
+                                         ("all_reduce", True)])
+def test_ray_sharded_gradients_equal_full_batch(mode, sparse):
+    """both bucket algorithms (one all_reduce; reduce-scatter + all-gather) and the touched-blocks variant
+    give the full-batch gradient"""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, mode, sparse), nprocs=world, join=True)
     po, lat, sh, pts, w1, sl, win = _problem()
     g_lat, g_w = _grads(po, lat, sh, pts, w1, sl, win)
     assert np.abs(ret["g_lat"] - g_lat.numpy()).max() <= 1e-5 * g_lat.abs().max().item()
     assert np.abs(ret["g_w"] - g_w.numpy()).max() <= 1e-5 * g_w.abs().max().item()
+    if sparse:
+        assert ret["touched_frac_0"] == ret["touched_frac_1"] and 0.0 < ret["touched_frac_0"] < 1.0
+        assert ret["bytes_0"][1] < g_lat.numel() * 4          # fewer bytes travelled than the dense bucket
+        assert ret["bytes_0"] == ret["bytes_1"]
 
 
 def test_single_process_is_a_noop():

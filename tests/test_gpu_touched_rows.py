@@ -171,10 +171,11 @@ def test_block_adamw_clears_unmarked_gradients_and_rebuilds_active(dev):
     opt_b = FusedAdamW([b.lattice_values], lr=1e-3)
     # two dense steps on both (no touched-rows state yet)
     for _ in range(2):
-        for enc, opt in ((a, opt_a), (b, opt_b)):
-            enc.lattice_values.grad = None
-            _loss(enc, w1, pts, win).backward()
-            opt.step()
+        a.lattice_values.grad = None
+        _loss(a, w1, pts, win).backward()
+        b.lattice_values.grad = a.lattice_values.grad.clone()     # the SAME gradient bits (float atomics are order dependent)
+        opt_a.step()
+        opt_b.step()
     assert torch.equal(a.lattice_values, b.lattice_values)
     tr = b.enable_touched_rows()
     opt_b.attach(b.lattice_values, tr)                                # after dense steps: active must come from the moments
