@@ -70,7 +70,8 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
 /* Which kernel variant the LAST call of an operator family dispatched to (host only, no device work): lets a parity test
    assert that the configuration it compares with the oracle ran the kernels the benchmark times.  No reference counterpart.
      family 0 encode backward: 1 LDS scatter cache + atomics, 2 queue mode (binning + encode_bwd_reduce_kernel), 3 positions only
-     family 1 MLP backward   : 1 fp32-MFMA kernel, 2 split-operand kernel (mlp_bwd_split.hip), 3 wide workgroup kernel
+     family 1 MLP backward   : 1 fp32-MFMA kernel, 2 split-bf16 kernel (mlp_bwd_split.hip), 3 wide workgroup kernel,
+                               4 split-fp16 kernel (mlp_bwd_split_f16.hip)
      family 2 MLP forward    : 1 fp32-MFMA kernel, 2 split-operand kernel
    0 = no call yet, -1 = unknown family. */
 int psdf_last_path(int family);
@@ -80,6 +81,16 @@ int psdf_last_path(int family);
    pipe with split fp32 operands (three bf16 pieces, six products kept: fp32-level accuracy); -2 for every other net and when
    stream-ordered scratch is unavailable (stream capture).  psdf_mlp_backward routes large batches here by itself. */
 int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+    const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
+
+/* ---- mlp_bwd_split_f16.hip ---- */
+/* same contract as psdf_mlp_backward for dims = {K0 <= 64, 64, 64, 64, 1} with dW/db requested, computed on the fp16 matrix pipe
+   with TWO fp16 pieces per fp32 operand (three products in the chains, four in the dW products); the gradient chain of every
+   sample runs on the mantissa of its dY and the factor 2^e is restored exactly, so the accuracy does not depend on the size or
+   spread of dY (errors of a few 1e-6 of the largest entry against float64; activations / weights must stay below 65504 in
+   magnitude).  -2 for every other net and when stream-ordered scratch is unavailable.  psdf_mlp_backward routes large batches
+   here by default (PSDF_MLP_BWD_SPLIT=bf16 selects psdf_mlp_backward_split instead). */
+int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
     const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 
 /* ---- mlp_wide.hip ---- */

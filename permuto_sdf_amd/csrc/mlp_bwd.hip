@@ -36,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #include <mutex>
 #include <vector>
 
+#define PSDF_MLP_BWD_SPLIT_DEFAULT 2   // 1 = three bf16 pieces, 2 = two fp16 pieces (see psdf_mlp_backward)
 namespace psdf {
 int g_last_path[PATH_FAMILIES] = {};
 void* stream_scratch(size_t bytes, hipStream_t st) {
@@ -1150,6 +1151,9 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
 int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
                            const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
                            void* stream);    // mlp_wide.hip
+int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                                const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                                void* stream);   // mlp_bwd_split_f16.hip
 
 // Backward of psdf_mlp_forward.  weights[l] / biases[l]: the torch-layout parameters (W_l [dims[l+1], dims[l]]);
 // X [dims[0], N], dY [dims[n_layers], N] and dX [dims[0], N] (or NULL) are feature-major; dW[l] (torch layout) and
@@ -1163,15 +1167,23 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   if (N == 0) return PSDF_OK;
   if (N < 0 || !X || !weights || !biases || !dY || ((dW == nullptr) != (db == nullptr))) return PSDF_ERR_ARG;
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
-  // Large batches of the BASELINE net (<= 36 inputs, 64x3, 1 output) with parameter gradients: the split-bf16 kernel on
-  // the bf16 matrix pipe (mlp_bwd_split.hip; same contract, fp32-level accuracy).  PSDF_MLP_BWD_SPLIT=0 keeps the fp32-MFMA
-  // kernel below; -2 from the split entry (other widths, no stream-ordered scratch) falls through to it as well.
+  // Large batches of the BASELINE net (<= 64 inputs, 64x3, 1 output) with parameter gradients: the split-operand kernels on
+  // the 16-bit matrix pipes -- by default two fp16 pieces per operand (mlp_bwd_split_f16.hip: errors of a few 1e-6 of the largest
+  // entry), PSDF_MLP_BWD_SPLIT=bf16 three bf16 pieces (mlp_bwd_split.hip: fp32-level accuracy, no range restriction, 1.3x
+  // slower), =0 the fp32-MFMA kernel below; -2 from a split entry (other widths, no stream-ordered scratch) falls through.
   if (dW && N >= (1 << 18)) {
-    static const bool enabled = [] {
-      const char* v = getenv("PSDF_MLP_BWD_SPLIT");
-      return !(v && v[0] == '0');
-    }();
-    if (enabled) {
+    // PSDF_MLP_BWD_SPLIT: "0" fp32-MFMA kernel, "bf16" three bf16 pieces (mlp_bwd_split.hip), "f16" two fp16 pieces
+    // (mlp_bwd_split_f16.hip); read at every call (a getenv is nanoseconds) so that tests can A/B the variants in one process
+    const char* v = getenv("PSDF_MLP_BWD_SPLIT");
+    const int which = !v ? PSDF_MLP_BWD_SPLIT_DEFAULT : (v[0] == '0' ? 0 : (v[0] == 'f' ? 2 : 1));
+    if (which == 2) {
+      const int r = psdf_mlp_backward_split_f16(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
+      if (r != PSDF_ERR_UNSUPPORTED) {
+        psdf::g_last_path[psdf::PATH_MLP_BWD] = 4;
+        return r;
+      }
+    }
+    if (which != 0) {
       const int r = psdf_mlp_backward_split(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
       if (r != PSDF_ERR_UNSUPPORTED) {
         psdf::g_last_path[psdf::PATH_MLP_BWD] = 2;
@@ -1218,7 +1230,7 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
 //   family 0, encode backward: 1 = LDS scatter cache + float atomics (small batches), 2 = queue mode (binning launch +
 //             encode_bwd_reduce_kernel), 3 = position gradient only
 //   family 1, MLP backward   : 1 = fp32-MFMA kernel (mlp_bwd_kernel), 2 = split-bf16 kernel (mlp_bwd_split_kernel),
-//             3 = workgroup-cooperative wide kernel (mlp_wide_bwd_kernel)
+//             3 = workgroup-cooperative wide kernel (mlp_wide_bwd_kernel), 4 = split-fp16 kernel (mlp_bwd_split_f16_kernel)
 //   family 2, MLP forward    : 1 = fp32-MFMA kernel (mlp_fwd_kernel), 2 = split-bf16 kernel (mlp_fwd_split_kernel)
 // 0 = no call yet; -1 = unknown family.
 int psdf_last_path(int family) {

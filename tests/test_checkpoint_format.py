@@ -32,9 +32,9 @@ def test_round_trip_and_key_names(tmp_path):
 
 SCRIPT = r'''
 import sys, torch
-from permuto_sdf_py.models.models import SDF, NerfHash
+from permuto_sdf_py.models.models import SDF, NerfHash, RGB
 from permuto_sdf_amd import checkpoint
-from permuto_sdf_amd.train_step import BgNet, HyperParams, SdfNet
+from permuto_sdf_amd.train_step import BgNet, HyperParams, RgbNet, SdfNet
 ours = checkpoint.to_reference_keys("sdf", SdfNet(HyperParams()).state_dict())
 ref = SDF(3, None, 32, 10000).state_dict()
 assert set(ours) == set(ref), (sorted(set(ours) ^ set(ref)))
@@ -44,6 +44,20 @@ ours = checkpoint.to_reference_keys("bg", BgNet().state_dict())
 ref = NerfHash(4, None, 1).state_dict()
 assert set(ours) == set(ref), (sorted(set(ours) ^ set(ref)))
 assert all(ours[k].shape == ref[k].shape for k in ref)
+# RGB (models.py:310-404): LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3 (layers.N.weight/bias + lipshitz_bound_per_layer.N),
+# the colour lattice, the NeuS variance at volume_renderer_neus.deviation_network.variance; geom_feat_size_in = 32
+# (VolumeRenderingNeus.__init__ moves its variance network to the GPU, volume_rendering_modules.py:121: a no-op here, this is a
+# key / shape check on the CPU)
+torch.nn.Module.cuda = lambda self, *a, **k: self
+ours_net = RgbNet(HyperParams())
+ours = checkpoint.to_reference_keys("rgb", ours_net.state_dict())
+ref_net = RGB(3, None, 32, 1)
+ref = ref_net.state_dict()
+assert set(ours) == set(ref), (sorted(set(ours) ^ set(ref)))
+assert all(ours[k].shape == ref[k].shape for k in ref), [(k, tuple(ours[k].shape), tuple(ref[k].shape)) for k in ref if ours[k].shape != ref[k].shape]
+ref_net.load_state_dict(ours)                           # strict: the reference's class accepts our file contents
+back = checkpoint.from_reference_keys("rgb", ref_net.state_dict())
+ours_net.load_state_dict(back)                          # and ours accepts a file the reference wrote
 print("CKPT_OK")
 '''
 

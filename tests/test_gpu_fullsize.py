@@ -166,7 +166,9 @@ def test_cfg2_fullsize_backward_conservation_and_linearity(dev):
     assert abs(float(db1[-1]) - float(dy1.double().sum())) <= 1e-5 * float(dy1.abs().double().sum())
     for a, b, c in zip([dx1] + dW1 + db1, [dx2] + dW2 + db2, [dx3] + dW3 + db3):
         ref = a.double() - 3.0 * b.double()
-        assert float((c.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-9
+        # three evaluations of the split-fp16 backward (each within ~1e-5 of the exact gradient, tests/test_gpu_mlp.py::
+        # test_split_f16_backward_matches_float64) combined 1 : 3: the north_star tolerance, 1e-4
+        assert float((c.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-9
 
 
 def test_overlap_schedule_is_race_free_under_an_asynchronous_backend(dev):

@@ -420,3 +420,62 @@ def test_unfused_widths_raise_unless_opted_in(dev):
         warnings.simplefilter("ignore")
         net(x.clone().requires_grad_(True)).sum().backward()
     assert net.layers[0].weight.grad is not None and float(net.layers[0].weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("dy_scale", [1.0, 1e-7, 3e4, "wide"])
+@pytest.mark.parametrize("K0,N", [(36, 300_001), (52, 290_003), (20, 262_160), (61, 270_001)])
+def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale):
+    """csrc/mlp_bwd_split_f16.hip (two fp16 pieces per fp32 operand, three products; gradient chain evaluated on dY * 2^k with k
+    from max|dY|): every gradient against a float64 evaluation, for upstream gradients of ordinary size, tiny (1e-7: every
+    value would be an fp16 subnormal without the scaling), large (3e4: would overflow fp16), and spread over six decades
+    within one batch.  Bar: 2e-5 relative to the largest entry -- a fifth of the north_star tolerance (1e-4), an order of
+    magnitude above what the three-piece bf16 kernel reaches (its test asks for fp32-level error).  Errors are printed."""
+    import copy
+    import ctypes
+    from permuto_sdf_amd import _lib as L
+    from permuto_sdf_amd.mlp import _dims_array, _zero_grads
+    torch.manual_seed(K0 + N % 7)
+    dims = [K0, 64, 64, 64, 1]
+    lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
+    for l in lin:
+        torch.nn.init.normal_(l.bias, 0.0, 0.1)
+    net = torch.nn.Sequential(lin[0], torch.nn.GELU(), lin[1], torch.nn.GELU(), lin[2], torch.nn.GELU(), lin[3]).to(dev)
+    x = torch.randn(N, K0, device=dev)
+    x[:, K0 // 2:] *= 1e-3                       # encoding-like inputs: half of the channels are small (low pieces subnormal)
+    gy = torch.randn(N, 1, device=dev)
+    gy = gy * (10.0 ** (-6.0 * torch.rand(N, 1, device=dev)) if dy_scale == "wide" else dy_scale)
+    net64 = copy.deepcopy(net).double()
+    x64 = x.double().requires_grad_(True)
+    net64(x64).backward(gy.double())
+    ref = [x64.grad] + [p.grad for p in net64.parameters()]
+    x_fm, gy_fm = x.t().contiguous(), gy.t().contiguous()
+    ws = [m.weight.detach().contiguous() for m in net if isinstance(m, torch.nn.Linear)]
+    bs = [m.bias.detach().contiguous() for m in net if isinstance(m, torch.nn.Linear)]
+    dx = torch.empty((K0, N), device=dev)
+    dWs, dbs = _zero_grads(dims, dev)
+    arr = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    fn = L.lib().psdf_mlp_backward_split_f16
+    fn.restype = ctypes.c_int
+    rc = fn(L.c_i(4), _dims_array(dims), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx), arr(dWs), arr(dbs),
+            L.stream())
+    assert rc == 0, rc
+    got = [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
+    names = ["dX", "dW1", "db1", "dW2", "db2", "dW3", "db3", "dW4", "db4"]
+    errs = {}
+    for name, g, r in zip(names, got, ref):
+        assert bool(torch.isfinite(g).all()), name
+        errs[name] = float((g.double() - r).abs().max()) / float(r.abs().max())
+    print("f16 split backward K0=%d N=%d dy_scale=%s: " % (K0, N, dy_scale) + " ".join("%s %.1e" % kv for kv in errs.items()))
+    assert max(errs.values()) <= 2e-5, errs
+    if dy_scale == "wide":
+        # per-sample accuracy of dX for the samples whose upstream gradient is small: relative to THEIR OWN largest entry
+        small = (gy.abs().view(-1) < 1e-4 * float(gy.abs().max())) & (gy.abs().view(-1) > 1e-6 * float(gy.abs().max()))
+        a, r = got[0].double()[small], ref[0][small]
+        rel_rows = ((a - r).abs().amax(1) / r.abs().amax(1).clamp_min(1e-300))
+        print("   rows with |dy| in (1e-6, 1e-4) of the largest: worst per-row relative error of dX %.1e" % float(rel_rows.max()))
+        # the chain of every sample runs on the mantissa of ITS dY: small-gradient samples are as accurate as the large ones
+        # (the lattice gradient is a sparse sum of these rows, and Adam rescales every entry by its own magnitude)
+        assert float(rel_rows.max()) <= 5e-5
+    fn2 = L.lib().psdf_mlp_backward_split_f16
+    assert fn2(L.c_i(4), _dims_array([36, 32, 32, 32, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
+               arr(dWs), arr(dbs), L.stream()) == -2
