@@ -250,6 +250,12 @@ class PermutoEncoding(torch.nn.Module):
         self.random_shift_per_level = torch.nn.Parameter(shift, requires_grad=False)
         self.register_buffer("scale_factor", scale_factor_tensor(scale_per_level, pos_dim), persistent=False)
         self.register_buffer("anneal_window_ones", torch.ones(nr_levels), persistent=False)
+        # PSDF_FUSE_REFERENCE_MLPS=1: when this encoding is being built inside the constructor of a reference model, that
+        # model's Linear/GELU stacks get the fused evaluators at our first forward call (reference_fusion.py)
+        self._fuse_owner = None
+        from . import reference_fusion as RF
+        if RF.enabled():
+            self._fuse_owner = RF.owner_under_construction()
 
     def output_dims(self):
         return self.cfg.channels
@@ -283,6 +289,11 @@ class PermutoEncoding(torch.nn.Module):
         if positions.dim() != 2 or positions.shape[1] != self.pos_dim:
             raise ValueError("positions must be [N, %d], got %s" % (self.pos_dim, tuple(positions.shape)))
         L.require_cuda(positions, self.lattice_values)
+        if self._fuse_owner is not None:
+            owner, self._fuse_owner = self._fuse_owner(), None
+            if owner is not None:
+                from . import reference_fusion as RF
+                RF.fuse_model(owner, verbose=True)
         if anneal_window is None:
             anneal_window = self.anneal_window_ones
         else:

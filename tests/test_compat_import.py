@@ -54,3 +54,41 @@ def test_reference_python_imports_unmodified():
     env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "compat"), REF])
     r = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
     assert r.returncode == 0 and "COMPAT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+FUSE_SCRIPT = r'''
+import torch
+torch.nn.Module.cuda = lambda self, *a, **k: self        # VolumeRenderingNeus.__init__ calls .cuda() (volume_rendering_modules.py:121)
+from permuto_sdf_py.models.models import SDF, RGB, NerfHash
+from permuto_sdf_amd import reference_fusion as RF
+from permuto_sdf_amd.mlp import LipshitzMLP
+for make, names in ((lambda: SDF(3, None, 32, 10000), ["mlp_sdf"]), (lambda: RGB(3, None, 32, 1), ["mlp"]),
+                    (lambda: NerfHash(4, None, 1), ["mlp_feat_and_density", "mlp_rgb"])):
+    m = make()
+    assert m.encoding._fuse_owner is not None and m.encoding._fuse_owner() is m     # the owner was found on the stack
+    keys, ids = list(m.state_dict().keys()), {k: id(p) for k, p in m.named_parameters()}
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    assert RF.fuse_model(m) == names, names
+    assert list(m.state_dict().keys()) == keys                    # checkpoint keys unchanged
+    assert {k: id(p) for k, p in m.named_parameters()} == ids     # the very same Parameter objects (optimisers keep working)
+    assert all(torch.equal(v, sd[k]) for k, v in m.state_dict().items())
+    for n in names:
+        sub = getattr(m, n)
+        assert isinstance(sub, (RF.FusedSequential, LipshitzMLP)), type(sub)
+        if isinstance(sub, RF.FusedSequential):
+            assert sub.fused, (n, sub.dims)                       # every Sequential of the reference has a fused kernel
+    make().load_state_dict(m.state_dict())                        # a fused model's checkpoint loads into an unfused one
+    assert RF.fuse_model(m) == []                                 # idempotent
+print("FUSE_OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "permuto_sdf_py")), reason="reference checkout not present")
+def test_fusion_hook_keeps_parameters_and_checkpoint_keys():
+    """PSDF_FUSE_REFERENCE_MLPS=1 on the reference's real model classes (CPU: bookkeeping only; numerics are a GPU test,
+    tests/test_gpu_reference_call_patterns.py::test_fused_evaluators_behind_reference_style_models)"""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "compat"), REF])
+    env["PSDF_FUSE_REFERENCE_MLPS"] = "1"
+    r = subprocess.run([sys.executable, "-c", FUSE_SCRIPT], capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
+    assert r.returncode == 0 and "FUSE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

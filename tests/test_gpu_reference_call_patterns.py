@@ -313,3 +313,105 @@ def test_importance_sampling_sequence_with_views(world, port, dev):
         if not last:
             # the merged container carries the SDF of both sources at the merged positions
             assert torch.allclose(rs.samples_sdf, rs.samples_pos.norm(dim=1, keepdim=True) - 0.3, atol=2e-6)
+
+
+def test_fused_evaluators_behind_reference_style_models(dev, monkeypatch):
+    """PSDF_FUSE_REFERENCE_MLPS=1 (permuto_sdf_amd/reference_fusion.py): a model class built like the reference's `SDF`
+    (models.py:132-203: encoding constructed first inside __init__, then a Linear/GELU nn.Sequential, forward = encoding ->
+    mlp) gets its Sequential swapped for the fused evaluator at the first forward -- same Parameters, same state_dict keys --
+    and sdf, its input gradient (create_graph=True, models.py:236-251) and every parameter gradient of an eikonal-style loss
+    equal the unfused torch evaluation within 1e-4.  A reference-style LipshitzMLP owner (`RGB`) is swapped as well."""
+    import numpy as np
+    import permutohedral_encoding as permuto_enc
+    from permuto_sdf_amd import reference_fusion as RF
+    from permuto_sdf_amd.mlp import LipshitzMLP as OurLipshitz
+
+    class SDF(torch.nn.Module):        # the name is what the owner detection looks for
+        def __init__(self):
+            super().__init__()
+            self.encoding = permuto_enc.PermutoEncoding(3, 2 ** 14, 24, 2, np.geomspace(1.0, 1e-3, 24), appply_random_shift_per_level=True,
+                                                        concat_points=True, concat_points_scaling=1e-3)
+            self.mlp_sdf = torch.nn.Sequential(torch.nn.Linear(self.encoding.output_dims(), 32), torch.nn.GELU(), torch.nn.Linear(32, 32),
+                                               torch.nn.GELU(), torch.nn.Linear(32, 32), torch.nn.GELU(), torch.nn.Linear(32, 33))
+            self.c2f = permuto_enc.Coarse2Fine(24)
+
+        def forward(self, points):
+            return self.mlp_sdf(self.encoding(points, self.c2f(0.9).view(-1)))
+
+    def run(model, pts0):
+        for p in model.parameters():
+            p.grad = None
+        pts = pts0.clone().requires_grad_(True)
+        y = model(pts)
+        sdf = y[:, 0:1]
+        (g,) = torch.autograd.grad(sdf, pts, torch.ones_like(sdf), create_graph=True)
+        loss = sdf.abs().mean() + ((g.norm(dim=1) - 1.0) ** 2).mean() + 0.1 * y[:, 1:].pow(2).mean()
+        loss.backward()
+        return y.detach().clone(), g.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    torch.manual_seed(0)
+    pts = (torch.rand(6000, 3, device=dev) - 0.5) * 0.8
+    monkeypatch.delenv("PSDF_FUSE_REFERENCE_MLPS", raising=False)
+    plain = SDF().to(dev)
+    with torch.no_grad():
+        plain.encoding.lattice_values.mul_(1e3)           # visible feature magnitudes
+    y0, g0, grads0 = run(plain, pts)
+    assert type(plain.mlp_sdf) is torch.nn.Sequential
+    monkeypatch.setenv("PSDF_FUSE_REFERENCE_MLPS", "1")
+    fused = SDF().to(dev)
+    keys = list(fused.state_dict().keys())
+    fused.load_state_dict(plain.state_dict())
+    params_before = {k: id(p) for k, p in fused.named_parameters()}
+    y1, g1, grads1 = run(fused, pts)
+    assert isinstance(fused.mlp_sdf, RF.FusedSequential) and fused.mlp_sdf.fused
+    assert list(fused.state_dict().keys()) == keys                                   # checkpoints are untouched
+    assert {k: id(p) for k, p in fused.named_parameters()} == params_before          # an optimiser built before keeps working
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(y1, y0) < 1e-4 and rel(g1, g0) < 1e-4, (rel(y1, y0), rel(g1, g0))
+    assert set(grads1) == set(grads0)
+    for k in grads0:
+        assert rel(grads1[k], grads0[k]) < 1e-4, (k, rel(grads1[k], grads0[k]))
+
+    # LipshitzMLP owner: a module that looks like the reference's class is replaced by ours, Parameters shared
+    class LipshitzMLP(torch.nn.Module):
+        def __init__(self, cin, outs, last_layer_linear):
+            super().__init__()
+            self.last_layer_linear = last_layer_linear
+            self.layers = torch.nn.ModuleList()
+            for c in outs:
+                self.layers.append(torch.nn.Linear(cin, c))
+                cin = c
+            self.weights_per_layer = torch.nn.ParameterList([l.weight for l in self.layers])
+            self.biases_per_layer = torch.nn.ParameterList([l.bias for l in self.layers])
+            self.lipshitz_bound_per_layer = torch.nn.ParameterList(
+                [torch.nn.Parameter(torch.ones(1) * l.weight.abs().sum(1).max().item() * 0.5) for l in self.layers])
+
+        def forward(self, x):
+            for i, l in enumerate(self.layers):
+                c = torch.nn.functional.softplus(self.lipshitz_bound_per_layer[i])
+                w = l.weight * torch.clamp(c / l.weight.abs().sum(1), max=1.0)[:, None]
+                x = torch.nn.functional.linear(x, w, l.bias)
+                if i < len(self.layers) - 1:
+                    x = torch.nn.functional.gelu(x)
+            return x
+
+    class RGB(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = LipshitzMLP(111, [128, 128, 64, 3], True)
+
+    net = RGB().to(dev)
+    x = torch.randn(4000, 111, device=dev)
+    ref_out = net.mlp(x)
+    ref_out.pow(2).sum().backward()
+    ref_grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    keys = list(net.state_dict().keys())
+    assert RF.fuse_model(net) == ["mlp"] and isinstance(net.mlp, OurLipshitz)
+    assert list(net.state_dict().keys()) == keys
+    out = net.mlp(x)
+    out.pow(2).sum().backward()
+    assert rel(out.detach(), ref_out.detach()) < 1e-4
+    for k, p in net.named_parameters():
+        assert rel(p.grad, ref_grads[k]) < 2e-4, k

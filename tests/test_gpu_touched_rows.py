@@ -177,6 +177,7 @@ def test_block_adamw_clears_unmarked_gradients_and_rebuilds_active(dev):
         opt_a.step()
         opt_b.step()
     assert torch.equal(a.lattice_values, b.lattice_values)
+    b.lattice_values.grad = None                                      # (zero_grad: a stale .grad would be folded in again)
     tr = b.enable_touched_rows()
     opt_b.attach(b.lattice_values, tr)                                # after dense steps: active must come from the moments
     st = opt_b.state[b.lattice_values]
