@@ -42,22 +42,26 @@ def from_reference_keys(kind, state_dict):
     return out
 
 
-def save(folder, sdf=None, rgb=None, bg=None, grid=None):
+def save(folder, sdf=None, rgb=None, bg=None, grid=None, colorcal=None):
     """writes the reference's file set into `folder` (the reference's <ckpt>/<experiment>/<iter>/models directory)"""
     os.makedirs(folder, exist_ok=True)
     for kind, model in (("sdf", sdf), ("rgb", rgb), ("bg", bg)):
         if model is not None:
             torch.save(to_reference_keys(kind, model.state_dict()), os.path.join(folder, FILES[kind]))
+    if colorcal is not None:      # models.py:753-760: colorcal_model.pt, keys weight_delta / bias
+        torch.save(colorcal.state_dict(), os.path.join(folder, "colorcal_model.pt"))
     if grid is not None:
         torch.save(grid.get_grid_values(), os.path.join(folder, "grid_values.pt"))
         torch.save(grid.get_grid_occupancy(), os.path.join(folder, "grid_occupancy.pt"))
 
 
-def load(folder, sdf=None, rgb=None, bg=None, grid=None, map_location=None, strict=True):
+def load(folder, sdf=None, rgb=None, bg=None, grid=None, colorcal=None, map_location=None, strict=True):
     for kind, model in (("sdf", sdf), ("rgb", rgb), ("bg", bg)):
         if model is not None:
             sd = torch.load(os.path.join(folder, FILES[kind]), map_location=map_location)
             model.load_state_dict(from_reference_keys(kind, sd), strict=strict)
+    if colorcal is not None:
+        colorcal.load_state_dict(torch.load(os.path.join(folder, "colorcal_model.pt"), map_location=map_location), strict=strict)
     if grid is not None:
         grid.set_grid_values(torch.load(os.path.join(folder, "grid_values.pt"), map_location=map_location))
         grid.set_grid_occupancy(torch.load(os.path.join(folder, "grid_occupancy.pt"), map_location=map_location))

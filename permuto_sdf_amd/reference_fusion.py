@@ -82,6 +82,7 @@ def fuse_lipshitz(ref):
     ours.biases_per_layer = torch.nn.ParameterList([l.bias for l in ours.layers])
     ours.lipshitz_bound_per_layer = torch.nn.ParameterList(list(ref.lipshitz_bound_per_layer))
     ours.allow_torch_fallback = True
+    ours.__dict__["_reference_module"] = ref      # not registered as a sub-module: unfuse_model() hands it back
     return ours
 
 
@@ -101,6 +102,19 @@ def fuse_model(model, verbose=False):
                 done.append(name)
     if verbose and done:
         print("[permuto_sdf_amd] fused evaluators behind %s: %s" % (type(model).__name__, ", ".join(done)), file=sys.stderr)
+    return done
+
+
+def unfuse_model(model):
+    """undo fuse_model (same Parameters again): for A/B comparisons of the fused and the torch evaluation of one set of weights"""
+    done = []
+    for name, child in list(model.named_children()):
+        if isinstance(child, FusedSequential):
+            setattr(model, name, torch.nn.Sequential(*list(child)))
+            done.append(name)
+        elif isinstance(child, M.LipshitzMLP) and "_reference_module" in child.__dict__:
+            setattr(model, name, child.__dict__["_reference_module"])
+            done.append(name)
     return done
 
 

@@ -12,12 +12,16 @@ restated on this repository's operators -- same order of operations, same hyper-
   gradient all-reduce (RCCL) overlapped with nothing it depends on; fused AdamW; every 8th step the occupancy grid is
   refreshed from 262 144 random voxel centres (same seed on every rank: replicas stay identical without communication).
 
-Not carried over from the reference's loop (they act after tens of thousands of iterations and do not change the cost of a
-step): the learning-rate warm-up / MultiStepLR decay (train_permuto_sdf.py:305,419-423), the weight-decay switch of the
-colour lattice and the eikonal weight change at iteration 50 000 (:400-406), the colour calibration module (:270-273), and
-the sphere-initialisation phase (:322-326).  The occupancy refresh runs after the optimiser step here, before it there
-(:383-391): the grid sees the parameters one step later.  Network initialisation follows the reference (leaky_relu_init,
-common_utils.py:248-293; sdf_shift added to the whole last bias vector, models.py:163-165).
+The reference's schedule is part of the trainer (round 3; `Trainer(..., reference_schedule=True)`): the sphere-initialisation
+phase (train_permuto_sdf.py:322-330, loss_sphere_init permuto_sdf_utils.py:53-77: 30 000 points, 3e3 * sdf error + 5e1 * eikonal)
+for `nr_iter_sphere_fit` iterations, then the linear learning-rate warm-up over 3 000 iterations followed by MultiStepLR (gamma
+0.3 at the milestones, counted from the end of the warm-up: :304,419-422, schedulers/warmup.py, multisteplr.py -- `lr_schedule`
+below is their closed form), the switch at `iter_start_reduce_curv` (weight decay 1.0 on the colour lattice, eikonal weight 0.01:
+:400-405), the colour calibration module (`Colorcal`, models.py:678-730; weight decay 0.1, :299) applied to foreground and
+background colours before the sigmoid, and the occupancy refresh BEFORE the backward / optimiser step of its iteration
+(:383-391).  With `reference_schedule=False` (tools/train_bench.py: the steady-state step of BASELINE config 4) the sphere phase,
+the warm-up and the calibration module are left out; everything else is the same code.  Network initialisation follows the
+reference (leaky_relu_init, common_utils.py:248-293; sdf_shift added to the whole last bias vector, models.py:163-165).
 
 Differences from the reference, all structural: no-grad SDF evaluations run in the fused single-launch evaluator with
 a 1-row head (csrc/fused.hip); the samplers are exact-size (no second compaction pass); the per-step ray count adapts
@@ -59,6 +63,33 @@ class HyperParams:
     sdf_geom_feat_size = 32
     sdf_nr_iters_for_c2f = 10000
     target_nr_of_samples = 512 * (64 + 16 + 16)
+    # the schedule (train_permuto_sdf.py:80,89-90,98; warm-up length :420)
+    nr_iter_sphere_fit = 4000
+    lr_warmup_iters = 3000
+    lr_milestones = (100000, 150000, 180000, 190000)
+    lr_gamma = 0.3
+    iter_finish_training = 200000
+    use_color_calibration = True
+    eikonal_weight_late = 0.01           # from iter_start_reduce_curv on (:405)
+    rgb_lattice_weight_decay_late = 1.0  # (:402-403)
+    colorcal_weight_decay = 1e-1         # (:299)
+
+
+def lr_schedule(global_iter, hp):
+    """Learning rate the optimiser step of iteration `global_iter` (0-based, sphere phase included) runs with: the closed form
+    of what the reference's scheduler objects do (train_permuto_sdf.py:304,419-422).  Through iteration nr_iter_sphere_fit the
+    base rate; GradualWarmupScheduler(multiplier=1, total_epoch=W) is created right after that step (its constructor already
+    steps once, to 0) and stepped after every later one: iteration n0 + k runs at base * k / W for k <= W, at base for
+    k = W + 1 (the hand-over), and MultiStepLR -- constructed at start-up, stepped only from then on -- has counted
+    m = k - (W + 1) epochs: base * gamma^(number of milestones <= m)."""
+    n0, W = int(hp.nr_iter_sphere_fit), int(hp.lr_warmup_iters)
+    if global_iter <= n0:
+        return hp.lr
+    k = global_iter - n0
+    if k <= W:
+        return hp.lr * (float(k) / W)
+    m = k - (W + 1)
+    return hp.lr * hp.lr_gamma ** sum(1 for ms in hp.lr_milestones if ms <= m)
 
 
 def map_range_val(v, in_lo, in_hi, out_lo, out_hi):
@@ -212,12 +243,14 @@ class RgbNet(torch.nn.Module):
         self.last_inv_s = None
         self.register_buffer("_win", torch.ones(24), persistent=False)  # rgb_nr_iters_for_c2f = 1: window is 1 from the first step
 
-    def forward(self, points, dirs, sdf_gradients, geom_feat):
+    def forward(self, points, dirs, sdf_gradients, geom_feat, colorcal=None, img_indices=None, ray_start_end_idx=None):
         win = self._win
         with torch.no_grad():
             sh = PermutoSDF.spherical_harmonics(dirs, 5)
-        x = cat_fm([self.encoding(points, win), sh, normalize3(sdf_gradients), geom_feat])
-        return torch.sigmoid(self.mlp(x))
+        x = self.mlp(cat_fm([self.encoding(points, win), sh, normalize3(sdf_gradients), geom_feat]))
+        if colorcal is not None:      # models.py:384-385
+            x = colorcal.calib_RGB_samples_packed(x, img_indices, ray_start_end_idx)
+        return torch.sigmoid(x)
 
     def neus_weights(self, rs, sdf, gradients, cos_anneal_ratio, forced_variance):  # volume_rendering_modules.py:129-174
         v = self.variance if forced_variance is None else torch.tensor(float(forced_variance), device=sdf.device)
@@ -244,12 +277,14 @@ class BgNet(torch.nn.Module):
         self.mlp_rgb = FusedMLP([64 + 16, 64, 64, 3], reference_init=True)
         self.register_buffer("_win", torch.ones(24), persistent=False)
 
-    def forward(self, pos4d, dirs):
+    def forward(self, pos4d, dirs, colorcal=None, img_indices=None, ray_start_end_idx=None):
         win = self._win
         with torch.no_grad():
             sh = PermutoSDF.spherical_harmonics(dirs, 4)
         fd = self.mlp_feat_and_density(self.encoding(pos4d, win))
         rgb = self.mlp_rgb(cat_fm([F.gelu(fd[:, 1:65]), sh]))
+        if colorcal is not None:      # models.py:523-524
+            rgb = colorcal.calib_RGB_samples_packed(rgb, img_indices, ray_start_end_idx)
         return torch.sigmoid(rgb), fd[:, 0:1]     # colour, RAW density: softplus (models.py:520) is fused into nerf_weights
 
     @staticmethod
@@ -257,6 +292,26 @@ class BgNet(torch.nn.Module):
         alpha, one_minus = nerf_alpha(raw_density, rs.samples_dt)
         T, bg = _Cumprod.apply(rs, one_minus)
         return (alpha * T).view(-1, 1)
+
+
+class Colorcal(torch.nn.Module):
+    """models.py:678-730: per-image affine colour calibration of the predicted sample colours, rgb * (1 + weight_delta[img]) +
+    bias[img]; image `idx_with_fixed_calib` keeps the identity.  Parameter names as in the reference (colorcal_model.pt)."""
+
+    def __init__(self, nr_cams, idx_with_fixed_calib=0):
+        super().__init__()
+        self.idx_with_fixed_calib = idx_with_fixed_calib
+        self.weight_delta = torch.nn.Parameter(torch.zeros(nr_cams, 3))
+        self.bias = torch.nn.Parameter(torch.zeros(nr_cams, 3))
+
+    def calib_RGB_samples_packed(self, rgb_samples, per_pixel_img_indices, ray_start_end_idx):
+        from .bridge import RaySamplesPacked
+        idx = per_pixel_img_indices.long()
+        fixed = (idx == self.idx_with_fixed_calib)[:, None]
+        w = torch.where(fixed, torch.ones_like(self.weight_delta[:1]), 1.0 + self.weight_delta.index_select(0, idx))
+        b = torch.where(fixed, torch.zeros_like(self.bias[:1]), self.bias.index_select(0, idx))
+        ray = RaySamplesPacked.compute_per_sample_ray_idx(ray_start_end_idx, rgb_samples.shape[0]).long()
+        return rgb_samples * w.index_select(0, ray) + b.index_select(0, ray)
 
 
 class SyntheticReel:
@@ -282,15 +337,29 @@ class SyntheticReel:
 
 # ------------------------------------------------------------------------------------------------------ trainer
 class Trainer:
-    def __init__(self, device, hp=None, seed=0, touched_rows=True):
+    def __init__(self, device, hp=None, seed=0, touched_rows=True, reference_schedule=False, nr_images=49):
+        """reference_schedule: run the reference's whole schedule (sphere phase, LR warm-up / decay, late switches, colour
+        calibration over `nr_images` cameras: see the module docstring); False = the steady-state step only."""
         self.hp = hp or HyperParams()
         self.dev = torch.device(device)
+        self.reference_schedule = bool(reference_schedule)
         torch.manual_seed(seed)  # identical replicas on every rank
         self.sdf, self.rgb, self.bg = SdfNet(self.hp).to(self.dev), RgbNet(self.hp).to(self.dev), BgNet().to(self.dev)
+        self.colorcal = (Colorcal(nr_images, 0).to(self.dev)
+                         if (self.reference_schedule and self.hp.use_color_calibration) else None)
         self.sphere = Sphere(0.5, [0, 0, 0])
         self.grid = OccupancyGrid(256, 1.0, [0, 0, 0], device=self.dev)
-        self.params = [p for m in (self.sdf, self.rgb, self.bg) for p in m.parameters() if p.requires_grad]
-        self.opt = FusedAdamW(self.params, lr=self.hp.lr, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+        # parameter groups as in train_permuto_sdf.py:293-299: the colour lattice has its own (its weight decay is switched on
+        # late), the calibration module decays from the start
+        rgb_lat = self.rgb.encoding.lattice_values
+        base = [p for m in (self.sdf, self.rgb, self.bg) for p in m.parameters() if p.requires_grad and p is not rgb_lat]
+        groups = [{"params": base, "weight_decay": 0.0, "name": "base"},
+                  {"params": [rgb_lat], "weight_decay": 0.0, "name": "model_rgb_only_encoding"}]
+        if self.colorcal is not None:
+            groups.append({"params": list(self.colorcal.parameters()), "weight_decay": self.hp.colorcal_weight_decay,
+                           "name": "model_colorcal"})
+        self.params = [p for g in groups for p in g["params"]]
+        self.opt = FusedAdamW(groups, lr=self.hp.lr, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
         # touched-rows path for the three 50-MB lattices (SURVEY 8f-3): persistent gradient buffers that all backward calls
         # of the step accumulate into, AdamW + zero-fill only over row blocks that are touched or carry non-zero moments
         self.touched = []
@@ -304,6 +373,7 @@ class Trainer:
         self.grad_buffers = [self.sdf.mlp_sdf.enable_grad_buffer()] if touched_rows else []
         self.nr_rays = self.hp.nr_rays
         self.iter = 0
+        self._late_seen = False       # set by the first iteration at / after iter_start_reduce_curv (acts from the next one on)
         self.last = {}
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
         self._seed = seed + 1
@@ -321,11 +391,13 @@ class Trainer:
     # ---- checkpoints in the reference's file layout (permuto_sdf_utils.py:222-237)
     def save_checkpoint(self, folder):
         from . import checkpoint
-        checkpoint.save(folder, sdf=self.sdf, rgb=self.rgb, bg=self.bg, grid=self.grid)
+        checkpoint.save(folder, sdf=self.sdf, rgb=self.rgb, bg=self.bg, grid=self.grid, colorcal=self.colorcal)
 
     def load_checkpoint(self, folder):
+        import os
         from . import checkpoint
-        checkpoint.load(folder, sdf=self.sdf, rgb=self.rgb, bg=self.bg, grid=self.grid, map_location=self.dev)
+        cc = self.colorcal if os.path.exists(os.path.join(folder, "colorcal_model.pt")) else None
+        checkpoint.load(folder, sdf=self.sdf, rgb=self.rgb, bg=self.bg, grid=self.grid, colorcal=cc, map_location=self.dev)
 
     # ---- sampling (no grad): nerf_utils.py:502-525 + sdf_utils.py:383-423
     @torch.no_grad()
@@ -354,44 +426,82 @@ class Trainer:
         return fg, bg
 
     # ---- run_net: train_permuto_sdf.py:111-169
-    def _render(self, o, d, it, cos_anneal_ratio, forced_variance, jitter=True):
+    def _render(self, o, d, it, cos_anneal_ratio, forced_variance, jitter=True, img_indices=None):
         """`jitter` = the reference's `model.training` flag (nerf_utils.py:507, sdf_utils.py:401): False in eval mode"""
         fg, bg = self._samples(o, d, it, jitter)
+        cc = self.colorcal if img_indices is not None else None
         R = o.shape[0]
         if fg.samples_pos.shape[0] == 0:
             pred = torch.zeros(R, 3, device=self.dev)
             sdf_grad, bgT = torch.zeros(0, 3, device=self.dev), torch.ones(R, 1, device=self.dev)
         else:
             sdf, sdf_grad, feat = self.sdf.sdf_and_gradient(fg.samples_pos, it)
-            rgb = self.rgb(fg.samples_pos, fg.samples_dirs, sdf_grad, feat)
+            rgb = self.rgb(fg.samples_pos, fg.samples_dirs, sdf_grad, feat, cc, img_indices, fg.ray_start_end_idx)
             w, _, bgT = self.rgb.neus_weights(fg, sdf, sdf_grad, cos_anneal_ratio, forced_variance)
             pred = _Integrate.apply(fg, rgb, w)
-        rgb_bg, dens = self.bg(bg.samples_pos_4d, bg.samples_dirs)
+        rgb_bg, dens = self.bg(bg.samples_pos_4d, bg.samples_dirs, cc, img_indices, bg.ray_start_end_idx)
         pred = pred + bgT.view(-1, 1) * _Integrate.apply(bg, rgb_bg, BgNet.nerf_weights(bg, dens.view(-1, 1)))
         return pred, sdf_grad, fg
 
+    def _sphere_init_loss(self, it):
+        """loss_sphere_init (permuto_sdf_utils.py:53-77 -> sdf_utils.py:60-83, dataset dtu): fit the SDF of a radius-0.3 sphere
+        at 30 000 random points of the bounding sphere, 3e3 * mean squared SDF error + 5e1 * eikonal"""
+        pts = self.sphere.rand_points_inside(30000)
+        sdf, grad, _ = self.sdf.sdf_and_gradient(pts, it)
+        dists = pts.norm(dim=-1, keepdim=True) - 0.3
+        return ((sdf - dists) ** 2).mean() * 3e3 + eikonal_loss(grad) * 5e1
+
     def step(self, reel):
         """one optimisation step; returns the loss (device tensor, no sync)"""
-        hp, it = self.hp, self.iter
-        torch.manual_seed(parallel.step_seed(self._seed, parallel.rank(), it))  # this rank's rays / jitter
-        cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
-        forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
-        with torch.no_grad():
-            o, d, gt, _, _ = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
-            _, _, _, _, hit = self.sphere.ray_intersection(o, d)
-        pred, sdf_grad, fg = self._render(o, d, it, cos_anneal_ratio, forced_variance)
-        loss = l1_loss(pred, gt, hit)                                                          # rgb_loss, one launch
-        n_fg = fg.samples_pos.shape[0]
-        if n_fg:
-            loss = loss + eikonal_loss(sdf_grad) * hp.eikonal_weight
-            gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
-            if gw > 0.0:
-                loss = loss + self.sdf.curvature(fg.samples_pos, sdf_grad, it) * (hp.curvature_weight * gw)
-        off = self.sphere.rand_points_inside(1024)
-        sdf_off, _ = self.sdf(off, it)
-        loss = loss + offsurface_loss(sdf_off, 1e2) * hp.offsurface_weight
-        if it >= hp.iter_start_reduce_curv:
-            loss = loss + self.rgb.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
+        hp, git = self.hp, self.iter                                  # git: global iteration (sphere phase included)
+        n0 = int(hp.nr_iter_sphere_fit) if self.reference_schedule else 0
+        in_sphere_init = git < n0
+        it = git if in_sphere_init else git - n0                      # iter_nr_for_anneal (permuto_sdf_utils.py:80-88)
+        torch.manual_seed(parallel.step_seed(self._seed, parallel.rank(), git))  # this rank's rays / jitter
+        late = (not in_sphere_init) and it >= hp.iter_start_reduce_curv
+        for group in self.opt.param_groups:
+            if self.reference_schedule:
+                group["lr"] = lr_schedule(git, hp)
+            if group.get("name") == "model_rgb_only_encoding":        # train_permuto_sdf.py:400-403: set before the optimiser
+                group["weight_decay"] = hp.rgb_lattice_weight_decay_late if late else 0.0   # step of the same iteration
+        # (:405) the reference lowers hyperparams.eikonal_weight AFTER this iteration's loss was built: from the next one on
+        eikonal_weight = hp.eikonal_weight_late if self._late_seen else hp.eikonal_weight
+        n_fg, nr_rays_used = 0, 0
+        if in_sphere_init:
+            loss = self._sphere_init_loss(it)
+        else:
+            cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
+            forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
+            with torch.no_grad():
+                o, d, gt, _, img_idx = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
+                _, _, _, _, hit = self.sphere.ray_intersection(o, d)
+            nr_rays_used = o.shape[0]
+            pred, sdf_grad, fg = self._render(o, d, it, cos_anneal_ratio, forced_variance,
+                                              img_indices=img_idx if self.colorcal is not None else None)
+            loss = l1_loss(pred, gt, hit)                                                      # rgb_loss, one launch
+            n_fg = fg.samples_pos.shape[0]
+            if n_fg:
+                loss = loss + eikonal_loss(sdf_grad) * eikonal_weight
+                gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
+                if gw > 0.0:
+                    loss = loss + self.sdf.curvature(fg.samples_pos, sdf_grad, it) * (hp.curvature_weight * gw)
+            off = self.sphere.rand_points_inside(1024)
+            sdf_off, _ = self.sdf(off, it)
+            loss = loss + offsurface_loss(sdf_off, 1e2) * hp.offsurface_weight
+            if it >= hp.iter_start_reduce_curv:
+                loss = loss + self.rgb.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
+            # ---- occupancy refresh, every 8th step, BEFORE this iteration's backward / optimiser step as in the reference
+            # (train_permuto_sdf.py:383-391); the same random voxels on every rank
+            with torch.no_grad():
+                if git % 8 == 0:
+                    torch.manual_seed(977 + git)
+                    centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
+                    inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
+                    self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it), inv_s.view(1), 1e-4)
+                if n_fg:  # adaptive ray count (train_permuto_sdf.py:393-397); the count is already on the host
+                    self.nr_rays = max(64, min(8192, int(self.nr_rays * hp.target_nr_of_samples / n_fg)))
+            if late:
+                self._late_seen = True
         # ---- backward, all-reduce, optimiser
         for p in self.params:
             p.grad = None
@@ -417,15 +527,7 @@ class Trainer:
         self.opt.step(grad_scale=1.0 / parallel.world_size())
         for gb in self.grad_buffers:
             gb.zero()
-        # ---- occupancy refresh, every 8th step, same random voxels on every rank (train_permuto_sdf.py:386-391)
-        with torch.no_grad():
-            if it % 8 == 0:
-                torch.manual_seed(977 + it)
-                centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
-                inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
-                self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it), inv_s.view(1), 1e-4)
-            if n_fg:  # adaptive ray count (train_permuto_sdf.py:393-397); the count is already on the host
-                self.nr_rays = max(64, min(8192, int(self.nr_rays * hp.target_nr_of_samples / n_fg)))
         self.iter += 1
-        self.last = {"nr_rays": o.shape[0], "nr_fg_samples": n_fg}
+        self.last = {"nr_rays": nr_rays_used, "nr_fg_samples": n_fg, "lr": self.opt.param_groups[0]["lr"],
+                     "phase": "sphere_init" if in_sphere_init else "train"}
         return loss.detach()

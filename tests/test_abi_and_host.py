@@ -184,3 +184,51 @@ def test_step_seeds_are_injective_in_rank_and_iteration():
     for world in (1, 2, 8):
         seeds = {parallel.step_seed(5, r, it, world) for r in range(world) for it in range(64)}
         assert len(seeds) == world * 64
+
+
+def test_lr_schedule_is_the_closed_form_of_the_reference_schedulers():
+    """train_step.lr_schedule against the reference's own scheduler objects used the way train_permuto_sdf.py:304,419-422 uses
+    them (MultiStepLR built at start-up, GradualWarmupScheduler built right after the step of iteration nr_iter_sphere_fit and
+    stepped after every later one).  The scheduler classes are restated here in their torch form (torch's MultiStepLR has the
+    chainable get_lr the reference's copy has, multisteplr.py:51-57; the warm-up class follows warmup.py:17-58 line by line)."""
+    import torch
+    from torch.optim.lr_scheduler import LRScheduler, MultiStepLR
+    from permuto_sdf_amd.train_step import HyperParams, lr_schedule
+
+    class GradualWarmup(LRScheduler):          # schedulers/warmup.py (multiplier = 1 branch)
+        def __init__(self, optimizer, total_epoch, after_scheduler):
+            self.total_epoch, self.after_scheduler, self.finished = total_epoch, after_scheduler, False
+            super().__init__(optimizer)
+
+        def get_lr(self):
+            if self.last_epoch > self.total_epoch:
+                if not self.finished:
+                    self.after_scheduler.base_lrs = list(self.base_lrs)
+                    self.finished = True
+                return self.after_scheduler.get_last_lr()
+            return [b * (float(self.last_epoch) / self.total_epoch) for b in self.base_lrs]
+
+        def step(self, epoch=None):
+            if self.finished and self.after_scheduler:
+                self.after_scheduler.step()
+                self._last_lr = self.after_scheduler.get_last_lr()
+            else:
+                super().step()
+
+    hp = HyperParams()
+    hp.nr_iter_sphere_fit, hp.lr_warmup_iters, hp.lr_milestones, hp.iter_finish_training = 5, 7, (4, 9, 11), 40
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=hp.lr)
+    decay = MultiStepLR(opt, milestones=list(hp.lr_milestones), gamma=hp.lr_gamma)
+    warm = None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(hp.iter_finish_training):
+            assert abs(opt.param_groups[0]["lr"] - lr_schedule(it, hp)) <= 1e-12 * hp.lr, (it, opt.param_groups[0]["lr"], lr_schedule(it, hp))
+            opt.step()
+            if it == hp.nr_iter_sphere_fit:
+                warm = GradualWarmup(opt, hp.lr_warmup_iters, decay)
+            if it >= hp.nr_iter_sphere_fit:
+                warm.step()
+    assert lr_schedule(hp.iter_finish_training, hp) == hp.lr * hp.lr_gamma ** 3

@@ -37,6 +37,20 @@ sched = GradualWarmupScheduler(opt, multiplier=1, total_epoch=3, after_scheduler
 for _ in range(12):
     opt.step(); sched.step()
 assert 0 < opt.param_groups[0]["lr"] < 1e-3
+# train_step.lr_schedule == these scheduler objects driven the way train_permuto_sdf.py:304,419-422 drives them
+from permuto_sdf_amd.train_step import HyperParams, lr_schedule
+hp = HyperParams()
+hp.nr_iter_sphere_fit, hp.lr_warmup_iters, hp.lr_milestones = 5, 7, (4, 9, 11)
+q = torch.nn.Parameter(torch.zeros(3))
+opt2 = torch.optim.AdamW([q], lr=hp.lr)
+decay = MultiStepLR(opt2, milestones=list(hp.lr_milestones), gamma=0.3, verbose=False)
+for it in range(40):
+    assert abs(opt2.param_groups[0]["lr"] - lr_schedule(it, hp)) < 1e-15, (it, opt2.param_groups[0]["lr"], lr_schedule(it, hp))
+    opt2.step()
+    if it == hp.nr_iter_sphere_fit:
+        warm = GradualWarmupScheduler(opt2, multiplier=1, total_epoch=hp.lr_warmup_iters, after_scheduler=decay)
+    if it >= hp.nr_iter_sphere_fit:
+        warm.step()
 # the training script itself: everything up to the first CUDA call at module level must import
 try:
     importlib.import_module("permuto_sdf_py.train_permuto_sdf")

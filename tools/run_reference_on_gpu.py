@@ -189,6 +189,20 @@ def main():
         "fg_samples_trainer": int(fg2.samples_pos.shape[0]),
         "same_sample_count": int(fg.samples_pos.shape[0]) == int(fg2.samples_pos.shape[0])}
     print("[run_net vs Trainer._render]", log["run_net_vs_trainer_render"], flush=True)
+    # ---- PSDF_FUSE_REFERENCE_MLPS=1: which sub-modules of the reference's models run on the fused evaluators, and the same
+    # run_net with the SAME weights on torch's own Linear / GELU evaluation (the fusion undone), for the 1e-4 bar
+    from permuto_sdf_amd import reference_fusion as RF
+    log["fused_modules"] = {n: {k: type(c).__module__ + "." + type(c).__name__ for k, c in m.named_children()
+                                if k.startswith("mlp")} for n, m in (("sdf", model_sdf), ("rgb", model_rgb), ("bg", model_bg))}
+    if RF.enabled():
+        undone = [RF.unfuse_model(m) for m in (model_sdf, model_rgb, model_bg)]
+        pred_u = T.run_net(Args, hp, o, d, img_idx, model_sdf, model_rgb, model_bg, None, grid, it_eval, cos_anneal, forced_var)[0]
+        for m in (model_sdf, model_rgb, model_bg):
+            RF.fuse_model(m)
+        du = (pred_u.detach() - pred_rgb.detach()).abs()
+        log["run_net_fused_vs_unfused"] = {"unfused": undone, "max_abs": float(du.max()), "max_rel_to_max": float(du.max() / pred_u.abs().max()),
+                                           "values_above_1e-4": int((du > 1e-4).sum()), "values": int(du.numel())}
+        print("[run_net fused vs unfused]", log["run_net_fused_vs_unfused"], flush=True)
 
     # ---- importance sampling on its own (sdf_utils.py:383-423)
     with torch.no_grad():
