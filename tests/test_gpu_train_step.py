@@ -81,7 +81,6 @@ def test_reference_schedule_phases(dev, tmp_path):
     assert abs(seen[6 + 5 + 1 + 3][1] - hp.lr * 0.3) < 1e-12                      # first milestone, counted from the hand-over
     # iteration n0 + 9 is the first with iter_nr_for_anneal >= iter_start_reduce_curv
     assert seen[14][2] == 0.0 and seen[15][2] == 1.0 and seen[15][3] is True and seen[14][3] is False
-    assert float(tr.colorcal.bias.abs().max()) > 0 and float(tr.colorcal.weight_delta[0].abs().max()) == 0.0 or True
     assert float(tr.colorcal.bias[1:].abs().max()) > 0                            # cameras other than the fixed one are calibrated
     tr.save_checkpoint(str(tmp_path))
     assert os.path.exists(tmp_path / "colorcal_model.pt")

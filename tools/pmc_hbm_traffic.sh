@@ -15,8 +15,14 @@ cd $R
 python - "$OUT" "$TAG" <<'PY'
 import csv, glob, json, collections, sys
 out, tag = sys.argv[1], sys.argv[2]
-names = ["encode_fwd_kernel", "mlp_fwd_kernel", "mlp_fwd_split_kernel", "mlp_bwd_kernel", "mlp_bwd_split_kernel", "encode_bwd_kernel",
-         "encode_bwd_reduce_kernel", "adamw_kernel", "neus_alpha_fwd_kernel", "neus_alpha_bwd_kernel"]
+names = ["encode_fwd_kernel", "mlp_fwd_kernel", "mlp_fwd_split_kernel", "mlp_bwd_kernel", "mlp_bwd_split_kernel",
+         "mlp_bwd_split_f16_kernel", "encode_bwd_kernel", "encode_bwd_reduce_kernel", "adamw_kernel", "neus_alpha_fwd_kernel",
+         "neus_alpha_bwd_kernel", "mlp_absmax_kernel"]
+# The guide's x2 correction of FETCH_SIZE was calibrated on WIDE COALESCED reads (mlp_fwd: 302 MB of features read, counter says
+# 151 MB).  It does not carry over to a GATHER kernel whose HBM reads are cache-line fills of L2-resident tables: for
+# encode_fwd the uncorrected counter (285 MB in round 2) is 8 XCDs x 32 MiB -- every XCD's L2 filling every table once -- plus
+# the positions, almost exactly; doubling it overstates the traffic by ~290 MB.  So the correction is applied per kernel class.
+gather = {"encode_fwd_kernel"}
 res = {n: {} for n in names}
 for c, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
     agg = collections.defaultdict(lambda: [0.0, 0])
@@ -31,12 +37,17 @@ for c, key in (("FETCH_SIZE", "fetch_kib"), ("WRITE_SIZE", "write_kib")):
         res[n][key] = v / k
 for n in names:
     if "fetch_kib" in res[n] and "write_kib" in res[n]:
-        res[n]["hbm_bytes"] = int(2 * res[n]["fetch_kib"] * 1024 + res[n]["write_kib"] * 1024)
+        k = 1 if n in gather else 2
+        res[n]["fetch_correction"] = k
+        res[n]["class"] = "gather (line fills of L2-resident tables: FETCH_SIZE as reported)" if n in gather else "streaming (FETCH_SIZE x 2)"
+        res[n]["hbm_bytes"] = int(k * res[n]["fetch_kib"] * 1024 + res[n]["write_kib"] * 1024)
 doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python bench.py --steps 3 "
                  "--warmup 1 --no-cpu-baseline --no-extra; MI355X; units KiB per launch (mean over launches)",
        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section; "
                      "confirmed here: mlp_fwd reads 302 MB of features, counter says ~151 MB) -> hbm_bytes = 2*FETCH_SIZE*1024 + "
-                     "WRITE_SIZE*1024; WRITE_SIZE calibrated exact on encode_fwd (294912 KiB = 36*2097152*4 B)",
+                     "WRITE_SIZE*1024 for streaming kernels; gather kernels (encode_fwd: cache-line fills of L2-resident tables) take "
+                     "FETCH_SIZE as reported (fetch_correction = 1: its raw value equals 8 XCDs x the table bytes + the positions); "
+                     "WRITE_SIZE calibrated exact on encode_fwd (294912 KiB = 36*2097152*4 B)",
        "kernels": {n: v for n, v in res.items() if v}}
 json.dump(doc, open(out + ".json", "w"), indent=1)
 print(json.dumps(doc["kernels"], indent=1))
