@@ -257,13 +257,16 @@ def main():
         roof["traffic"] = None
         try:
             prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            src = "r02_pmc_hbm_traffic.json" if os.path.exists(os.path.join(prof, "r02_pmc_hbm_traffic.json")) else "r01_pmc_hbm_traffic_v3.json"
+            # the newest committed summary that holds the kernel the timed steps dispatched to
+            want = {"enc_bwd": "encode_bwd_kernel", "mlp_bwd": "mlp_bwd_split_f16_kernel" if f16 else "mlp_bwd_split_kernel"}[dom]
+            cands = sorted((f for f in os.listdir(prof) if f.endswith("pmc_hbm_traffic.json")), reverse=True)
+            src = next((f for f in cands if want in json.load(open(os.path.join(prof, f))).get("kernels", {})), cands[0])
             pmc = json.load(open(os.path.join(prof, src)))
             key = {"enc_bwd": ["encode_bwd_kernel", "encode_bwd_reduce_kernel"],
                    "mlp_bwd": [next(k for k in ("mlp_bwd_split_f16_kernel" if f16 else "mlp_bwd_split_kernel", "mlp_bwd_split_kernel",
                                                 "mlp_bwd_kernel") if k in pmc["kernels"])]}[dom]
             roof["traffic"] = int(sum(pmc["kernels"][k]["hbm_bytes"] for k in key))
-            roof["traffic_source"] = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)" % src
+            roof["traffic_source"] = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes; kernel(s): %s)" % (src, ", ".join(key))
         except Exception:
             pass
         other = {k: {kk: v[kk] for kk in ("bound", "achieved", "peak", "unit", "avg_launch_ms")} for k, v in cand.items() if k != dom}

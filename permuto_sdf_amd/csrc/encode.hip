@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include "encode_device.h"
+#include <vector>
 
 namespace {
 
@@ -97,7 +98,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // switches the cache off for the rest of its walk (vote after its first tile: share of contributions that hit an
 // entry which already existed).
 constexpr uint32_t SC_EMPTY = 0xFFFFFFFFu;
-constexpr int QUEUE_SPT = 2;   // points per thread and super-tile in queue mode (see ScatterCache)
+#if !defined(PSDF_ENC_QSPT)
+#define PSDF_ENC_QSPT 2
+#endif
+constexpr int QUEUE_SPT = PSDF_ENC_QSPT;   // points per thread and super-tile in queue mode (see ScatterCache)
 
 // LDS float accumulation without ds_add_f32.  Measured on this chip (tools/atomic_bench.hip): a wave-wide ds_add_f32
 // costs ~197 cycles whatever the access pattern (1 lane per ~3 cycles), while INTEGER LDS atomics run at LDS speed
@@ -303,13 +307,16 @@ __device__ __forceinline__ void queue_push_staged(const Queues& Q, int level, in
   for (int r = 0; r < NC; r++)
     if (pending[r]) slot[r] = atomicAdd(&q_cnt[crow[r] >> Q.shift], 1);
   __syncthreads();
-  if (threadIdx.x < Q.np) {
-    const int c = q_cnt[threadIdx.x];
-    q_base[threadIdx.x] = c ? atomicAdd(&Q.tails[level * Q.np + threadIdx.x], c) : 0;
-    int off = 0;
-    for (int j = 0; j < (int)threadIdx.x; j++) off += q_cnt[j];
-    q_off[threadIdx.x] = off;
-    if ((int)threadIdx.x == Q.np - 1) q_off[Q.np] = off + c;
+  if (threadIdx.x < 64) {   // the first wave: segment offsets by a wave scan (np <= 64).  A serial walk over the counters by
+    // thread p (p LDS reads in a dependent chain, up to 31 of them, inside a barrier-separated phase) cost 4.5 % of the pair.
+    const int lane = threadIdx.x;
+    const int c = lane < Q.np ? q_cnt[lane] : 0;
+    const int incl = psdf::wave_incl_scan_add_i(c);
+    if (lane < Q.np) {
+      q_base[lane] = c ? atomicAdd(&Q.tails[level * Q.np + lane], c) : 0;
+      q_off[lane] = incl - c;
+      if (lane == Q.np - 1) q_off[Q.np] = incl;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -363,7 +370,10 @@ __device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, in
 // extra residents pay: bench batch 0.835 -> 0.79 ms (4 waves: no change; 6 waves spill 13 VGPRs).  The 24-KiB cache of queue
 // mode lets 5 workgroups share a CU's LDS.  (P = 4 and F = 4 would spill a few VGPRs at 5 waves: they ask for 4.)
 template <int P, int F, bool LATTICE, bool POS, bool QUEUE>
-__global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? 5 : 4) : 1)
+#if !defined(PSDF_ENC_QWAVES)
+#define PSDF_ENC_QWAVES 5
+#endif
+__global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF_ENC_QWAVES : 4) : 1)
     encode_bwd_kernel(int64_t N, int L, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
@@ -485,6 +495,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? 5 : 
       // all lanes (also those past the end of the batch) take part in the DPP run combine
 #pragma unroll
       for (int c = 0; c < NC; c++) {
+        // (also when the cache has been voted off: skipping the combine there was measured, round 3 -- encode backward pair
+        // 0.78 -> 0.92 ms, the runs of the mid levels are what keeps their queue traffic down)
         const bool own = combine_runs16<F>(crow[c], pending[c], cval[c]);
         bool absorbed = false;
         if (own && use_cache) {
@@ -1054,9 +1066,15 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
       (void)hipStreamSynchronize(st);
       int prof[192];
       (void)hipMemcpy(prof, Q.tails + nr_levels * Q.np, sizeof(prof), hipMemcpyDeviceToHost);
-      for (int l = 0; l < nr_levels; l++)
-        fprintf(stderr, "[enc-profile] level %2d: max %8d ticks, mean %8.0f ticks, cache kept by %d of %u workgroups\n", l, prof[l],
-                64.0 * prof[64 + l] / grid.x, prof[128 + l], grid.x);
+      std::vector<int> tails((size_t)nr_levels * Q.np);
+      (void)hipMemcpy(tails.data(), Q.tails, tails.size() * sizeof(int), hipMemcpyDeviceToHost);
+      for (int l = 0; l < nr_levels; l++) {
+        long long queued = 0;
+        for (int q = 0; q < Q.np; q++) queued += tails[(size_t)l * Q.np + q];
+        fprintf(stderr, "[enc-profile] level %2d: max %8d ticks, mean %8.0f ticks, cache kept by %d of %u workgroups, queued %lld of %lld "
+                "contributions (%.1f %%)\n", l, prof[l], 64.0 * prof[64 + l] / grid.x, prof[128 + l], grid.x, queued,
+                (long long)N * (pos_dim + 1), 100.0 * queued / ((double)N * (pos_dim + 1)));
+      }
     }
   }
 #endif
