@@ -66,6 +66,23 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced, float* grad_lattice,
     float* grad_grad_sliced, void* stream);
 
+/* ---- composite_fused.hip ---- */
+/* replaces, fused: VolumeRenderingNeus.compute_weights + integrate (permuto_sdf_py/volume_rendering/volume_rendering_modules.py:
+   129-190), i.e. the chain psdf_neus_alpha_forward -> psdf_cumprod_alpha2transmittance -> (alpha * T) ->
+   psdf_integrate_with_weights in ONE launch: pred [R,3] (pass zeros: invalid / empty rays keep them), bg [R] (optional; pass
+   ones), weights [N] (optional).  Same arithmetic and summation order as the separate entry points. */
+int psdf_neus_composite_forward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float* sdf,
+    const float* dirs, const float* gradients, const float* dt, const float* rgb, const float* inv_s, float cos_anneal_ratio,
+    float* pred, float* bg, float* weights, void* stream);
+/* its backward in one launch (integrate_with_weights_backward, the transmittance backward with its inverse cumulative sum,
+   the opacity backward: volume_rendering_funcs.py:55-190): grad_pred [R,3], grad_bg [R] or NULL -> grad_sdf [N]; optional
+   grad_gradients [N,3], grad_rgb [N,3], grad_inv_s [1] (accumulated into).  max_per_ray = an upper bound of the samples of any
+   ray, at most 256 (-2 beyond: use the per-operator entry points); reference_compat as in psdf_integrate_with_weights_backward. */
+int psdf_neus_composite_backward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, int max_per_ray,
+    const float* grad_pred, const float* grad_bg, const float* sdf, const float* dirs, const float* gradients, const float* dt,
+    const float* rgb, const float* inv_s, float cos_anneal_ratio, int reference_compat, float* grad_sdf, float* grad_gradients,
+    float* grad_rgb, float* grad_inv_s, void* stream);
+
 /* ---- debug query (mlp_bwd.hip) ---- */
 /* Which kernel variant the LAST call of an operator family dispatched to (host only, no device work): lets a parity test
    assert that the configuration it compares with the oracle ran the kernels the benchmark times.  No reference counterpart.

@@ -9,33 +9,11 @@
 // Arithmetic is fp32 in the order the reference's expressions are written (contraction off), the sigmoid is
 // 1 / (1 + exp(-x)) as torch evaluates it.
 #include "psdf_common.h"
+#include "composite_device.h"
 
 using namespace psdf;
 
 namespace {
-
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-struct Section {   // everything the backward needs again
-  float tc, pre_a, pre_b, ic, en, ep, pc, nc, p, c, q;
-};
-
-__device__ __forceinline__ Section section(float sdf, v3 dir, v3 grad, float dt, float inv_s, float r) {
-  Section s;
-  s.tc = (dir.x * grad.x + dir.y * grad.y) + dir.z * grad.z;            // (dirs * gradients).sum(-1)
-  s.pre_a = -s.tc * 0.5f + 0.5f;
-  s.pre_b = -s.tc;
-  s.ic = -(fmaxf(s.pre_a, 0.f) * (1.0f - r) + fmaxf(s.pre_b, 0.f) * r); // always non-positive
-  const float half = s.ic * dt * 0.5f;
-  s.en = sdf + half;
-  s.ep = sdf - half;
-  s.pc = sigm(s.ep * inv_s);
-  s.nc = sigm(s.en * inv_s);
-  s.p = s.pc - s.nc;
-  s.c = s.pc;
-  s.q = (s.p + 1e-5f) / (s.c + 1e-5f);
-  return s;
-}
 
 __global__ void __launch_bounds__(PSDF_BLOCK)
     neus_alpha_fwd_kernel(int64_t N, const float* __restrict__ sdf, const float* __restrict__ dirs,

@@ -11,36 +11,11 @@
 // The two kernels whose results are index-exact contracts (importance_sample, combine) keep the reference's
 // per-ray serial order of operations.
 #include "psdf_common.h"
+#include "composite_device.h"
 
 using namespace psdf;
 
 namespace {
-
-struct RayIndex {
-  const int* __restrict__ start_end;  // [R,2]
-  int equal;                          // rays_have_equal_nr_of_samples
-  int fixed;                          // fixed_nr_of_samples_per_ray
-  int max_nr_samples;
-  __device__ __forceinline__ void get(int ray, int& s, int& e) const {
-    if (equal) {
-      s = ray * fixed;
-      e = s + fixed;
-    } else {
-      s = start_end[2 * ray];
-      e = start_end[2 * ray + 1];
-    }
-  }
-  // the reference skips rays whose reservation overflowed the pool, and empty rays
-  __device__ __forceinline__ bool valid(int s, int e) const { return !(e > max_nr_samples || e == s); }
-};
-
-#define RAY_LOOP(ray, nr_rays) \
-  for (int ray = blockIdx.x * (PSDF_BLOCK / 64) + (threadIdx.x >> 6); ray < nr_rays; ray += gridDim.x * (PSDF_BLOCK / 64))
-
-static inline unsigned ray_grid(int nr_rays) {
-  unsigned b = psdf_blocks(nr_rays, PSDF_BLOCK / 64);
-  return b < 16384u ? (b ? b : 1u) : 16384u;
-}
 
 // ------------------------------------------------------------------ cumprod alpha -> transmittance
 __global__ void __launch_bounds__(PSDF_BLOCK)

@@ -15,7 +15,8 @@ from . import parallel
 from .bridge import VolumeRendering as VR
 from .encoding import PermutoEncoding, encode_backward_raw, encode_forward_raw
 from .mlp import FusedMLP, mlp_backward_raw, mlp_forward_raw, pack_params
-from .neus import neus_alpha_backward_raw, neus_alpha_forward_raw
+from .neus import (FUSED_MAX_PER_RAY, neus_alpha_backward_raw, neus_alpha_forward_raw, neus_composite_backward_raw,
+                   neus_composite_forward_raw)
 
 
 class SdfHotPath:
@@ -38,6 +39,18 @@ class SdfHotPath:
         from .optim import FusedAdamW
         self.opt = FusedAdamW(self.params, lr=lr)
         self.events = None
+        # fused compositing (one launch per direction) where the container says how long its rays are at most; `want_rgb_grad`:
+        # the per-sample radiance is an INPUT of this path (in training it comes from the colour network: its gradient is then
+        # wanted); the benchmark's synthetic radiance has no consumer for it
+        self.fuse_compositing = True
+        self.want_rgb_grad = True
+
+    @staticmethod
+    def _max_per_ray(rs):
+        """an upper bound of the samples per ray known WITHOUT a host sync, or None"""
+        if rs.rays_have_equal_nr_of_samples and 0 < int(rs.fixed_nr_of_samples_per_ray) <= FUSED_MAX_PER_RAY:
+            return int(rs.fixed_nr_of_samples_per_ray)
+        return None
 
     # ------------------------------------------------------------------ forward
     def forward(self, rs, rgb_samples, normals):
@@ -56,6 +69,12 @@ class SdfHotPath:
                                   self.enc.random_shift_per_level.detach(), self.window)
         sdf = mlp_forward_raw(self.mlp.dims, feat, packed)                    # [1, N] feature-major == [N,1] memory
         sdf_col = sdf.view(-1, 1)
+        per_ray = self._max_per_ray(rs)
+        if self.fuse_compositing and per_ray is not None:
+            # opacity -> transmittance -> weights -> radiance in ONE launch (csrc/composite_fused.hip): the same arithmetic as the
+            # four operators below, for callers that own the whole chain (tests/test_gpu_neus.py compares the two)
+            pred, bg, _ = neus_composite_forward_raw(rs, sdf_col, normals, rgb_samples, self.inv_s, self.cos_anneal_ratio)
+            return pred, dict(feat=feat, packed=packed, sdf=sdf, bg=bg, normals=normals, fused_per_ray=per_ray)
         alpha, one_minus = neus_alpha_forward_raw(sdf_col, rs.samples_dirs, normals, rs.samples_dt, self.inv_s,
                                                   self.cos_anneal_ratio)
         T, bg = VR.cumprod_alpha2transmittance(rs, one_minus)
@@ -72,15 +91,21 @@ class SdfHotPath:
         backward -> encoding backward."""
         cfg = self.enc.cfg
         N = rs.samples_pos.shape[0]
-        g_rgb, g_w = VR.integrate_with_weights_backward(grad_pred, rs, rgb_samples, saved["w"], None)
-        g_T = g_w * saved["alpha"]
-        cs = VR.cumsum_over_each_ray(rs, g_T * saved["T"], True)
-        g_om = VR.cumprod_alpha2transmittance_backward(g_T, torch.zeros_like(saved["bg"]), rs, saved["one_minus"], saved["T"],
-                                                       saved["bg"], cs)
-        g_alpha = torch.addcmul(-g_om, g_w, saved["T"])      # alpha enters as w = alpha T and as 1 - alpha + 1e-7
-        g_sdf, _, _ = neus_alpha_backward_raw(g_alpha, saved["sdf"].view(-1, 1), rs.samples_dirs, saved["normals"],
-                                               rs.samples_dt, self.inv_s, self.cos_anneal_ratio, need_grad=False,
-                                               need_inv_s=False)
+        if "fused_per_ray" in saved:
+            g_sdf, _, g_rgb, _ = neus_composite_backward_raw(rs, saved["fused_per_ray"], grad_pred, None, saved["sdf"].view(-1, 1),
+                                                             saved["normals"], rgb_samples, self.inv_s, self.cos_anneal_ratio,
+                                                             need_grad=False, need_rgb=self.want_rgb_grad, need_inv_s=False)
+            g_om = g_alpha = None
+        else:
+            g_rgb, g_w = VR.integrate_with_weights_backward(grad_pred, rs, rgb_samples, saved["w"], None)
+            g_T = g_w * saved["alpha"]
+            cs = VR.cumsum_over_each_ray(rs, g_T * saved["T"], True)
+            g_om = VR.cumprod_alpha2transmittance_backward(g_T, torch.zeros_like(saved["bg"]), rs, saved["one_minus"], saved["T"],
+                                                           saved["bg"], cs)
+            g_alpha = torch.addcmul(-g_om, g_w, saved["T"])      # alpha enters as w = alpha T and as 1 - alpha + 1e-7
+            g_sdf, _, _ = neus_alpha_backward_raw(g_alpha, saved["sdf"].view(-1, 1), rs.samples_dirs, saved["normals"],
+                                                   rs.samples_dt, self.inv_s, self.cos_anneal_ratio, need_grad=False,
+                                                   need_inv_s=False)
         grad_sdf = g_sdf.view(1, N)
         if self.events is not None:
             self.events["mlp_bwd"][0].record()

@@ -59,6 +59,68 @@ def neus_alpha(sdf, dirs, gradients, dt, inv_s, cos_anneal_ratio):
     return NeusAlphaFunc.apply(sdf, dirs, gradients, dt, inv_s, cos_anneal_ratio)
 
 
+# ---------------------------------------------------------------------------------------------- fused NeuS rendering
+def neus_composite_forward_raw(rs, sdf, gradients, rgb, inv_s, cos_anneal_ratio, want_weights=False):
+    """csrc/composite_fused.hip: opacity -> transmittance -> weights -> radiance of a packed container in one launch.
+    -> pred [R,3], bg transmittance [R,1], weights [N,1] or None"""
+    R, N, dev = rs.ray_start_end_idx.shape[0], sdf.shape[0], sdf.device
+    L.require_cuda(sdf, gradients, rgb, inv_s)
+    pred = torch.zeros((R, 3), dtype=torch.float32, device=dev)
+    bg = torch.ones((R, 1), dtype=torch.float32, device=dev)
+    w = torch.zeros((N, 1), dtype=torch.float32, device=dev) if want_weights else None
+    L.call("psdf_neus_composite_forward", *rs._ri(), L.ptr(sdf), L.ptr(rs.samples_dirs), L.ptr(gradients), L.ptr(rs.samples_dt),
+           L.ptr(rgb), L.ptr(inv_s), L.c_f(float(cos_anneal_ratio)), L.ptr(pred), L.ptr(bg), L.ptr(w), L.stream())
+    return pred, bg, w
+
+
+def neus_composite_backward_raw(rs, max_per_ray, g_pred, g_bg, sdf, gradients, rgb, inv_s, cos_anneal_ratio, need_grad=True,
+                                need_rgb=True, need_inv_s=True):
+    """-> g_sdf [N,1], g_gradients [N,3] | None, g_rgb [N,3] | None, g_inv_s [1] | None; PsdfError(-2) when a ray may hold more
+    than 256 samples (callers then use the per-operator chain)"""
+    from .bridge import VolumeRendering, _per_sample
+    N, dev = sdf.shape[0], sdf.device
+    g_sdf = _per_sample(rs, (N, 1), dev)
+    g_grad = _per_sample(rs, (N, 3), dev) if need_grad else None
+    g_rgb = _per_sample(rs, (N, 3), dev) if need_rgb else None
+    g_inv_s = L.zeroed_scalar(dev) if need_inv_s else None
+    L.call("psdf_neus_composite_backward", *rs._ri(), L.c_i(int(max_per_ray)), L.ptr(g_pred), L.ptr(g_bg), L.ptr(sdf),
+           L.ptr(rs.samples_dirs), L.ptr(gradients), L.ptr(rs.samples_dt), L.ptr(rgb), L.ptr(inv_s),
+           L.c_f(float(cos_anneal_ratio)), L.c_i(int(VolumeRendering.reference_compat)), L.ptr(g_sdf), L.ptr(g_grad),
+           L.ptr(g_rgb), L.ptr(g_inv_s), L.stream())
+    return g_sdf, g_grad, g_rgb, g_inv_s
+
+
+FUSED_MAX_PER_RAY = 256
+
+
+class NeusCompositeFunc(torch.autograd.Function):
+    """(sdf, gradients, rgb, inv_s) -> (pred [R,3], bg transmittance [R,1]): VolumeRenderingNeus.compute_weights + integrate
+    (volume_rendering_modules.py:129-190) as one launch per direction; gradients flow to all four inputs."""
+
+    @staticmethod
+    def forward(ctx, rs, max_per_ray, sdf, gradients, rgb, inv_s, cos_anneal_ratio):
+        sdf_c, grad_c, rgb_c, inv_s_c = _c(sdf).view(-1, 1), _c(gradients), _c(rgb), _c(inv_s).view(1)
+        pred, bg, _ = neus_composite_forward_raw(rs, sdf_c, grad_c, rgb_c, inv_s_c, cos_anneal_ratio)
+        ctx.save_for_backward(sdf_c, grad_c, rgb_c, inv_s_c)
+        ctx.rs, ctx.max_per_ray, ctx.r, ctx.inv_s_shape = rs, int(max_per_ray), float(cos_anneal_ratio), inv_s.shape
+        return pred, bg
+
+    @staticmethod
+    def backward(ctx, g_pred, g_bg):
+        sdf, grad, rgb, inv_s = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        g_sdf, g_grad, g_rgb, g_inv_s = neus_composite_backward_raw(
+            ctx.rs, ctx.max_per_ray, g_pred.contiguous(), None if g_bg is None else g_bg.contiguous(), sdf, grad, rgb, inv_s, ctx.r,
+            need_grad=need[3], need_rgb=need[4], need_inv_s=need[5])
+        return (None, None, g_sdf if need[2] else None, g_grad, g_rgb,
+                g_inv_s.view(ctx.inv_s_shape) if g_inv_s is not None else None, None)
+
+
+def neus_composite(rs, max_per_ray, sdf, gradients, rgb, inv_s, cos_anneal_ratio):
+    """fused NeuS rendering of a packed container whose rays hold at most `max_per_ray` (<= 256) samples"""
+    return NeusCompositeFunc.apply(rs, max_per_ray, sdf, gradients, rgb, inv_s, cos_anneal_ratio)
+
+
 def l1_loss_raw(pred, gt, mask=None, scale=None, want_grad=True):
     """-> (loss [1], g_pred or None): loss = scale * sum |gt - pred| * mask; scale defaults to 1/numel (the reference's mean)"""
     L.require_cuda(pred, gt)

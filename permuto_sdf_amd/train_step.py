@@ -39,7 +39,7 @@ from .bridge import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRenderi
 from .encoding import Coarse2Fine, PermutoEncoding
 from .fused import encode_mlp_forward_raw
 from .mlp import FusedMLP, LipshitzMLP, pack_params
-from .neus import (curvature_loss, curvature_shift, eikonal_loss, l1_loss, nerf_alpha, neus_alpha, normalize3,
+from .neus import (curvature_loss, curvature_shift, eikonal_loss, l1_loss, nerf_alpha, neus_alpha, neus_composite, normalize3,
                    offsurface_loss)
 from .optim import FusedAdamW
 
@@ -264,6 +264,18 @@ class RgbNet(torch.nn.Module):
         w_sum, _ = _SumRay.apply(rs, w)
         return w, w_sum, bg
 
+    def neus_render(self, rs, max_per_ray, sdf, gradients, rgb, cos_anneal_ratio, forced_variance):
+        """compute_weights + integrate (volume_rendering_modules.py:129-190) in one launch per direction
+        (csrc/composite_fused.hip) -> (radiance [R,3], bg transmittance [R,1]); gradients flow to sdf, the SDF gradient, the
+        colours and the variance"""
+        v = self.variance if forced_variance is None else torch.tensor(float(forced_variance), device=sdf.device)
+        inv_s = torch.exp(v * 10.0).clip(1e-6, 1e6)
+        self.last_inv_s = inv_s.detach()
+        return neus_composite(rs, max_per_ray, sdf, gradients, rgb, inv_s, cos_anneal_ratio)
+
+
+# (RgbNet.neus_render below is the fused form of neus_weights + _Integrate: one launch per direction)
+
 
 class BgNet(torch.nn.Module):
     """NerfHash, models.py:431-526: 4-D lattice, density+feature net 52->64x3->65, colour head [64+16]->64->64->3."""
@@ -437,8 +449,13 @@ class Trainer:
         else:
             sdf, sdf_grad, feat = self.sdf.sdf_and_gradient(fg.samples_pos, it)
             rgb = self.rgb(fg.samples_pos, fg.samples_dirs, sdf_grad, feat, cc, img_indices, fg.ray_start_end_idx)
-            w, _, bgT = self.rgb.neus_weights(fg, sdf, sdf_grad, cos_anneal_ratio, forced_variance)
-            pred = _Integrate.apply(fg, rgb, w)
+            # a ray holds at most max_nr_samples_per_ray uniform + 2 rounds of importance samples
+            per_ray = self.hp.max_nr_samples_per_ray + 2 * self.hp.nr_samples_imp_sampling
+            if per_ray <= 256:
+                pred, bgT = self.rgb.neus_render(fg, per_ray, sdf, sdf_grad, rgb, cos_anneal_ratio, forced_variance)
+            else:
+                w, _, bgT = self.rgb.neus_weights(fg, sdf, sdf_grad, cos_anneal_ratio, forced_variance)
+                pred = _Integrate.apply(fg, rgb, w)
         rgb_bg, dens = self.bg(bg.samples_pos_4d, bg.samples_dirs, cc, img_indices, bg.ray_start_end_idx)
         pred = pred + bgT.view(-1, 1) * _Integrate.apply(bg, rgb_bg, BgNet.nerf_weights(bg, dens.view(-1, 1)))
         return pred, sdf_grad, fg

@@ -198,3 +198,77 @@ def test_offsurface_and_nerf_alpha_match_torch(dev):
     e = eikonal_loss(gd)
     (ge,) = torch.autograd.grad(e * 0.04, gd)
     assert abs(float(e) - float(e_ref)) < 1e-5 and _rel(ge, ge_ref * 0.04) < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["equal128", "equal48", "ragged", "holes"])
+def test_fused_compositing_equals_the_operator_chain_and_the_oracle(dev, mode):
+    """csrc/composite_fused.hip: opacity -> transmittance -> weights -> radiance in one launch and its backward in one launch,
+    against (1) the chain of per-operator kernels it fuses (neus_alpha -> cumprod -> alpha T -> integrate, and their backward
+    kernels as hotpath.py / train_step.py string them), bit for bit where the summation orders coincide (ray lengths that are
+    multiples of 64) and within 2e-6 elsewhere, and (2) the reference's own torch expressions (oracle/neus_oracle.py, autograd)
+    for equal-count rays.  Containers: equal counts, ragged counts up to 200 samples, and rays the reference skips (empty)."""
+    from permuto_sdf import RaySamplesPacked, VolumeRendering as VR
+    from permuto_sdf_amd.neus import (neus_alpha_backward_raw, neus_alpha_forward_raw, neus_composite_backward_raw,
+                                      neus_composite_forward_raw)
+    g = torch.Generator().manual_seed({"equal128": 1, "equal48": 2, "ragged": 3, "holes": 4}[mode])
+    R = 300
+    if mode.startswith("equal"):
+        per = int(mode[5:])
+        counts = torch.full((R,), per, dtype=torch.int64)
+    else:
+        counts = torch.randint(1, 200, (R,), generator=g)
+        if mode == "holes":
+            counts[torch.randperm(R, generator=g)[:40]] = 0
+    ends = torch.cumsum(counts, 0)
+    starts = ends - counts
+    N = int(ends[-1])
+    sdf, dirs, grad, dt = _inputs(N, 11, scale=0.01)
+    rgb = torch.rand(N, 3, generator=g)
+    rs = RaySamplesPacked(R, N, device=dev)
+    if mode.startswith("equal"):
+        rs.rays_have_equal_nr_of_samples, rs.fixed_nr_of_samples_per_ray = True, per
+    rs.ray_start_end_idx = torch.stack([starts, ends], 1).to(torch.int32).to(dev)
+    rs.samples_dirs, rs.samples_dt = dirs.to(dev), dt.to(dev)
+    rs.cur_nr_samples.fill_(N)
+    sdf_d, grad_d, rgb_d = sdf.to(dev), grad.to(dev), rgb.to(dev)
+    inv_s = torch.tensor([300.0], device=dev)
+    ratio = 0.6
+    g_pred = torch.randn(R, 3, generator=g).to(dev)
+    g_bg = torch.randn(R, 1, generator=g).to(dev)
+    # ---- fused
+    pred, bg, w = neus_composite_forward_raw(rs, sdf_d, grad_d, rgb_d, inv_s, ratio, want_weights=True)
+    gs, gg, gr, gi = neus_composite_backward_raw(rs, 200 if not mode.startswith("equal") else per, g_pred, g_bg, sdf_d, grad_d, rgb_d,
+                                                 inv_s, ratio)
+    # ---- the operator chain
+    alpha, om = neus_alpha_forward_raw(sdf_d, rs.samples_dirs, grad_d, rs.samples_dt, inv_s, ratio)
+    T, bg2 = VR.cumprod_alpha2transmittance(rs, om)
+    w2 = alpha * T
+    pred2 = VR.integrate_with_weights(rs, rgb_d, w2)
+    g_rgb2, g_w2 = VR.integrate_with_weights_backward(g_pred, rs, rgb_d, w2, None)
+    g_T = g_w2 * alpha
+    cs = VR.cumsum_over_each_ray(rs, g_T * T, True)
+    g_om = VR.cumprod_alpha2transmittance_backward(g_T, g_bg, rs, om, T, bg2, cs)
+    g_alpha = torch.addcmul(-g_om, g_w2, T)
+    gs2, gg2, gi2 = neus_alpha_backward_raw(g_alpha, sdf_d, rs.samples_dirs, grad_d, rs.samples_dt, inv_s, ratio)
+    live = (counts > 0).to(dev)
+    assert torch.equal(pred[live], pred2[live]) and torch.equal(bg[live], bg2[live])          # forward: identical order
+    assert torch.equal(w, w2) and torch.equal(gr, g_rgb2)
+    tol = 0.0 if mode == "equal128" else 2e-6
+    for a, b, name in ((gs, gs2, "g_sdf"), (gg, gg2, "g_gradients")):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + (0 if tol == 0 else 1e-12), (name, float((a - b).abs().max()))
+    assert abs(float(gi) - float(gi2)) <= 2e-5 * float(g_alpha.abs().sum()) + 1e-6 * abs(float(gi2))   # an atomic sum: order free
+    # ---- the reference's expressions (equal counts: oracle/neus_oracle.composite_equal)
+    if mode.startswith("equal"):
+        sdf_r, grad_r, rgb_r = sdf.clone().requires_grad_(True), grad.clone().requires_grad_(True), rgb.clone().requires_grad_(True)
+        a_ref, om_ref = no.neus_alpha(sdf_r, dirs, grad_r, dt, torch.tensor(300.0), ratio)
+        pred_ref, w_ref, T_ref = no.composite_equal(a_ref, om_ref, rgb_r, R, per, reference_compat=VR.reference_compat)
+        bg_ref = (T_ref.view(R, per)[:, -1:])                               # bg transmittance == T of the last sample
+        ((pred_ref * g_pred.cpu()).sum() + (bg_ref * g_bg.cpu()).sum()).backward()
+        assert (pred.cpu() - pred_ref.detach()).abs().max() <= 2e-6 * max(1.0, float(pred_ref.abs().max()))
+        assert (gs.cpu() - sdf_r.grad).abs().max() <= 3e-5 * sdf_r.grad.abs().max()
+        assert (gg.cpu() - grad_r.grad).abs().max() <= 3e-5 * grad_r.grad.abs().max()
+        assert (gr.cpu() - rgb_r.grad).abs().max() <= 3e-5 * rgb_r.grad.abs().max()
+    # more than 256 samples per ray: the fused backward says so (-2) and the caller uses the operator chain
+    from permuto_sdf_amd._lib import PsdfError
+    with pytest.raises(PsdfError):
+        neus_composite_backward_raw(rs, 300, g_pred, g_bg, sdf_d, grad_d, rgb_d, inv_s, ratio)
