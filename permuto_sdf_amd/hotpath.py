@@ -120,7 +120,7 @@ class SdfHotPath:
         if self.events is not None:
             self.events["enc_bwd"][0].record()
         if split_levels is None:
-            split_levels = reduce and parallel.world_size() > 1
+            split_levels = reduce and parallel.collectives_active()
         if split_levels:
             # Data parallel: the lattice gradient (4*L*T*F bytes, the same 2 MiB for every level) is the only large message
             # of the step.  The levels are independent, so the backward runs as two launches over level ranges and the

@@ -43,6 +43,16 @@ def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
+def collectives_active():
+    """True when gradient reductions are to be issued: more than one rank -- or ONE rank of an initialised process group with
+    PSDF_DP_FORCE_COLLECTIVES=1, which sends every bucket through RCCL anyway (a sum over one rank): the only way to execute the
+    real reduce-scatter / all-gather / all-reduce calls, their stream ordering and the level-split schedule on a single-GPU box
+    (tests/test_gpu_rccl_single_rank.py)."""
+    if world_size() > 1:
+        return True
+    return dist.is_initialized() and os.environ.get("PSDF_DP_FORCE_COLLECTIVES") == "1"
+
+
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -137,6 +147,7 @@ class Loopback:
 
 
 _loopback = None
+_rs_warned = False
 
 
 def set_loopback(lb):
@@ -182,7 +193,16 @@ class GradientBuckets:
         shard = torch.empty(n, dtype=flat.dtype, device=flat.device)
         if dist.get_backend() == "nccl":
             # both enqueue on the process group's stream, in order: the gather starts when the scatter's result is there
-            a = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)
+            try:
+                a = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)
+            except Exception as e:      # a backend build without the tensor form: say so once and use one all_reduce per bucket
+                global _rs_warned
+                if not _rs_warned:
+                    _rs_warned = True
+                    import warnings
+                    warnings.warn("GradientBuckets: reduce_scatter_tensor failed (%r); falling back to all_reduce" % (e,))
+                self.mode = "all_reduce"
+                return [dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)]
             b = dist.all_gather_into_tensor(flat, shard, async_op=True)
             return [a, b, shard]
         # gloo (CPU tests) has no reduce_scatter: one reduce per owner, then the gather
@@ -198,7 +218,7 @@ class GradientBuckets:
 
     def reduce(self, tensors):
         """Launch the reduction of one bucket (a list of gradient tensors that are final).  No-op on one rank."""
-        if world_size() == 1:
+        if not collectives_active():
             return
         tensors = [t for t in tensors if t is not None]
         if not tensors:
@@ -238,7 +258,7 @@ class GradientBuckets:
         block_elems]) travel.  Blocks nobody touched carry an all-zero gradient on every rank: skipping them changes nothing.
         Costs one host sync (the number of touched blocks sizes the message).  Worth it when a batch touches a small part of
         the table: the coarse levels always, the hashed levels only for small batches."""
-        if world_size() == 1:
+        if not collectives_active():
             return
         idx = torch.nonzero(touched.reshape(-1), as_tuple=False).reshape(-1)
         if idx.numel() == 0:
