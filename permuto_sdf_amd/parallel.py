@@ -22,7 +22,8 @@ def init(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get("PSDF_DP_FORCE_COLLECTIVES") == "1"       # a one-rank group that still talks to RCCL (tests)
+    if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("PSDF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -1,8 +1,8 @@
-"""Lane-level numpy emulation of ONE 32-sample tile of tools/mlp_bwd_split_bf16_v2.hip (the split-bf16 MLP backward with
+"""Lane-level numpy emulation of ONE 32-sample tile of tools/prototypes/mlp_bwd_split_bf16_v2.hip (the split-bf16 MLP backward with
 transposes on the matrix pipe), statement by statement, on the MFMA lane maps of tools/mfma_lane_maps.py: checks the whole
 data flow (operand images, chaining, 0/1-operand transposes, piece packing, sample order of the X / dY row loads, bias
 sums, accumulator layout) against a float64 backward of the same net.  CPU only; it does not model timing.
-usage: python tools/emulate_bwd_v2.py"""
+usage: python tools/prototypes/emulate_bwd_v2.py"""
 import os
 import sys
 

@@ -1,4 +1,4 @@
-"""Lane-level numpy emulation of ONE 16-sample tile of tools/mlp_bwd_split_bf16_v3.hip: the split-bf16 MLP backward on
+"""Lane-level numpy emulation of ONE 16-sample tile of tools/prototypes/mlp_bwd_split_bf16_v3.hip: the split-bf16 MLP backward on
 v_mfma_f32_16x16x32_bf16 (16-sample tiles halve the per-sample register state that makes the 32-sample versions spill).
 Lane maps of the 16x16x32 instruction (c = lane & 15, g = lane >> 4):
     A[m][k]: lane (m = c, g) holds k = 8 g + j;   B[k][n]: lane (n = c, g) holds k = 8 g + j;   D[m][n]: lane (n = c, g),
@@ -8,7 +8,7 @@ Chained order of a k-step s (32 features = the D tiles 2s and 2s+1 of the previo
 Transposes are products with a 0/1 operand (two per k-step, one per 16-feature tile); a feature-lane tile holds samples
 4 g + r in register r, which sit in k-slots 8 g + r of a dW operand (slots 8 g + 4 .. + 7 are zero: half-filled k).
 Checks all nine gradients against float64.  CPU only.
-usage: python tools/emulate_bwd_v3.py"""
+usage: python tools/prototypes/emulate_bwd_v3.py"""
 import sys
 
 import numpy as np

@@ -1,7 +1,7 @@
 // Prototype of the FULL backward (dX, dW1..4, db1..4) of the 36-64-64-64-1 SDF MLP with split-bf16 operands on
 // v_mfma_f32_32x32x16_bf16 -- the plan of DESIGN.md ("fp32 MFMAs do not overlap with VALU work").  Per 32-sample tile:
-//   forward recompute (h_l, gelu'(z_l) kept in registers)                       tools/mlp_fwd_split_bf16.hip
-//   dH chain with transposed weight images                                      tools/mlp_dx_split_bf16.hip
+//   forward recompute (h_l, gelu'(z_l) kept in registers)                       tools/prototypes/mlp_fwd_split_bf16.hip
+//   dH chain with transposed weight images                                      tools/prototypes/mlp_dx_split_bf16.hip
 //   dW_l += dZ_l^T-tile x H_{l-1}-tile with k = the 32 samples: both operands need sample<->feature transposes, done one
 //     32x32 fp32 tile at a time through a 4.6 KB per-wave LDS scratch (row stride 36 floats), then split into pieces;
 //     the transposed tile of dZ is the A operand, that of H the B operand (same lane mapping); X is read transposed
@@ -9,7 +9,7 @@
 //   dW accumulators (12 tiles x 16 registers) persist for the life of the wave; at the end the four waves add them into an
 //   fp32 image in LDS (the weight images are dead by then), the workgroup stores the image, a second launch sums the images.
 // One wave per SIMD (the register budget), 160.8 KB of LDS.  Checked against float64 at N = 65536, timed at N = 2 M.
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/mlp_bwd_split_bf16.hip -o tools/mlp_bwd_split_bf16
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/prototypes/mlp_bwd_split_bf16.hip -o tools/mlp_bwd_split_bf16
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>

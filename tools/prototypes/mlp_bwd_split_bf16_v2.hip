@@ -1,4 +1,4 @@
-// Prototype v2 of the full split-bf16 MLP backward (36-64-64-64-1): same arithmetic as tools/mlp_bwd_split_bf16.hip
+// Prototype v2 of the full split-bf16 MLP backward (36-64-64-64-1): same arithmetic as tools/prototypes/mlp_bwd_split_bf16.hip
 // (which is verified on the GPU but stall-bound: every sample<->feature transpose went through LDS with two wavefront
 // fences), with the TRANSPOSES MOVED TO THE MATRIX PIPE, which is mostly idle:
 //   D = H I   with A = the D-layout tile H (rows = samples, k = the features a lane already holds) and B = a 0/1 operand
@@ -9,10 +9,10 @@
 //   (h1 + h2 + h3 = h, every partial sum representable): used for h_l, which waits for the backward sweep.  Transposing
 //   the pieces one by one gives bf16-valued fp32 registers whose top halves ARE the transposed pieces: used for dZ_l,
 //   consumed at once (pack = one v_perm per pair instead of a 5.5-instruction split per element).
-// The whole data flow of one tile is emulated lane by lane in numpy on the MFMA lane maps (tools/emulate_bwd_v2.py,
+// The whole data flow of one tile is emulated lane by lane in numpy on the MFMA lane maps (tools/prototypes/emulate_bwd_v2.py,
 // statement for statement the tile loop below): all nine gradients match float64 to 3e-7.
 // *** NOT YET RUN ON THE GPU (the round's GPU budget was spent): treat every number it prints as unverified. ***
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/mlp_bwd_split_bf16_v2.hip -o tools/mlp_bwd_split_bf16_v2
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/prototypes/mlp_bwd_split_bf16_v2.hip -o tools/mlp_bwd_split_bf16_v2
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>

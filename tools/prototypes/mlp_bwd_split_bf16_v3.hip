@@ -1,5 +1,5 @@
 // Prototype v3 of the full split-bf16 MLP backward (36-64-64-64-1): 16-SAMPLE tiles on v_mfma_f32_16x16x32_bf16.
-// v1 (tools/mlp_bwd_split_bf16.hip, verified on the GPU) and v2 (transposes on the matrix pipe) carry ~500 registers of
+// v1 (tools/prototypes/mlp_bwd_split_bf16.hip, verified on the GPU) and v2 (transposes on the matrix pipe) carry ~500 registers of
 // live state per wave with 32-sample tiles and spill; halving the tile halves the per-sample state (activations and
 // derivatives: 16 registers per layer instead of 32) while the 176 accumulator registers stay -- about 230 VGPRs + 176
 // AGPRs.  Price: the dW products run with half-filled k (16 samples in the 32 k-slots), matrix time that is otherwise idle.
@@ -7,9 +7,9 @@
 // D[m][n]: lane (n = c, g), register r = row 4 g + r.  Chained k order of a k-step s (= D tiles 2s, 2s+1 of the previous
 // layer): slot (g, j) <-> feature kf = 32 s + 16 (j >> 2) + 4 g + (j & 3).  Transposes = products with a 0/1 operand, two per
 // k-step (one per 16-feature tile); a feature-lane tile holds samples 4 g + r, which fill k-slots (g, 0..3) of a dW operand.
-// The tile loop is emulated lane by lane in numpy (tools/emulate_bwd_v3.py: all nine gradients match float64 to 4e-7).
+// The tile loop is emulated lane by lane in numpy (tools/prototypes/emulate_bwd_v3.py: all nine gradients match float64 to 4e-7).
 // *** NOT YET RUN ON THE GPU (the round's GPU budget was spent): treat every number it prints as unverified. ***
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 tools/mlp_bwd_split_bf16_v3.hip \
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 tools/prototypes/mlp_bwd_split_bf16_v3.hip \
 //         -o tools/mlp_bwd_split_bf16_v3
 // (by default every MFMA writes AGPRs and each chain / transpose result is copied out with v_accvgpr_read: 948 copies and
 //  80 spilled dwords per tile; with the VGPR form allowed the compiler keeps only accumulators in AGPRs: 583 and 24)

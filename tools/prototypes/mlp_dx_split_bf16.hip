@@ -5,7 +5,7 @@
 // cross-lane movement, no accumulators.  This is the first half of the full backward (the dW products and their
 // sample<->feature transposes are the second) and what the sphere tracer / normal renderer call.
 // 8 waves per workgroup share one 143 KB LDS image (three forward + three transposed layers of bf16 pieces).
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/mlp_dx_split_bf16.hip -o tools/mlp_dx_split_bf16
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/prototypes/mlp_dx_split_bf16.hip -o tools/mlp_dx_split_bf16
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>

@@ -6,7 +6,7 @@
 // matrix pipe.  TERMS = 3 keeps only the first three products (~2^-16).
 // Same chained-register design as csrc/mlp.hip: everything is computed transposed (Z^T = W H^T), the D tile of layer l
 // is the B operand of layer l+1, only the weight images are permuted.
-//   hipcc -O3 --offload-arch=gfx950 tools/mlp_fwd_split_bf16.hip -o tools/mlp_fwd_split_bf16 && tools/mlp_fwd_split_bf16
+//   hipcc -O3 --offload-arch=gfx950 tools/prototypes/mlp_fwd_split_bf16.hip -o tools/mlp_fwd_split_bf16 && tools/mlp_fwd_split_bf16
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>

@@ -6,7 +6,7 @@
 // the accuracy is in both cases.  Modes:
 //   0  bf16 x 6 products (the product scheme; baseline)         1  fp16 x 3, low piece as is (needs subnormal inputs honoured)
 //   2  fp16 x 3, low pieces scaled by 2^11 into a second accumulator set (no subnormals anywhere): out = acc_hh + 2^-11 acc_cross
-//   hipcc -O3 --offload-arch=gfx950 tools/mlp_fwd_split_f16.hip -o tools/mlp_fwd_split_f16 && tools/mlp_fwd_split_f16
+//   hipcc -O3 --offload-arch=gfx950 tools/prototypes/mlp_fwd_split_f16.hip -o tools/mlp_fwd_split_f16 && tools/mlp_fwd_split_f16
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
