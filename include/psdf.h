@@ -66,6 +66,15 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced, float* grad_lattice,
     float* grad_grad_sliced, void* stream);
 
+/* ---- mlp.hip, opt-in arithmetic ---- */
+/* psdf_mlp_pack / psdf_mlp_forward with TWO fp16 pieces per fp32 operand (three products on v_mfma_f32_32x32x16_f16) instead of
+   three bf16 pieces (six products): the BASELINE net only (dims = {<= 64, 64, 64, 64, <= 4}; -2 otherwise); max error ~3e-6 of
+   the largest output instead of ~1e-6; inputs, activations and weights must stay below 65504 in magnitude.  A buffer made by
+   psdf_mlp_pack_f16 is consumed by psdf_mlp_forward_f16 only. */
+int psdf_mlp_pack_f16(int n_layers, const int* dims, const float* const* weights, const float* const* biases, float* packed,
+    void* stream);
+int psdf_mlp_forward_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y, void* stream);
+
 /* ---- composite_fused.hip ---- */
 /* replaces, fused: VolumeRenderingNeus.compute_weights + integrate (permuto_sdf_py/volume_rendering/volume_rendering_modules.py:
    129-190), i.e. the chain psdf_neus_alpha_forward -> psdf_cumprod_alpha2transmittance -> (alpha * T) ->
@@ -89,7 +98,7 @@ int psdf_neus_composite_backward(int nr_rays, const int* start_end, int equal, i
      family 0 encode backward: 1 LDS scatter cache + atomics, 2 queue mode (binning + encode_bwd_reduce_kernel), 3 positions only
      family 1 MLP backward   : 1 fp32-MFMA kernel, 2 split-bf16 kernel (mlp_bwd_split.hip), 3 wide workgroup kernel,
                                4 split-fp16 kernel (mlp_bwd_split_f16.hip)
-     family 2 MLP forward    : 1 fp32-MFMA kernel, 2 split-operand kernel
+     family 2 MLP forward    : 1 fp32-MFMA kernel, 2 split-bf16 kernel, 3 split-fp16 kernel (psdf_mlp_forward_f16)
    0 = no call yet, -1 = unknown family. */
 int psdf_last_path(int family);
 

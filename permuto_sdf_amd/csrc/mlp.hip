@@ -66,7 +66,7 @@ __global__ void mlp_pack_kernel(PackArgs a, float* __restrict__ packed) {
 
 // Split-bf16 image (mlp_device.h): one thread per 32-bit word = two bf16 of one piece of one lane record, or one float
 // of the tail.
-__global__ void mlp_pack_split_kernel(PackArgs a, SplitPlan sp, float* __restrict__ packed) {
+__global__ void mlp_pack_split_kernel(PackArgs a, SplitPlan sp, float* __restrict__ packed, int f16) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   const MlpPlan& p = a.plan;
   if (w >= sp.total_rec * 4) return;
@@ -108,7 +108,8 @@ __global__ void mlp_pack_split_kernel(PackArgs a, SplitPlan sp, float* __restric
     float v = 0.f;
     if (row < p.dims[l + 1] && col < p.dims[l]) v = a.W[l][(int64_t)row * p.dims[l] + col];
     uint32_t pc[3];
-    split3(v, pc);
+    if (f16) split2h_bits(v, pc);      // two fp16 pieces (slot 2 unused)
+    else split3(v, pc);
     out |= pc[piece] << (16 * e);
   }
   dst[w] = out;
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
 
 // The same evaluator on the bf16 matrix pipe with split fp32 operands (mlp_device.h, "split-bf16 operand path").
 // CH: k-steps of layer 0 whose loads are issued together (= all of them when the input has <= 64 features).
-template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, int CH>
+template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, int CH, bool F16 = false>
 __global__ void __launch_bounds__(PSDF_BLOCK, 2)
     mlp_fwd_split_kernel(MlpPlan p, SplitPlan sp, int64_t N, const float* __restrict__ X,
                          const float* __restrict__ packed, const unsigned char* __restrict__ skip,
@@ -266,19 +267,19 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
 #pragma unroll
       for (int i = 0; i < CH; i++) {
         const int s = s0 + i < ns0 ? s0 + i : ns0 - 1;
-        split_mac<T1>(h1, xs[i], simg + sp.w_rec[0] + s * 192, ns0, lane);
+        split_mac<T1, F16>(h1, xs[i], simg + sp.w_rec[0] + s * 192, ns0, lane);
       }
     }
     apply_gelu_scalar<T1>(h1);
     f32x16 h2[T2];
     init_bias4<T2>(h2, tail + sp.b_off[1], h);
-    split_chain<T1, T2>(h1, h2, simg + sp.w_rec[1], lane);
+    split_chain<T1, T2, F16>(h1, h2, simg + sp.w_rec[1], lane);
     apply_gelu_scalar<T2>(h2);
     constexpr int TL = (T3 > 0) ? T3 : T2;
     f32x16 hl[TL];
     if constexpr (T3 > 0) {
       init_bias4<T3>(hl, tail + sp.b_off[2], h);
-      split_chain<T2, T3>(h2, hl, simg + sp.w_rec[2], lane);
+      split_chain<T2, T3, F16>(h2, hl, simg + sp.w_rec[2], lane);
       apply_gelu_scalar<T3>(hl);
     } else {
 #pragma unroll
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
     } else {
       f32x16 y[OUT_T];
       init_bias4<OUT_T>(y, tail + sp.b_off[lf], h);
-      split_chain<TL, OUT_T>(hl, y, simg + sp.w_rec[lf], lane);
+      split_chain<TL, OUT_T, F16>(hl, y, simg + sp.w_rec[lf], lane);
       if (n < N) {
 #pragma unroll
         for (int to = 0; to < OUT_T; to++)
@@ -314,11 +315,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
   }
 }
 
-template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, int CH>
+template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, int CH, bool F16 = false>
 int launch_fwd_split_ch(const MlpPlan& p, const SplitPlan& sp, int64_t N, const float* X, const float* packed,
                      const unsigned char* skip, float* Y, hipStream_t st) {
   const size_t shmem = (size_t)sp.total_rec * 16;
-  auto kern = mlp_fwd_split_kernel<T1, T2, T3, OUT_T, FINAL_DOT, CH>;
+  auto kern = mlp_fwd_split_kernel<T1, T2, T3, OUT_T, FINAL_DOT, CH, F16>;
   if (shmem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return (int)e;
@@ -334,7 +335,20 @@ int launch_fwd_split_ch(const MlpPlan& p, const SplitPlan& sp, int64_t N, const 
 
 template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
 int launch_fwd_split(const MlpPlan& p, const SplitPlan& sp, int64_t N, const float* X, const float* packed,
-                     const unsigned char* skip, float* Y, hipStream_t st) {
+                     const unsigned char* skip, float* Y, hipStream_t st, bool f16 = false) {
+  if constexpr (T1 == 2 && T2 == 2 && T3 == 2 && OUT_T == 1 && FINAL_DOT) {
+    // the two-piece fp16 arithmetic is instantiated for the BASELINE net only (64x3 -> 1..4 outputs, <= 64 inputs)
+    if (f16) {
+      switch (sp.ns[0]) {
+        case 1: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 1, true>(p, sp, N, X, packed, skip, Y, st);
+        case 2: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 2, true>(p, sp, N, X, packed, skip, Y, st);
+        case 3: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 3, true>(p, sp, N, X, packed, skip, Y, st);
+        default: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 4, true>(p, sp, N, X, packed, skip, Y, st);
+      }
+    }
+  } else if (f16) {
+    return PSDF_ERR_UNSUPPORTED;
+  }
   switch (sp.ns[0]) {  // up to 64 input features: one chunk, no padded k-step
     case 1: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 1>(p, sp, N, X, packed, skip, Y, st);
     case 2: return launch_fwd_split_ch<T1, T2, T3, OUT_T, FINAL_DOT, 2>(p, sp, N, X, packed, skip, Y, st);
@@ -378,11 +392,14 @@ int64_t psdf_mlp_packed_size(int n_layers, const int* dims) {
 }
 
 // weights[l]: device pointer to torch-layout W_l [dims[l+1], dims[l]]; biases[l]: [dims[l+1]].
-int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, const float* const* biases,
-                  float* packed, void* stream) {
+static int mlp_pack_impl(int n_layers, const int* dims, const float* const* weights, const float* const* biases,
+                         float* packed, void* stream, int f16) {
   PackArgs a;
   int rc = make_plan(n_layers, dims, a.plan);
   if (rc != PSDF_OK) return rc;
+  // the two-piece fp16 image exists for the net psdf_mlp_forward_f16 is instantiated for
+  if (f16 && !(n_layers == 4 && dims[0] <= 64 && dims[1] == 64 && dims[2] == 64 && dims[3] == 64 && dims[4] <= 4))
+    return PSDF_ERR_UNSUPPORTED;
   for (int l = 0; l < MAXL; l++) {
     a.W[l] = l < n_layers ? weights[l] : nullptr;
     a.b[l] = l < n_layers ? biases[l] : nullptr;
@@ -394,15 +411,28 @@ int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, co
   make_split_plan(a.plan, sp);
   if (sp.ok) {  // second image of the same parameters: bf16 pieces in the operand order of mlp_fwd_split_kernel
     hipLaunchKernelGGL(mlp_pack_split_kernel, dim3(psdf_blocks(sp.total_rec * 4, 256)), dim3(256), 0,
-                       (hipStream_t)stream, a, sp, packed);
+                       (hipStream_t)stream, a, sp, packed, f16);
     PSDF_LAUNCH_CHECK();
+  } else if (f16) {
+    return PSDF_ERR_UNSUPPORTED;
   }
   return PSDF_OK;
 }
 
+int psdf_mlp_pack(int n_layers, const int* dims, const float* const* weights, const float* const* biases,
+                  float* packed, void* stream) {
+  return mlp_pack_impl(n_layers, dims, weights, biases, packed, stream, 0);
+}
+
+// The same buffer with the split image holding TWO fp16 pieces per weight: what psdf_mlp_forward_f16 consumes (and only it).
+int psdf_mlp_pack_f16(int n_layers, const int* dims, const float* const* weights, const float* const* biases,
+                      float* packed, void* stream) {
+  return mlp_pack_impl(n_layers, dims, weights, biases, packed, stream, 1);
+}
+
 // X: [dims[0], N] feature-major; Y: [dims[n_layers], N] feature-major.  GELU (erf) after every layer but the last.
 static int mlp_forward_impl(int n_layers, const int* dims, int64_t N, const float* X, const float* packed,
-                            const unsigned char* skip, float* Y, void* stream) {
+                            const unsigned char* skip, float* Y, void* stream, bool f16 = false) {
   MlpPlan p;
   int rc = make_plan(n_layers, dims, p);
   if (rc != PSDF_OK) return rc;
@@ -418,10 +448,11 @@ static int mlp_forward_impl(int n_layers, const int* dims, int64_t N, const floa
   if (t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) {           \
     if constexpr (S) {                                                          \
       if (sp.ok) {                                                              \
-        psdf::g_last_path[psdf::PATH_MLP_FWD] = 2;                              \
-        return launch_fwd_split<A, B, C, O, D>(p, sp, N, X, packed, skip, Y, st); \
+        psdf::g_last_path[psdf::PATH_MLP_FWD] = f16 ? 3 : 2;                    \
+        return launch_fwd_split<A, B, C, O, D>(p, sp, N, X, packed, skip, Y, st, f16); \
       }                                                                         \
     }                                                                           \
+    if (f16) return PSDF_ERR_UNSUPPORTED;                                       \
     psdf::g_last_path[psdf::PATH_MLP_FWD] = 1;                                  \
     return launch_fwd<A, B, C, O, D>(p, N, X, packed, skip, Y, st);             \
   }
@@ -440,6 +471,14 @@ static int mlp_forward_impl(int n_layers, const int* dims, int64_t N, const floa
 int psdf_mlp_forward(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y,
                      void* stream) {
   return mlp_forward_impl(n_layers, dims, N, X, packed, nullptr, Y, stream);
+}
+
+// The same evaluation with TWO fp16 pieces per fp32 operand (three products) for a buffer made by psdf_mlp_pack_f16: the
+// BASELINE net only (dims = {<= 64, 64, 64, 64, <= 4}; -2 otherwise).  Opt-in: max error ~3e-6 of the largest output instead of
+// ~1e-6, and inputs / activations / weights must stay below 65504 in magnitude (the three-piece bf16 form has no such limit).
+int psdf_mlp_forward_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* packed, float* Y,
+                         void* stream) {
+  return mlp_forward_impl(n_layers, dims, N, X, packed, nullptr, Y, stream, true);
 }
 
 // Same with a per-sample mask: 32-sample tiles whose samples all have skip[n] != 0 are not evaluated (their Y entries

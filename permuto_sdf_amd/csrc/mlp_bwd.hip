@@ -1231,7 +1231,8 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
 //             encode_bwd_reduce_kernel), 3 = position gradient only
 //   family 1, MLP backward   : 1 = fp32-MFMA kernel (mlp_bwd_kernel), 2 = split-bf16 kernel (mlp_bwd_split_kernel),
 //             3 = workgroup-cooperative wide kernel (mlp_wide_bwd_kernel), 4 = split-fp16 kernel (mlp_bwd_split_f16_kernel)
-//   family 2, MLP forward    : 1 = fp32-MFMA kernel (mlp_fwd_kernel), 2 = split-bf16 kernel (mlp_fwd_split_kernel)
+//   family 2, MLP forward    : 1 = fp32-MFMA kernel (mlp_fwd_kernel), 2 = split-bf16 kernel (mlp_fwd_split_kernel),
+//             3 = split-fp16 kernel (psdf_mlp_forward_f16)
 // 0 = no call yet; -1 = unknown family.
 int psdf_last_path(int family) {
   if (family < 0 || family >= psdf::PATH_FAMILIES) return -1;

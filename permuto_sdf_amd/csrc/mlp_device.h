@@ -296,10 +296,53 @@ __device__ __forceinline__ void init_bias4(f32x16 (&acc)[T], const float* __rest
     }
 }
 
+// ---- the same with TWO fp16 pieces per operand (round 3; opt-in, see psdf_mlp_forward_f16): a = a0 + a1, a0 = fp16(a) rounded
+// toward zero (the remainder is exact in fp32), a1 = fp16(a - a0); products a1 b0 + a0 b1 + a0 b0 on v_mfma_f32_32x32x16_f16.
+// Half the MFMAs and about half the splitting work of the three-piece bf16 scheme; gfx950's matrix pipe honours fp16 subnormals
+// (tools/prototypes/mlp_fwd_split_f16.hip), so small low pieces keep an absolute precision of 2^-24; values must stay below 65504.
+// The image keeps the three-slot record layout (slot 2 unused), so SplitPlan is shared.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8h(const float (&x)[8], f16x8& hi, f16x8& lo) {
+  u32x4 qh, ql;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
+    const f32x2 r = f32x2{x[2 * i], x[2 * i + 1]} - f32x2{(float)h2[0], (float)h2[1]};
+    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r.x, r.y);
+    qh[i] = __builtin_bit_cast(uint32_t, h2);
+    ql[i] = __builtin_bit_cast(uint32_t, l2);
+  }
+  hi = __builtin_bit_cast(f16x8, qh);
+  lo = __builtin_bit_cast(f16x8, ql);
+}
+// two pieces of a float for the pack kernel: {hi, lo} as 16-bit patterns
+__device__ __forceinline__ void split2h_bits(float x, uint32_t (&piece)[3]) {
+  const auto h2 = __builtin_amdgcn_cvt_pkrtz(x, 0.f);
+  const float r = x - (float)h2[0];
+  const auto l2 = __builtin_amdgcn_cvt_pkrtz(r, 0.f);
+  piece[0] = __builtin_bit_cast(uint32_t, h2) & 0xFFFFu;
+  piece[1] = __builtin_bit_cast(uint32_t, l2) & 0xFFFFu;
+  piece[2] = 0u;
+}
+
 // one k-step (16 inputs) into TO output tiles.  w_s -> record [to = 0][s][piece 0][lane 0]; `to` stride = ns*192 records.
-template <int TO>
+template <int TO, bool F16 = false>
 __device__ __forceinline__ void split_mac(f32x16 (&out)[TO], const float (&x)[8], const u32x4* __restrict__ w_s, int ns,
                                           int lane) {
+  if constexpr (F16) {
+    f16x8 bh, bl;
+    split8h(x, bh, bl);
+#pragma unroll
+    for (int to = 0; to < TO; to++) {
+      const u32x4* wt = w_s + to * ns * 192 + lane;
+      const f16x8 ah = __builtin_bit_cast(f16x8, wt[0]);
+      const f16x8 al = __builtin_bit_cast(f16x8, wt[64]);
+      out[to] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, out[to], 0, 0, 0);  // smallest terms first
+      out[to] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, out[to], 0, 0, 0);
+      out[to] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, out[to], 0, 0, 0);
+    }
+    return;
+  }
   bf16x8 b1, b2, b3;
   split8(x, b1, b2, b3);
 #pragma unroll
@@ -317,7 +360,7 @@ __device__ __forceinline__ void split_mac(f32x16 (&out)[TO], const float (&x)[8]
   }
 }
 
-template <int TI, int TO>
+template <int TI, int TO, bool F16 = false>
 __device__ __forceinline__ void split_chain(const f32x16 (&in)[TI], f32x16 (&out)[TO], const u32x4* __restrict__ w,
                                             int lane) {
 #pragma unroll
@@ -325,7 +368,7 @@ __device__ __forceinline__ void split_chain(const f32x16 (&in)[TI], f32x16 (&out
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) x[j] = in[s >> 1][8 * (s & 1) + j];
-    split_mac<TO>(out, x, w + s * 192, 2 * TI, lane);
+    split_mac<TO, F16>(out, x, w + s * 192, 2 * TI, lane);
   }
 }
 

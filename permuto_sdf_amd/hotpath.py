@@ -14,7 +14,7 @@ from . import _lib as L
 from . import parallel
 from .bridge import VolumeRendering as VR
 from .encoding import PermutoEncoding, encode_backward_raw, encode_forward_raw
-from .mlp import FusedMLP, mlp_backward_raw, mlp_forward_raw, pack_params
+from .mlp import FusedMLP, f16_forward_supported, mlp_backward_raw, mlp_forward_raw, pack_params
 from .neus import (FUSED_MAX_PER_RAY, neus_alpha_backward_raw, neus_alpha_forward_raw, neus_composite_backward_raw,
                    neus_composite_forward_raw)
 
@@ -44,6 +44,8 @@ class SdfHotPath:
         # wanted); the benchmark's synthetic radiance has no consumer for it
         self.fuse_compositing = True
         self.want_rgb_grad = True
+        import os
+        self.fwd_f16 = os.environ.get("PSDF_MLP_FWD_SPLIT", "f16") != "bf16"
 
     @staticmethod
     def _max_per_ray(rs):
@@ -60,14 +62,17 @@ class SdfHotPath:
         and the tensors the backward needs."""
         cfg = self.enc.cfg
         pos = rs.samples_pos
-        packed = pack_params(self.mlp.dims, [l.weight for l in self.mlp.layers], [l.bias for l in self.mlp.layers])
+        # two-piece fp16 forward where it exists (the BASELINE net): its inputs are encoding features and 1e-3-scaled points,
+        # far below fp16's range; PSDF_MLP_FWD_SPLIT=bf16 keeps the three-piece bf16 evaluation
+        f16 = self.fwd_f16 and f16_forward_supported(self.mlp.dims)
+        packed = pack_params(self.mlp.dims, [l.weight for l in self.mlp.layers], [l.bias for l in self.mlp.layers], f16=f16)
         # Two launches on purpose: the level-major encode kernel keeps one 2-MiB table at a time in every XCD's L2 and
         # runs at full occupancy, which measured faster than the single fused launch of csrc/fused.hip at this size
         # (tools/fused_bench.py: 0.38 + 0.67 ms against 1.13 ms); the fused launch is used where its per-sample skip
         # mask pays (sphere tracing).
         feat = encode_forward_raw(cfg, pos, self.enc.lattice_values.detach(), self.enc.scale_factor,
                                   self.enc.random_shift_per_level.detach(), self.window)
-        sdf = mlp_forward_raw(self.mlp.dims, feat, packed)                    # [1, N] feature-major == [N,1] memory
+        sdf = mlp_forward_raw(self.mlp.dims, feat, packed, f16=f16)           # [1, N] feature-major == [N,1] memory
         sdf_col = sdf.view(-1, 1)
         per_ray = self._max_per_ray(rs)
         if self.fuse_compositing and per_ray is not None:

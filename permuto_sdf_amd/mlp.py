@@ -26,8 +26,14 @@ def packed_size(dims):
     return int(r)
 
 
-def pack_params(dims, weights, biases):
-    """torch-layout weights/biases -> MFMA-operand ordered buffer (one small kernel)."""
+def f16_forward_supported(dims):
+    """psdf_mlp_forward_f16 exists for the BASELINE net: <= 64 inputs, 64x3, <= 4 outputs"""
+    return len(dims) == 5 and dims[0] <= 64 and dims[1] == dims[2] == dims[3] == 64 and dims[4] <= 4
+
+
+def pack_params(dims, weights, biases, f16=False):
+    """torch-layout weights/biases -> MFMA-operand ordered buffer (one small kernel).  f16: the split image holds two fp16
+    pieces per weight (for mlp_forward_raw(..., f16=True) only)."""
     n_layers = len(dims) - 1
     L.require_cuda(*weights)
     packed = torch.empty(packed_size(dims), dtype=torch.float32, device=weights[0].device)
@@ -35,16 +41,21 @@ def pack_params(dims, weights, biases):
     bs = [b.detach().contiguous() for b in biases]
     W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in ws])
     B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
-    L.call("psdf_mlp_pack", L.c_i(n_layers), _dims_array(dims), W, B, L.ptr(packed), L.stream())
+    L.call("psdf_mlp_pack_f16" if f16 else "psdf_mlp_pack", L.c_i(n_layers), _dims_array(dims), W, B, L.ptr(packed), L.stream())
     return packed
 
 
-def mlp_forward_raw(dims, x_fm, packed, skip=None, out=None):
+def mlp_forward_raw(dims, x_fm, packed, skip=None, out=None, f16=False):
     """x_fm [dims[0], N] feature-major -> y [dims[-1], N] feature-major.  `skip` [N]: 32-sample tiles that are masked
-    entirely are not evaluated (their entries of `out` stay as they are)."""
+    entirely are not evaluated (their entries of `out` stay as they are).  f16: the two-piece fp16 arithmetic (`packed` from
+    pack_params(..., f16=True); BASELINE net only; values below 65504)."""
     N = x_fm.shape[1]
     y = out if out is not None else torch.empty((dims[-1], N), dtype=torch.float32, device=x_fm.device)
-    if skip is None:
+    if f16:
+        assert skip is None
+        L.call("psdf_mlp_forward_f16", L.c_i(len(dims) - 1), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(y),
+               L.stream())
+    elif skip is None:
         L.call("psdf_mlp_forward", L.c_i(len(dims) - 1), _dims_array(dims), L.c_l(N), L.ptr(x_fm), L.ptr(packed), L.ptr(y),
                L.stream())
     else:

@@ -56,7 +56,7 @@ def test_step_on_the_benchmarked_kernels_matches_oracle(dev, nr_levels):
     pred, saved, out = hp.step(rs, rgb, normals, gt, reduce=False, optimizer_step=False)
     torch.cuda.synchronize()
     # the kernels bench.py times ran -- not their small-batch siblings
-    assert last_path(2) == 2, "MLP forward did not run mlp_fwd_split_kernel"
+    assert last_path(2) in (2, 3), "MLP forward did not run mlp_fwd_split_kernel (2: bf16 pieces, 3: fp16 pieces)"
     assert last_path(1) in (2, 4), "MLP backward did not run a split-operand kernel (2: bf16 pieces, 4: fp16 pieces)"
     assert last_path(0) == 2, "encode backward did not run the queue-mode binning + reduce kernels"
 
@@ -112,7 +112,7 @@ def test_cfg2_full_batch_subset_matches_oracle(dev):
     encode_backward_raw(cfg, pos, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
                         d_feat, g_lat, None)
     torch.cuda.synchronize()
-    assert (last_path(2), last_path(0)) == (2, 2) and last_path(1) in (2, 4)
+    assert last_path(2) in (2, 3) and last_path(0) == 2 and last_path(1) in (2, 4)
     # ---- oracle on the subset only
     lat = enc.lattice_values.detach().cpu().clone().requires_grad_(True)
     f_ref = po.encode(pos[sub].cpu(), lat, enc.scale_per_level, enc.random_shift_per_level.detach().cpu(), win.cpu(), True, 1e-3)

@@ -479,3 +479,35 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale):
     fn2 = L.lib().psdf_mlp_backward_split_f16
     assert fn2(L.c_i(4), _dims_array([36, 32, 32, 32, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
                arr(dWs), arr(dbs), L.stream()) == -2
+
+
+@pytest.mark.parametrize("K0,N", [(36, 200_003), (52, 70_000), (20, 4_097), (64, 33)])
+def test_split_f16_forward_against_float64(dev, K0, N):
+    """psdf_mlp_forward_f16 (two fp16 pieces per operand, three products; opt-in, the hot path's forward): against float64,
+    bar 4e-6 of the largest output (measured ~1e-6 relative: tools/prototypes/mlp_fwd_split_f16.hip: 2.8e-6 absolute at outputs
+    up to 2.5); inputs with small channels (encoding-like) included; other nets say -2."""
+    import copy
+    from permuto_sdf_amd._lib import PsdfError
+    from permuto_sdf_amd.mlp import f16_forward_supported, mlp_forward_raw, pack_params
+    torch.manual_seed(K0)
+    dims = [K0, 64, 64, 64, 1]
+    assert f16_forward_supported(dims) and not f16_forward_supported([K0, 32, 32, 32, 33])
+    lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
+    net = torch.nn.Sequential(lin[0], torch.nn.GELU(), lin[1], torch.nn.GELU(), lin[2], torch.nn.GELU(), lin[3]).to(dev)
+    x = torch.randn(N, K0, device=dev)
+    x[:, K0 // 2:] *= 1e-3
+    y64 = copy.deepcopy(net).double()(x.double())
+    ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+    ws, bs = [w.to(dev) for w in ws], [b.to(dev) for b in bs]
+    x_fm = x.t().contiguous()
+    y16 = mlp_forward_raw(dims, x_fm, pack_params(dims, ws, bs, f16=True), f16=True)
+    y_bf = mlp_forward_raw(dims, x_fm, pack_params(dims, ws, bs))
+    scale = float(y64.abs().max())
+    e16 = float((y16.t().double() - y64).abs().max()) / scale
+    ebf = float((y_bf.t().double() - y64).abs().max()) / scale
+    print("forward K0=%d N=%d: fp16 two-piece %.1e, bf16 three-piece %.1e (of the largest output)" % (K0, N, e16, ebf))
+    assert e16 <= 4e-6 and ebf <= 3e-6
+    with pytest.raises(PsdfError):
+        d2 = [K0, 32, 32, 32, 33]
+        l2 = [torch.nn.Linear(d2[i], d2[i + 1]).to(dev) for i in range(4)]
+        pack_params(d2, [l.weight for l in l2], [l.bias for l in l2], f16=True)
