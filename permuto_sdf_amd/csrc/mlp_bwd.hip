@@ -1203,6 +1203,17 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   hipStream_t st = (hipStream_t)stream;
   const int ti0 = p.tiles[0], t1 = p.tiles[1], t2 = p.tiles[2], t3 = (n_layers == 4) ? p.tiles[3] : 0,
             to = p.tiles[n_layers];
+  // 64-wide nets with MANY outputs (the background density / feature net 52 -> 64 x 3 -> 65, and 64 x 3 -> 33): their dW does
+  // not fit one wave's registers (the single-wave instantiations below spill 213-227 registers) -- the workgroup-cooperative
+  // kernel of mlp_wide.hip splits the dW rows over 8 waves.  -2 (no stream-ordered scratch: capture) falls through.
+  const char* many = getenv("PSDF_MLP_BWD_WIDE_MANY");     // "0": keep the single-wave kernel (A/B measurements)
+  if (dW && n_layers == 4 && to >= 2 && t1 == 4 && t2 == 4 && t3 == 4 && !(many && many[0] == '0')) {
+    const int r = psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
+    if (r != PSDF_ERR_UNSUPPORTED) {
+      psdf::g_last_path[psdf::PATH_MLP_BWD] = 3;
+      return r;
+    }
+  }
   psdf::g_last_path[psdf::PATH_MLP_BWD] = 1;
 #define CASE(I, A, B, C, O, D)                                                   \
   if (ti0 == I && t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \

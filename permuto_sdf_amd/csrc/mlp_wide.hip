@@ -133,19 +133,23 @@ __device__ __forceinline__ void layer_dh(const float* __restrict__ WT, int out_p
   }
 }
 
-// gradient image of one workgroup (floats): dW1 [T1*16][TI0*16], dW2 [T2*16][T1*16], dW3 [T3*16][T2*16], dW4 [16][T3*16],
+// gradient image of one workgroup (floats): dW1 [T1*16][TI0*16], dW2 [T2*16][T1*16], dW3 [T3*16][T2*16], dW4 [T4*16][T3*16],
 // then db1, db2, db3, db4 (padded widths)
-template <int TI0, int T1, int T2, int T3>
+template <int TI0, int T1, int T2, int T3, int T4>
 struct GImg {
   static constexpr int W1 = 0, W2 = W1 + T1 * 16 * TI0 * 16, W3 = W2 + T2 * 16 * T1 * 16, W4 = W3 + T3 * 16 * T2 * 16,
-                       B1 = W4 + 16 * T3 * 16, B2 = B1 + T1 * 16, B3 = B2 + T2 * 16, B4 = B3 + T3 * 16, TOTAL = B4 + 16;
+                       B1 = W4 + T4 * 16 * T3 * 16, B2 = B1 + T1 * 16, B3 = B2 + T2 * 16, B4 = B3 + T3 * 16,
+                       TOTAL = B4 + T4 * 16;
 };
 
-template <int TI0, int T1, int T2, int T3>
+// T4 = output tiles of the (linear) last layer: 1 for the colour network (3 outputs), 5 for the background density / feature
+// net 52 -> 64 x 3 -> 65 (models.py:451-459), whose single-wave fp32 kernel ran out of the register file (213-227 spilled
+// registers, 209 us per call at 23 k samples: the second most expensive kernel of the training step until round 3).
+template <int TI0, int T1, int T2, int T3, int T4>
 __global__ void __launch_bounds__(WN * 64, 1)
     mlp_wide_bwd_kernel(WideArgs a, int64_t N, const float* __restrict__ X, const float* __restrict__ dY,
                         float* __restrict__ dX, float* __restrict__ partial) {
-  static_assert(TI0 <= WN && T1 <= WN && T2 <= WN && T3 <= WN, "one output tile per wave and layer");
+  static_assert(TI0 <= WN && T1 <= WN && T2 <= WN && T3 <= WN && T4 <= WN, "one output tile per wave and layer");
   extern __shared__ __align__(16) float lds[];
   float* H0 = lds;                         // [TI0*16][RS]   inputs
   float* H1 = H0 + TI0 * 16 * RS;          // activations
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(WN * 64, 1)
   float* D1 = H3 + T3 * 16 * RS;           // gelu' of the layer, overwritten by dZ
   float* D2 = D1 + T1 * 16 * RS;
   float* D3 = D2 + T2 * 16 * RS;
-  float* D4 = D3 + T3 * 16 * RS;           // [16][RS]: upstream gradient of the (linear) last layer, rows >= out are zero
+  float* D4 = D3 + T3 * 16 * RS;           // [T4*16][RS]: upstream gradient of the (linear) last layer, rows >= out are zero
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int K0 = a.dims[0], OUT = a.dims[4];
   const int in_pad[4] = {TI0 * 16, T1 * 16, T2 * 16, T3 * 16};
@@ -178,7 +182,7 @@ __global__ void __launch_bounds__(WN * 64, 1)
       const int64_t n = n0 + s;
       H0[row * RS + s] = (row < K0 && n < N) ? X[(int64_t)row * N + n] : 0.f;
     }
-    for (int e = threadIdx.x; e < 16 * TS; e += WN * 64) {
+    for (int e = threadIdx.x; e < T4 * 16 * TS; e += WN * 64) {
       const int row = e / TS, s = e % TS;
       const int64_t n = n0 + s;
       D4[row * RS + s] = (row < OUT && n < N) ? dY[(int64_t)row * N + n] : 0.f;
@@ -192,11 +196,11 @@ __global__ void __launch_bounds__(WN * 64, 1)
     if (wave < T3) layer_fwd<T2, true>(a.W[2], in_pad[2], a.b[2], a.dims[3], wave, H2, H3, D3, c, g);
     __syncthreads();
     // (the last layer's output is not needed: the upstream gradient is given)
-    // ---- backward, layer 4 (linear): dW4, db4 by wave 0; dH3 -> dZ3 by the owners of H3's tiles
-    if (wave == 0) layer_dw<T3>(D4, H3, 0, dW4, db4, c, g);
+    // ---- backward, layer 4 (linear): dW4, db4 by the owners of its output tiles; dH3 -> dZ3 by the owners of H3's tiles
+    if (wave < T4) layer_dw<T3>(D4, H3, wave, dW4, db4, c, g);
     if (wave < T3) {
       f32x4 acc[2];
-      layer_dh<1>(a.WT[3], 16, wave, D4, acc, c, g);
+      layer_dh<T4>(a.WT[3], T4 * 16, wave, D4, acc, c, g);
 #pragma unroll
       for (int sb = 0; sb < 2; sb++)
 #pragma unroll
@@ -251,7 +255,7 @@ __global__ void __launch_bounds__(WN * 64, 1)
   }
   // ---- the wave's accumulators -> this workgroup's gradient image.  D layout of an MFMA result: lane (col = c, g), register
   // r = row 4 g + r; the dW tiles have rows = output feature (own tile), cols = input feature.
-  using GI = GImg<TI0, T1, T2, T3>;
+  using GI = GImg<TI0, T1, T2, T3, T4>;
   float* img = partial + (size_t)blockIdx.x * GI::TOTAL;
   auto put = [&](int base, int ncols_pad, int to, int ntiles_in, const f32x4* acc) {
     for (int ti = 0; ti < ntiles_in; ti++)
@@ -266,14 +270,14 @@ __global__ void __launch_bounds__(WN * 64, 1)
   if (wave < T1) { put(GI::W1, TI0 * 16, wave, TI0, dW1); put_db(GI::B1, wave, db1); }
   if (wave < T2) { put(GI::W2, T1 * 16, wave, T1, dW2); put_db(GI::B2, wave, db2); }
   if (wave < T3) { put(GI::W3, T2 * 16, wave, T2, dW3); put_db(GI::B3, wave, db3); }
-  if (wave == 0) { put(GI::W4, T3 * 16, 0, T3, dW4); put_db(GI::B4, 0, db4); }
+  if (wave < T4) { put(GI::W4, T3 * 16, wave, T3, dW4); put_db(GI::B4, wave, db4); }
 }
 
 // sum of the workgroup images -> ACCUMULATED into the torch-layout gradients of the (normalised) weights
-template <int TI0, int T1, int T2, int T3>
+template <int TI0, int T1, int T2, int T3, int T4>
 __global__ void mlp_wide_reduce_kernel(const float* __restrict__ partial, int nimg, WideArgs a, float* dW0, float* dW1,
                                        float* dW2, float* dW3, float* db0, float* db1, float* db2, float* db3) {
-  using GI = GImg<TI0, T1, T2, T3>;
+  using GI = GImg<TI0, T1, T2, T3, T4>;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= GI::TOTAL) return;
   float s = 0.f;
@@ -346,6 +350,44 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// pack (both weight orientations, zero padded), main launch, summing launch
+template <int TI0, int T1, int T2, int T3, int T4>
+int wide_launch(const int* dims, int64_t N, const float* X, const float* const* weights, const float* const* biases,
+                const float* dY, float* dX, float* const* dW, float* const* db, hipStream_t st) {
+  using GI = GImg<TI0, T1, T2, T3, T4>;
+  const int pads[5] = {TI0 * 16, T1 * 16, T2 * 16, T3 * 16, T4 * 16};
+  size_t wfloats = 0;
+  for (int l = 0; l < 4; l++) wfloats += 2 * (size_t)pads[l] * pads[l + 1];
+  const int64_t ntiles = (N + TS - 1) / TS;
+  int64_t blocks = ntiles < 256 ? ntiles : 256;
+  char* scratch = (char*)psdf::stream_scratch((wfloats + (size_t)blocks * GI::TOTAL) * sizeof(float), st);  // NULL while capturing
+  if (!scratch) return PSDF_ERR_UNSUPPORTED;
+  WideArgs a;
+  float* wp = reinterpret_cast<float*>(scratch);
+  for (int l = 0; l < 4; l++) {
+    const int n = pads[l] * pads[l + 1];
+    float* Wp = wp;
+    float* WTp = wp + n;
+    wp += 2 * n;
+    hipLaunchKernelGGL(mlp_wide_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dims[l + 1], dims[l], pads[l + 1],
+                       pads[l], weights[l], Wp, WTp);
+    a.W[l] = Wp;
+    a.WT[l] = WTp;
+    a.b[l] = biases[l];
+  }
+  for (int i = 0; i < 5; i++) a.dims[i] = dims[i];
+  float* partial = wp;
+  const size_t lds_bytes = (size_t)((TI0 + 2 * T1 + 2 * T2 + 2 * T3 + T4) * 16) * RS * sizeof(float);
+  auto kern = mlp_wide_bwd_kernel<TI0, T1, T2, T3, T4>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, dY, dX, partial);
+  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3, T4>), dim3((GI::TOTAL + 255) / 256, 8), dim3(256), 0, st, partial,
+                     (int)blocks, a, dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -369,52 +411,27 @@ int psdf_lipshitz_normalize_backward(int out, int in, const float* W, const floa
   return PSDF_OK;
 }
 
-// Same contract as psdf_mlp_backward (include/psdf.h) for 4-layer nets whose widths the narrow kernels do not hold:
-// dims[0] <= 112, dims[1], dims[2] <= 128, dims[3] <= 64, dims[4] <= 16; -2 otherwise.  The reference's colour network
-// (LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3, models.py:349-350) is the net it is instantiated for.
+// Same contract as psdf_mlp_backward (include/psdf.h) for 4-layer nets whose dW does not fit one wave's registers:
+//   * dims[0] <= 112, dims[1], dims[2] <= 128, dims[3] <= 64, dims[4] <= 16 (not both hidden widths <= 64): the reference's colour
+//     network, LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3 (models.py:349-350);
+//   * dims[0..3] <= 64, 16 < dims[4] <= 80: the background density / feature net 52 -> 64 x 3 -> 65 (models.py:451-459) and
+//     64 x 3 -> 33 (round 3);
+// -2 otherwise.
 int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
                            const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
                            void* stream) {
-  constexpr int TI0 = 7, T1 = 8, T2 = 8, T3 = 4;
   if (n_layers != 4 || !dims || !dW || !db) return PSDF_ERR_UNSUPPORTED;
-  if (dims[0] > TI0 * 16 || dims[1] > T1 * 16 || dims[2] > T2 * 16 || dims[3] > T3 * 16 || dims[4] > 16) return PSDF_ERR_UNSUPPORTED;
-  if (dims[1] <= 64 && dims[2] <= 64) return PSDF_ERR_UNSUPPORTED;   // the narrow family's territory
   if (N <= 0 || !X || !weights || !biases || !dY) return PSDF_ERR_ARG;
   for (int l = 0; l < 4; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  using GI = GImg<TI0, T1, T2, T3>;
-  const int pads[5] = {TI0 * 16, T1 * 16, T2 * 16, T3 * 16, 16};
-  size_t wfloats = 0;
-  for (int l = 0; l < 4; l++) wfloats += 2 * (size_t)pads[l] * pads[l + 1];
-  const int64_t ntiles = (N + TS - 1) / TS;
-  int64_t blocks = ntiles < 256 ? ntiles : 256;
-  char* scratch = (char*)psdf::stream_scratch((wfloats + (size_t)blocks * GI::TOTAL) * sizeof(float), st);  // NULL while capturing
-  if (!scratch) return PSDF_ERR_UNSUPPORTED;
-  WideArgs a;
-  float* wp = reinterpret_cast<float*>(scratch);
-  for (int l = 0; l < 4; l++) {
-    const int n = pads[l] * pads[l + 1];
-    float* Wp = wp;
-    float* WTp = wp + n;
-    wp += 2 * n;
-    hipLaunchKernelGGL(mlp_wide_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dims[l + 1], dims[l], pads[l + 1],
-                       pads[l], weights[l], Wp, WTp);
-    a.W[l] = Wp;
-    a.WT[l] = WTp;
-    a.b[l] = biases[l];
-  }
-  for (int i = 0; i < 5; i++) a.dims[i] = dims[i];
-  float* partial = wp;
-  const size_t lds_bytes = (size_t)((TI0 + 2 * T1 + 2 * T2 + 2 * T3 + 1) * 16) * RS * sizeof(float);
-  auto kern = mlp_wide_bwd_kernel<TI0, T1, T2, T3>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, dY, dX, partial);
-  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3>), dim3((GI::TOTAL + 255) / 256, 8), dim3(256), 0, st, partial,
-                     (int)blocks, a, dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
-  PSDF_LAUNCH_CHECK();
-  return PSDF_OK;
+  // the colour network (111 -> 128 -> 128 -> 64 -> 3) and anything that fits its tile counts with one output tile
+  if (dims[0] <= 112 && dims[1] <= 128 && dims[2] <= 128 && dims[3] <= 64 && dims[4] <= 16 && !(dims[1] <= 64 && dims[2] <= 64))
+    return wide_launch<7, 8, 8, 4, 1>(dims, N, X, weights, biases, dY, dX, dW, db, st);
+  // the background density / feature net (52 -> 64 x 3 -> 65) and its 33-output sibling: up to 80 outputs, 64-wide hidden layers
+  if (dims[0] <= 64 && dims[1] <= 64 && dims[2] <= 64 && dims[3] <= 64 && dims[4] > 16 && dims[4] <= 80)
+    return wide_launch<4, 4, 4, 4, 5>(dims, N, X, weights, biases, dY, dX, dW, db, st);
+  return PSDF_ERR_UNSUPPORTED;
 }
 
 }  // extern "C"

@@ -73,5 +73,26 @@ def test_split_bf16_backward_of_the_baseline_net_does_not_spill(objdir, tmp_path
 
 def test_split_bf16_forward_fits_two_workgroups_per_cu(objdir, tmp_path):
     k = _kernels(os.path.join(objdir, "mlp.o"), str(tmp_path))
-    f = _one(k, r"mlp_fwd_split_kernelILi2ELi2ELi2ELi1ELb1ELi3E")           # 36 -> 64 x 3 -> 1, the bench net
+    f = _one(k, r"mlp_fwd_split_kernelILi2ELi2ELi2ELi1ELb1ELi3ELb0E")       # 36 -> 64 x 3 -> 1, the bench net, bf16 pieces
     assert f["vgpr_count"] <= 128 and f["vgpr_spill_count"] == 0, f
+    f16 = _one(k, r"mlp_fwd_split_kernelILi2ELi2ELi2ELi1ELb1ELi3ELb1E")     # the same net, two fp16 pieces (round 3)
+    assert f16["vgpr_count"] <= 256 and f16["vgpr_spill_count"] == 0 and f16["private_segment_fixed_size"] == 0, f16
+
+
+def test_round3_kernels_do_not_spill(objdir, tmp_path):
+    """the fp16 two-piece backward of the BASELINE net (one wave per SIMD, accumulators in AGPRs), the workgroup-cooperative
+    backward of the background density net (52 -> 64 x 3 -> 65: its single-wave predecessor spilled 213-227 registers) and the
+    fused compositing kernels"""
+    k = _kernels(os.path.join(objdir, "mlp_bwd_split_f16.o"), str(tmp_path))
+    for pat in (r"mlp_bwd_split_f16_kernelILi3ELb1E", r"mlp_bwd_split_f16_kernelILi4ELb1E"):
+        b = _one(k, pat)
+        assert b["vgpr_count"] <= 512 and b["agpr_count"] >= 176, b
+        assert b["vgpr_spill_count"] == 0 and b["private_segment_fixed_size"] == 0, b
+    k = _kernels(os.path.join(objdir, "mlp_wide.o"), str(tmp_path))
+    for pat in (r"mlp_wide_bwd_kernelILi7ELi8ELi8ELi4ELi1E", r"mlp_wide_bwd_kernelILi4ELi4ELi4ELi4ELi5E"):
+        b = _one(k, pat)
+        assert b["vgpr_count"] <= 256 and b["vgpr_spill_count"] == 0 and b["private_segment_fixed_size"] == 0, b   # 2 waves / SIMD
+    k = _kernels(os.path.join(objdir, "composite_fused.o"), str(tmp_path))
+    for pat in (r"neus_composite_fwd_kernel", r"neus_composite_bwd_kernelILi2E", r"neus_composite_bwd_kernelILi4E"):
+        b = _one(k, pat)
+        assert b["vgpr_count"] <= 64 and b["vgpr_spill_count"] == 0, b

@@ -10,7 +10,7 @@ from permuto_sdf_amd.mlp import mlp_backward_raw  # noqa: E402
 
 dev = torch.device("cuda:0")
 dims = [int(a) for a in (sys.argv[1].split("-") if len(sys.argv) > 1 else "36-64-64-64-1".split("-"))]
-N = 2 ** 21
+N = int(os.environ.get("PSDF_BENCH_N", 2 ** 21))
 torch.manual_seed(0)
 m = FusedMLP(dims).to(dev)
 x = torch.randn(dims[0], N, device=dev)
