@@ -324,7 +324,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
