@@ -1,0 +1,291 @@
+"""BASELINE config 4 with a HAND-WRITTEN backward: the same optimisation step as `train_step.Trainer` (same networks, samplers,
+losses, schedule, optimiser, data-parallel reduction -- it IS a Trainer), but the main phase's forward and backward are
+written out over the raw feature-major kernels instead of being recorded and replayed by torch autograd.
+
+Why: the step is host bound (train_step.py): ~250 launches, the autograd engine's bookkeeping
+(`run_backward` alone is a third of the host time), [N, C] <-> [C, N] glue around every Function, gradient-accumulation adds
+and zero fills that autograd inserts.  Written by hand, every tensor stays feature-major, every gradient is produced once where
+it is needed, the three evaluations of the SDF network share one parameter image, and the four contributions to the SDF
+network's parameter gradient land in one buffer.
+
+What is differentiated (train_permuto_sdf.py:311-429, run_net :111-169; names as in train_step.py):
+  fg samples -> SDF net: y = mlp(enc(p)) -> sdf = y[0], geom = y[1:33];  n = d sdf / d p  (MLP data backward of e0, then the
+  encoding's position backward);  colour = sigmoid(Lipshitz-MLP([enc2(p), SH5(dir), normalize(n), geom]));
+  (radiance, bgT) = NeuS(sdf, n, colour);  bg samples -> NerfHash -> radiance_bg;  pred = radiance + bgT * radiance_bg;
+  loss = L1(pred, gt) + w_e eikonal(n) + w_c curvature(n, n(p + eps cross(norm n, norm r))) + w_o offsurface(sdf(p_off)) [+ Lipschitz].
+The backward of  n = d sdf / d p  is the double backward: `psdf_encode_double_backward` (gradient w.r.t. the lattice and w.r.t.
+the feature gradient) -> `psdf_mlp_double_backward` (gradient w.r.t. features and parameters) -> the encoding's lattice backward.
+`tests/test_gpu_train_step.py::test_manual_backward_equals_autograd` holds every gradient of this file against the autograd
+trainer's on the same batch.
+"""
+import torch
+
+from . import _lib as L
+from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
+from .encoding import _head, _tail, encode_backward_raw, encode_forward_raw
+from .mlp import mlp_backward_raw, mlp_double_backward, mlp_forward_raw, pack_params
+from .neus import eikonal_loss_raw, l1_loss_raw, neus_composite_backward_raw, neus_composite_forward_raw
+from .train_step import Trainer, map_range_val
+
+
+def _enc_fwd(enc, pts, win, train=True):
+    tr = enc.touched_rows
+    return encode_forward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
+                              touched=tr.touched if train else None, block_rows_log2=tr.block_rows_log2)
+
+
+def _enc_bwd(enc, pts, win, g_fm, want_pos=False, want_lattice=True):
+    """lattice gradient into the encoding's persistent buffer; optionally the position gradient [N, P]"""
+    g_pos = torch.zeros_like(pts) if want_pos else None
+    encode_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win, g_fm,
+                        enc.touched_rows.grad if want_lattice else None, g_pos)
+    return g_pos
+
+
+def _enc_dbl_bwd(enc, pts, win, dd_pos, g_fm):
+    """backward of the position gradient: adds to the lattice buffer, returns the gradient w.r.t. the feature gradient [C, N]"""
+    gg = torch.empty_like(g_fm)
+    cfg = enc.cfg
+    L.call("psdf_encode_double_backward", *_head(cfg, pts.shape[0]), L.ptr(pts), L.ptr(enc.lattice_values.detach()),
+           L.ptr(enc.scale_factor), L.ptr(enc.random_shift_per_level.detach()), L.ptr(win), *_tail(cfg), L.ptr(dd_pos), L.ptr(g_fm),
+           L.ptr(enc.touched_rows.grad), L.ptr(gg), L.stream())
+    return gg
+
+
+def _normalize3(x, gy=None):
+    out = torch.empty_like(x)
+    L.call("psdf_normalize3", L.c_l(x.shape[0]), L.ptr(x), L.ptr(gy), L.ptr(out), L.stream())
+    return out
+
+
+def _set_grads(layers, dWs, dbs):
+    for l, dW, db in zip(layers, dWs, dbs):
+        l.weight.grad, l.bias.grad = dW, db
+
+
+class ManualTrainer(Trainer):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        assert self.touched, "ManualTrainer accumulates the lattice gradients in the touched-rows buffers"
+
+    def _unit_row(self, rows, N):
+        """[rows, N] feature-major upstream gradient that selects output 0 (d sdf / d .)"""
+        t = torch.zeros((rows, N), dtype=torch.float32, device=self.dev)
+        t[0].fill_(1.0)
+        return t
+
+    # ------------------------------------------------------------------ the SDF network, one evaluation
+    def _sdf_gradient(self, feat, pts, win, ws, bs):
+        """n = d sdf / d p and the feature gradient it came through"""
+        dims = self.sdf.mlp_sdf.dims
+        e0 = self._unit_row(dims[-1], pts.shape[0])
+        dfeat, _, _ = mlp_backward_raw(dims, feat, ws, bs, e0, need_dx=True, need_dw=False)
+        n = _enc_bwd(self.sdf.encoding, pts, win, dfeat, want_pos=True, want_lattice=False)
+        return n, dfeat, e0
+
+    def _sdf_gradient_backward(self, g_n, feat, dfeat, e0, pts, win, ws, bs, gb, want_pos=False, extra_dfeat=None):
+        """backward of  n = d sdf / d p  for an upstream g_n [N,3]: lattice and parameter gradients are accumulated; returns the
+        position gradient when asked (the shifted points of the curvature term depend on n)"""
+        enc, dims = self.sdf.encoding, self.sdf.mlp_sdf.dims
+        gg = _enc_dbl_bwd(enc, pts, win, g_n, dfeat)
+        dX2, _, _ = mlp_double_backward(dims, feat, ws, bs, e0, gg, into=(gb.dWs, gb.dbs), module=self.sdf.mlp_sdf)
+        if extra_dfeat is not None:
+            dX2 = dX2 + extra_dfeat
+        return _enc_bwd(enc, pts, win, dX2, want_pos=want_pos)
+
+    # ------------------------------------------------------------------ one iteration of the main phase
+    def _main_phase(self, reel, it, git, eikonal_weight):
+        hp, dev = self.hp, self.dev
+        cos_r = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
+        forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
+        with torch.no_grad():
+            o, d, gt, hit, img_idx = self._draw_rays(reel)
+            fg, bg = self._samples(o, d, it, True)
+            R = o.shape[0]
+            n_fg = fg.samples_pos.shape[0]
+            cc = self.colorcal
+            sdfn, rgbn, bgn = self.sdf, self.rgb, self.bg
+            gb = self.grad_buffers[0]
+            lin = list(sdfn.mlp_sdf.layers)
+            ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+            dims_s = sdfn.mlp_sdf.dims
+            win = sdfn.window(it).contiguous()
+            packed_s = pack_params(dims_s, ws, bs)
+            inv_s = torch.exp(torch.tensor(float(forced_variance) * 10.0, device=dev)).clip(1e-6, 1e6).view(1)
+            rgbn.last_inv_s = inv_s.view(())
+            loss = torch.zeros((), device=dev)
+            # ================================================================= forward
+            if n_fg:
+                pts, dirs = fg.samples_pos, fg.samples_dirs
+                feat = _enc_fwd(sdfn.encoding, pts, win)
+                y = mlp_forward_raw(dims_s, feat, packed_s)                                   # [33, N]: sdf, geometry features
+                n, dfeat, e0 = self._sdf_gradient(feat, pts, win, ws, bs)
+                # colour network
+                feat2 = _enc_fwd(rgbn.encoding, pts, rgbn._win)
+                sh = PermutoSDF.spherical_harmonics(dirs, 5)
+                nn = _normalize3(n)
+                x_rgb = torch.cat([feat2, sh.t(), nn.t(), y[1:]], 0)                         # [111, N]
+                c_enc, c_sh = feat2.shape[0], feat2.shape[0] + sh.shape[1]
+                m = rgbn.mlp
+                wn = []
+                for w, c in zip(m.weights_per_layer, m.lipshitz_bound_per_layer):
+                    o_ = torch.empty_like(w)
+                    L.call("psdf_lipshitz_normalize_forward", L.c_i(w.shape[0]), L.c_i(w.shape[1]), L.ptr(w.detach()), L.ptr(c.detach()),
+                           L.ptr(o_), L.stream())
+                    wn.append(o_)
+                bsr = [b.detach() for b in m.biases_per_layer]
+                rgb_raw = mlp_forward_raw(m.dims, x_rgb, pack_params(m.dims, wn, bsr)).t().contiguous()        # [N, 3]
+                if cc is not None:
+                    ridx_fg = RaySamplesPacked.compute_per_sample_ray_idx(fg.ray_start_end_idx, n_fg).long()
+                    cam = img_idx.long()
+                    fixed = (cam == cc.idx_with_fixed_calib)[:, None]
+                    cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
+                    cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
+                    rgb_pre = rgb_raw * cw.index_select(0, ridx_fg) + cb.index_select(0, ridx_fg)
+                else:
+                    rgb_pre = rgb_raw
+                rgb = torch.sigmoid(rgb_pre)
+                per_ray = hp.max_nr_samples_per_ray + 2 * hp.nr_samples_imp_sampling
+                sdf_col = y[0].view(-1, 1)
+                pred_fg, bgT, _ = neus_composite_forward_raw(fg, sdf_col, n, rgb, inv_s, cos_r)
+            else:
+                pred_fg = torch.zeros(R, 3, device=dev)
+                bgT = torch.ones(R, 1, device=dev)
+            # background NeRF
+            M = bg.samples_pos_4d.shape[0]
+            p4, dirs_b = bg.samples_pos_4d, bg.samples_dirs
+            feat4 = _enc_fwd(bgn.encoding, p4, bgn._win)
+            l1b = list(bgn.mlp_feat_and_density.layers)
+            w1b, b1b = [l.weight for l in l1b], [l.bias for l in l1b]
+            d1 = bgn.mlp_feat_and_density.dims
+            fd = mlp_forward_raw(d1, feat4, pack_params(d1, w1b, b1b))                        # [65, M]
+            gel = torch.nn.functional.gelu(fd[1:65])
+            sh4 = PermutoSDF.spherical_harmonics(dirs_b, 4)
+            x2 = torch.cat([gel, sh4.t()], 0)                                                 # [80, M]
+            l2b = list(bgn.mlp_rgb.layers)
+            w2b, b2b = [l.weight for l in l2b], [l.bias for l in l2b]
+            d2 = bgn.mlp_rgb.dims
+            rgbb_raw = mlp_forward_raw(d2, x2, pack_params(d2, w2b, b2b)).t().contiguous()    # [M, 3]
+            if cc is not None:
+                ridx_bg = RaySamplesPacked.compute_per_sample_ray_idx(bg.ray_start_end_idx, M).long()
+                if not n_fg:
+                    cam = img_idx.long()
+                    fixed = (cam == cc.idx_with_fixed_calib)[:, None]
+                    cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
+                    cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
+                rgbb_pre = rgbb_raw * cw.index_select(0, ridx_bg) + cb.index_select(0, ridx_bg)
+            else:
+                rgbb_pre = rgbb_raw
+            rgbb = torch.sigmoid(rgbb_pre)
+            raw_den = fd[0].contiguous()
+            dt_b = bg.samples_dt.reshape(-1).contiguous()
+            alpha_b, om_b = torch.empty_like(raw_den), torch.empty_like(raw_den)
+            L.call("psdf_nerf_alpha_forward", L.c_l(M), L.ptr(raw_den), L.ptr(dt_b), L.ptr(alpha_b), L.ptr(om_b), L.stream())
+            T_b, bgT_b = VR.cumprod_alpha2transmittance(bg, om_b.view(-1, 1))
+            w_b = alpha_b.view(-1, 1) * T_b
+            pred_bg = VR.integrate_with_weights(bg, rgbb, w_b)
+            pred = pred_fg + bgT * pred_bg
+            # ---- losses (forward values; their gradients are produced by the same launches)
+            l_rgb, g_pred = l1_loss_raw(pred, gt, hit)
+            loss = loss + l_rgb.view(())
+            g_n = None
+            curv = None
+            if n_fg:
+                l_e, g_n = eikonal_loss_raw(n, scale=eikonal_weight / n_fg)
+                loss = loss + l_e.view(())
+                gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
+                if gw > 0.0:
+                    rnd = torch.randn_like(pts)
+                    shifted = torch.empty_like(pts)
+                    L.call("psdf_curvature_shift", L.c_l(n_fg), L.ptr(pts), L.ptr(n), L.ptr(rnd), L.c_f(1e-4), None, L.ptr(shifted),
+                           L.stream())
+                    feat_s = _enc_fwd(sdfn.encoding, shifted, win)
+                    n2, dfeat_s, _ = self._sdf_gradient(feat_s, shifted, win, ws, bs)
+                    l_c = L.zeroed_scalar(dev)
+                    ga, gb2 = torch.empty_like(n), torch.empty_like(n2)
+                    L.call("psdf_curvature_loss", L.c_l(n_fg), L.ptr(n), L.ptr(n2), L.c_f(hp.curvature_weight * gw / n_fg), L.ptr(l_c),
+                           L.ptr(ga), L.ptr(gb2), L.stream())
+                    loss = loss + l_c.view(())
+                    curv = (rnd, shifted, feat_s, dfeat_s, ga, gb2)
+            off = self.sphere.rand_points_inside(1024)
+            feat_o = _enc_fwd(sdfn.encoding, off, win)
+            y_o = mlp_forward_raw(dims_s, feat_o, packed_s)
+            l_o = L.zeroed_scalar(dev)
+            g_so = torch.empty(1024, dtype=torch.float32, device=dev)
+            L.call("psdf_offsurface_loss", L.c_l(1024), L.ptr(y_o[0].contiguous()), L.c_f(1e2), L.c_f(hp.offsurface_weight / 1024.0),
+                   L.ptr(l_o), L.ptr(g_so), L.stream())
+            loss = loss + l_o.view(())
+            self._refresh_and_adapt(it, git, n_fg)
+
+            # ================================================================= backward
+            # pred = pred_fg + bgT * pred_bg
+            g_bgT = (g_pred * pred_bg).sum(1, keepdim=True)
+            g_pred_bg = bgT * g_pred
+            # ---- background branch
+            g_rgbb, g_wb = VR.integrate_with_weights_backward(g_pred_bg, bg, rgbb, w_b, None)
+            g_Tb = g_wb * alpha_b.view(-1, 1)
+            cs = VR.cumsum_over_each_ray(bg, g_Tb * T_b, True)
+            g_omb = VR.cumprod_alpha2transmittance_backward(g_Tb, torch.zeros_like(bgT_b), bg, om_b.view(-1, 1), T_b, bgT_b, cs)
+            g_alb = g_wb * T_b
+            g_raw = torch.empty_like(raw_den)
+            L.call("psdf_nerf_alpha_backward", L.c_l(M), L.ptr(raw_den), L.ptr(dt_b), L.ptr(g_alb.reshape(-1).contiguous()),
+                   L.ptr(g_omb.reshape(-1).contiguous()), L.ptr(g_raw), L.stream())
+            g_pre_b = g_rgbb * rgbb * (1.0 - rgbb)                                            # sigmoid
+            g_cw = g_cb = None
+            if cc is not None:
+                g_cb = torch.zeros(R, 3, device=dev).index_add_(0, ridx_bg, g_pre_b)
+                g_cw = torch.zeros(R, 3, device=dev).index_add_(0, ridx_bg, g_pre_b * rgbb_raw)
+                g_pre_b = g_pre_b * cw.index_select(0, ridx_bg)
+            dX2b, dW2b, db2b = mlp_backward_raw(d2, x2, w2b, b2b, g_pre_b.t().contiguous(), need_dx=True)
+            _set_grads(l2b, dW2b, db2b)
+            g_fd = torch.cat([g_raw.view(1, -1), torch.ops.aten.gelu_backward(dX2b[:64], fd[1:65])], 0)      # [65, M]
+            dX4, dW1b, db1b = mlp_backward_raw(d1, feat4, w1b, b1b, g_fd, need_dx=True)
+            _set_grads(l1b, dW1b, db1b)
+            _enc_bwd(bgn.encoding, p4, bgn._win, dX4)
+            # ---- foreground
+            if n_fg:
+                g_sdf, g_nc, g_rgb, _ = neus_composite_backward_raw(fg, per_ray, g_pred.contiguous(), g_bgT.contiguous(), sdf_col, n,
+                                                                    rgb, inv_s, cos_r, need_grad=True, need_rgb=True, need_inv_s=False)
+                g_pre = g_rgb * rgb * (1.0 - rgb)
+                if cc is not None:
+                    g_cb.index_add_(0, ridx_fg, g_pre)
+                    g_cw.index_add_(0, ridx_fg, g_pre * rgb_raw)
+                    g_pre = g_pre * cw.index_select(0, ridx_fg)
+                dXr, dWn, dbr = mlp_backward_raw(m.dims, x_rgb, wn, bsr, g_pre.t().contiguous(), need_dx=True)
+                for i, (w, c) in enumerate(zip(m.weights_per_layer, m.lipshitz_bound_per_layer)):
+                    dw = torch.empty_like(w)
+                    dc = torch.zeros_like(c)
+                    L.call("psdf_lipshitz_normalize_backward", L.c_i(w.shape[0]), L.c_i(w.shape[1]), L.ptr(w.detach()), L.ptr(c.detach()),
+                           L.ptr(dWn[i]), L.ptr(dw), L.ptr(dc), L.stream())
+                    w.grad, c.grad, m.biases_per_layer[i].grad = dw, dc, dbr[i]
+                _enc_bwd(rgbn.encoding, pts, rgbn._win, dXr[:c_enc])
+                g_n = g_n + g_nc + _normalize3(n, dXr[c_sh:c_sh + 3].t().contiguous())
+                g_y = torch.cat([g_sdf.view(1, -1), dXr[c_sh + 3:]], 0)                           # [33, N]
+                if curv is not None:
+                    rnd, shifted, feat_s, dfeat_s, ga, gb2 = curv
+                    g_n = g_n + ga
+                    g_shift = self._sdf_gradient_backward(gb2, feat_s, dfeat_s, e0, shifted, win, ws, bs, gb, want_pos=True)
+                    g_from_shift = torch.empty_like(n)
+                    L.call("psdf_curvature_shift", L.c_l(n_fg), None, L.ptr(n), L.ptr(rnd), L.c_f(1e-4), L.ptr(g_shift),
+                           L.ptr(g_from_shift), L.stream())
+                    g_n = g_n + g_from_shift
+                # first evaluation: from (sdf, geom) directly and from n through the double backward; ONE lattice scatter
+                dX1, _, _ = mlp_backward_raw(dims_s, feat, ws, bs, g_y, need_dx=True, into=(gb.dWs, gb.dbs))
+                self._sdf_gradient_backward(g_n, feat, dfeat, e0, pts, win, ws, bs, gb, extra_dfeat=dX1)
+            # ---- off-surface points
+            g_yo = torch.zeros_like(y_o)
+            g_yo[0] = g_so
+            dXo, _, _ = mlp_backward_raw(dims_s, feat_o, ws, bs, g_yo, need_dx=True, into=(gb.dWs, gb.dbs))
+            _enc_bwd(sdfn.encoding, off, win, dXo)
+            if cc is not None:
+                fixed3 = fixed.expand(-1, 3)
+                gwd = torch.zeros_like(cc.weight_delta).index_add_(0, cam, torch.where(fixed3, torch.zeros_like(g_cw), g_cw))
+                gbi = torch.zeros_like(cc.bias).index_add_(0, cam, torch.where(fixed3, torch.zeros_like(g_cb), g_cb))
+                cc.weight_delta.grad, cc.bias.grad = gwd, gbi
+        if it >= hp.iter_start_reduce_curv:      # the Lipschitz bound: four scalars, autograd is fine
+            lb = rgbn.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
+            gs = torch.autograd.grad(lb, list(rgbn.mlp.lipshitz_bound_per_layer))
+            for c, g in zip(rgbn.mlp.lipshitz_bound_per_layer, gs):
+                c.grad = g if c.grad is None else c.grad + g
+            loss = loss + lb.detach()
+        return loss, n_fg, R, True

@@ -385,6 +385,7 @@ class Trainer:
         self.grad_buffers = [self.sdf.mlp_sdf.enable_grad_buffer()] if touched_rows else []
         self.nr_rays = self.hp.nr_rays
         self.iter = 0
+        self.capture_grads = None     # set to {} to have step() record the gradients it hands to the optimiser
         self._late_seen = False       # set by the first iteration at / after iter_start_reduce_curv (acts from the next one on)
         self.last = {}
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
@@ -468,6 +469,49 @@ class Trainer:
         dists = pts.norm(dim=-1, keepdim=True) - 0.3
         return ((sdf - dists) ** 2).mean() * 3e3 + eikonal_loss(grad) * 5e1
 
+    def _refresh_and_adapt(self, it, git, n_fg):
+        """occupancy refresh every 8th step, BEFORE this iteration's backward / optimiser step as in the reference
+        (train_permuto_sdf.py:383-391), from the same random voxels on every rank; adaptive ray count (:393-397)"""
+        hp = self.hp
+        with torch.no_grad():
+            if git % 8 == 0:
+                torch.manual_seed(977 + git)
+                centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
+                inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
+                self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it), inv_s.view(1), 1e-4)
+            if n_fg:  # the count is already on the host
+                self.nr_rays = max(64, min(8192, int(self.nr_rays * hp.target_nr_of_samples / n_fg)))
+
+    def _draw_rays(self, reel):
+        with torch.no_grad():
+            o, d, gt, _, img_idx = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
+            _, _, _, _, hit = self.sphere.ray_intersection(o, d)
+        return o, d, gt, hit, img_idx
+
+    def _main_phase(self, reel, it, git, eikonal_weight):
+        """forward + losses of one iteration of the main phase as an autograd graph -> (loss, n_fg, nr_rays, False): the caller
+        runs loss.backward().  train_manual.ManualTrainer overrides this with a hand-written backward over the raw kernels."""
+        hp = self.hp
+        cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
+        forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
+        o, d, gt, hit, img_idx = self._draw_rays(reel)
+        pred, sdf_grad, fg = self._render(o, d, it, cos_anneal_ratio, forced_variance,
+                                          img_indices=img_idx if self.colorcal is not None else None)
+        loss = l1_loss(pred, gt, hit)                                                      # rgb_loss, one launch
+        n_fg = fg.samples_pos.shape[0]
+        if n_fg:
+            loss = loss + eikonal_loss(sdf_grad) * eikonal_weight
+            gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
+            if gw > 0.0:
+                loss = loss + self.sdf.curvature(fg.samples_pos, sdf_grad, it) * (hp.curvature_weight * gw)
+        off = self.sphere.rand_points_inside(1024)
+        sdf_off, _ = self.sdf(off, it)
+        loss = loss + offsurface_loss(sdf_off, 1e2) * hp.offsurface_weight
+        if it >= hp.iter_start_reduce_curv:
+            loss = loss + self.rgb.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
+        self._refresh_and_adapt(it, git, n_fg)
+        return loss, n_fg, o.shape[0], False
+
     def step(self, reel):
         """one optimisation step; returns the loss (device tensor, no sync)"""
         hp, git = self.hp, self.iter                                  # git: global iteration (sphere phase included)
@@ -484,46 +528,19 @@ class Trainer:
         # (:405) the reference lowers hyperparams.eikonal_weight AFTER this iteration's loss was built: from the next one on
         eikonal_weight = hp.eikonal_weight_late if self._late_seen else hp.eikonal_weight
         n_fg, nr_rays_used = 0, 0
+        for p in self.params:
+            p.grad = None
+        grads_done = False
         if in_sphere_init:
             loss = self._sphere_init_loss(it)
         else:
-            cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
-            forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
-            with torch.no_grad():
-                o, d, gt, _, img_idx = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
-                _, _, _, _, hit = self.sphere.ray_intersection(o, d)
-            nr_rays_used = o.shape[0]
-            pred, sdf_grad, fg = self._render(o, d, it, cos_anneal_ratio, forced_variance,
-                                              img_indices=img_idx if self.colorcal is not None else None)
-            loss = l1_loss(pred, gt, hit)                                                      # rgb_loss, one launch
-            n_fg = fg.samples_pos.shape[0]
-            if n_fg:
-                loss = loss + eikonal_loss(sdf_grad) * eikonal_weight
-                gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
-                if gw > 0.0:
-                    loss = loss + self.sdf.curvature(fg.samples_pos, sdf_grad, it) * (hp.curvature_weight * gw)
-            off = self.sphere.rand_points_inside(1024)
-            sdf_off, _ = self.sdf(off, it)
-            loss = loss + offsurface_loss(sdf_off, 1e2) * hp.offsurface_weight
-            if it >= hp.iter_start_reduce_curv:
-                loss = loss + self.rgb.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
-            # ---- occupancy refresh, every 8th step, BEFORE this iteration's backward / optimiser step as in the reference
-            # (train_permuto_sdf.py:383-391); the same random voxels on every rank
-            with torch.no_grad():
-                if git % 8 == 0:
-                    torch.manual_seed(977 + git)
-                    centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
-                    inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
-                    self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it), inv_s.view(1), 1e-4)
-                if n_fg:  # adaptive ray count (train_permuto_sdf.py:393-397); the count is already on the host
-                    self.nr_rays = max(64, min(8192, int(self.nr_rays * hp.target_nr_of_samples / n_fg)))
+            loss, n_fg, nr_rays_used, grads_done = self._main_phase(reel, it, git, eikonal_weight)
             if late:
                 self._late_seen = True
-        # ---- backward, all-reduce, optimiser
-        for p in self.params:
-            p.grad = None
-        with self.accumulate_grads():      # the persistent gradient buffers are open for THIS backward only
-            loss.backward()
+        # ---- backward (unless the main phase produced the gradients itself: train_manual.ManualTrainer), all-reduce, optimiser
+        if not grads_done:
+            with self.accumulate_grads():      # the persistent gradient buffers are open for THIS backward only
+                loss.backward()
         if self.grad_buffers:
             self.sdf.mlp_sdf.assign_grads()
         buffered = {id(m.encoding.lattice_values) for m in (self.sdf, self.rgb, self.bg)} if self.touched else set()
@@ -531,6 +548,9 @@ class Trainer:
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in dense]
         for p, g in zip(dense, grads):
             p.grad = g
+        if self.capture_grads is not None:      # tests: the gradients of this step as the optimiser is about to see them
+            self.capture_grads = {"dense": [g.detach().clone() for g in grads], "lattices": [tr.grad.clone() for tr in self.touched],
+                                  "loss": loss.detach().clone()}
         if parallel.world_size() > 1:
             buckets = parallel.GradientBuckets()
             small = [g for g in grads if g.numel() < (1 << 20)]

@@ -88,3 +88,67 @@ def test_reference_schedule_phases(dev, tmp_path):
     tr2 = Trainer(dev, hp, reference_schedule=True, nr_images=3, seed=3)
     tr2.load_checkpoint(str(tmp_path))
     assert torch.equal(tr2.colorcal.bias, tr.colorcal.bias)
+
+
+def _trainer_pair(dev, reference_schedule, late=False):
+    """the autograd trainer and the hand-written-backward trainer, same seed, same first iteration (the samplers' process-global
+    generators are rewound in between) -> the gradients each hands to its optimiser.  (Only the first iteration is compared
+    gradient by gradient: Adam with eps 1e-15 turns last-bit differences of near-zero gradients into +-lr parameter differences,
+    so two correct trainers drift apart from the second iteration on; the trajectory is covered by the learning test below.)"""
+    import copy
+    from permuto_sdf_amd.bridge import OccupancyGrid, RaySampler, VolumeRendering
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel, Trainer
+    reel = SyntheticReel(dev, nr_images=4, height=60, width=80)
+    owners = (OccupancyGrid, RaySampler, VolumeRendering)
+    saved = [copy.deepcopy(c._rng) for c in owners]
+    out = []
+    for cls in (Trainer, ManualTrainer):
+        for c, r in zip(owners, saved):
+            c._rng = copy.deepcopy(r)
+        hp = HyperParams()
+        hp.nr_rays, hp.target_nr_of_samples = 256, 256 * 96
+        if reference_schedule:
+            hp.nr_iter_sphere_fit, hp.lr_warmup_iters = 0, 4       # straight into the main phase, colour calibration on
+        if late:   # the late phase: no curvature term, Lipschitz term on, weight decay on the colour lattice
+            hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv = -1, 0
+        tr = cls(dev, hp, reference_schedule=reference_schedule, nr_images=4)
+        tr.capture_grads = {}
+        tr.step(reel)
+        out.append((tr, tr.capture_grads))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["steady", "reference_schedule", "late"])
+def test_manual_backward_equals_autograd(dev, mode):
+    """train_manual.ManualTrainer (forward and backward written out over the raw feature-major kernels) produces the gradients
+    torch autograd produces for the same step: every dense parameter and the three lattice buffers, after identical preceding
+    iteration.  Float atomics make the lattice scatter order-dependent in the last bits, hence the tolerances."""
+    (a, ga), (m, gm) = _trainer_pair(dev, mode == "reference_schedule", late=(mode == "late"))
+    assert a.last == m.last and a.last["nr_fg_samples"] > 0, (a.last, m.last)
+    assert abs(float(ga["loss"]) - float(gm["loss"])) <= 1e-5 * max(1.0, abs(float(ga["loss"])))
+    for i, (x, y) in enumerate(zip(ga["dense"], gm["dense"])):
+        scale = float(x.abs().max())
+        err = float((x - y).abs().max())
+        assert err <= 2e-4 * scale + 1e-9, ("dense gradient %d" % i, tuple(x.shape), err, scale)
+    for i, (x, y) in enumerate(zip(ga["lattices"], gm["lattices"])):
+        scale = float(x.abs().max())
+        err = float((x - y).abs().max())
+        rel = float((x - y).norm() / x.norm())
+        # (elements are sums of many signed contributions added by float atomics in launch-dependent order)
+        assert scale > 0 and err <= 1e-3 * scale and rel <= 2e-4, ("lattice %d" % i, err, scale, rel)
+
+
+def test_manual_trainer_learns_constant_colour(dev):
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel
+    hp = HyperParams()
+    hp.nr_rays, hp.target_nr_of_samples = 256, 256 * 96
+    tr = ManualTrainer(dev, hp)
+    reel = SyntheticReel(dev, nr_images=4, height=60, width=80)
+    reel.rgb_reel[:] = torch.tensor([0.8, 0.3, 0.1], device=dev).view(1, 3, 1, 1)
+    losses = [float(tr.step(reel)) for _ in range(60)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert sum(losses[-10:]) / 10 < 0.6 * sum(losses[:5]) / 5, (losses[:5], losses[-10:])
+    t = tr.sdf.encoding.touched_rows
+    assert float(t.grad.abs().max()) == 0.0 and int(t.touched.sum()) == 0

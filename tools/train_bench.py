@@ -19,13 +19,18 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--manual", action="store_true", help="train_manual.ManualTrainer: hand-written backward over the raw kernels")
     args = ap.parse_args()
     rank, world, local = parallel.init()
     if os.environ.get("PSDF_BENCH_SINGLE_DEVICE") == "1":
         local = 0   # development aid (with PSDF_DIST_BACKEND=gloo): every rank on cuda:0, exercises the N>1 path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    tr = Trainer(dev)
+    if args.manual:
+        from permuto_sdf_amd.train_manual import ManualTrainer
+        tr = ManualTrainer(dev)
+    else:
+        tr = Trainer(dev)
     reel = SyntheticReel(dev)
     for _ in range(args.warmup):
         tr.step(reel)
@@ -65,6 +70,7 @@ def main():
                           "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                           "fg_samples_per_step_per_gpu": samples / args.steps, "rays_last_step": tr.last["nr_rays"],
                           "scaling": "weak", "dtype": "f32", "data": "synthetic",
+                          "backward": "hand-written (train_manual.py)" if args.manual else "torch autograd over the fused operators",
                           "repeats_it_per_s": [round(args.steps / r, 1) for r in reps]}))
     parallel.shutdown()
 
