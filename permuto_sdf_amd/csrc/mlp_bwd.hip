@@ -313,38 +313,55 @@ struct LayerAcc {
 #pragma unroll
         for (int s = 0; s < 4; s++) aw[to][ti] = MFMA16(a_nt[to][s], b_nt[ti][s], aw[to][ti]);
   }
-  // once per wave: into the workgroup image (chain-layer layout)
-  __device__ __forceinline__ void flush_chain(float* __restrict__ acc_w, float* __restrict__ acc_b, int g, int c) {
+  // Wave accumulators -> workgroup image, WITHOUT LDS float atomics: a wave-wide ds_add_f32 costs ~197 cycles on this chip
+  // whatever the addresses (tools/atomic_bench.hip), and the ~90 of them per wave x 8 waves were 54 us of a kernel whose tile
+  // loop takes 10 (measured with stage stamps, tools/bwd_stage_timing.py: cfg-4 training step sizes).  Instead the image is cut
+  // into blocks (one per 16x16 accumulator tile, one per bias tile); the flush runs in NWV rounds separated by barriers, and
+  // in round r wave w adds -- plain read, add, write -- the blocks b with b mod NWV == (w + r) mod NWV.  Within a round the
+  // waves own disjoint blocks, after NWV rounds every wave has added every block.  `sel` = (w + r) mod NWV, `blk0` = index
+  // of this layer's first block (compile-time after inlining); returns the number of blocks of the layer.
+  template <int NWV>
+  __device__ __forceinline__ int flush_chain(float* __restrict__ acc_w, float* __restrict__ acc_b, int g, int c, int sel, int blk0) {
     const int lane_off = (c & 3) * WS + (c >> 2) * 16 + 4 * g;
 #pragma unroll
     for (int to = 0; to < TO; to++) {
 #pragma unroll
       for (int ti = 0; ti < TI; ti++)
+        if (((blk0 + to * TI + ti) & (NWV - 1)) == sel) {
+          float* dst = acc_w + (to * TI + ti) * 4 * WS + lane_off;
 #pragma unroll
-        for (int q = 0; q < 4; q++) atomicAdd(acc_w + (to * TI + ti) * 4 * WS + lane_off + q, aw[to][ti][q]);
-      float sb = ab[to];
-      sb += __shfl_xor(sb, 16, 64);
-      sb += __shfl_xor(sb, 32, 64);
-      if (g == 0) atomicAdd(acc_b + 16 * to + c, sb);
+          for (int q = 0; q < 4; q++) dst[q] += aw[to][ti][q];
+        }
+      if (((blk0 + TO * TI + to) & (NWV - 1)) == sel) {
+        float sb = ab[to];
+        sb += __shfl_xor(sb, 16, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        if (g == 0) acc_b[16 * to + c] += sb;
+      }
     }
+    return TO * TI + TO;
   }
   // layer 0 image layout: [(to*S0 + 4t + c>>2)][(c&3)*16 + 4g + q]
-  __device__ __forceinline__ void flush_layer0(float* __restrict__ acc_w, float* __restrict__ acc_b, int S0, int g, int c) {
+  template <int NWV>
+  __device__ __forceinline__ int flush_layer0(float* __restrict__ acc_w, float* __restrict__ acc_b, int S0, int g, int c, int sel,
+                                              int blk0) {
 #pragma unroll
     for (int to = 0; to < TO; to++) {
 #pragma unroll
-      for (int t = 0; t < TI; t++) {
-        if ((4 * t + (c >> 2)) < S0) {
-          float* base = acc_w + (to * S0 + 4 * t + (c >> 2)) * WS + (c & 3) * 16 + 4 * g;
+      for (int t = 0; t < TI; t++)
+        if (((blk0 + to * TI + t) & (NWV - 1)) == sel && (4 * t + (c >> 2)) < S0) {
+          float* dst = acc_w + (to * S0 + 4 * t + (c >> 2)) * WS + (c & 3) * 16 + 4 * g;
 #pragma unroll
-          for (int q = 0; q < 4; q++) atomicAdd(base + q, aw[to][t][q]);
+          for (int q = 0; q < 4; q++) dst[q] += aw[to][t][q];
         }
+      if (((blk0 + TO * TI + to) & (NWV - 1)) == sel) {
+        float sb = ab[to];
+        sb += __shfl_xor(sb, 16, 64);
+        sb += __shfl_xor(sb, 32, 64);
+        if (g == 0) acc_b[16 * to + c] += sb;
       }
-      float sb = ab[to];
-      sb += __shfl_xor(sb, 16, 64);
-      sb += __shfl_xor(sb, 32, 64);
-      if (g == 0) atomicAdd(acc_b + 16 * to + c, sb);
     }
+    return TO * TI + TO;
   }
 };
 
@@ -420,6 +437,13 @@ __device__ __forceinline__ void chain_bwd4(const f32x4 (&dz)[TO], f32x4 (&dh)[TI
 
 constexpr int BW = 4;  // waves per workgroup (one per SIMD: the kernel wants the whole 512-register file)
 
+#ifdef PSDF_BWD_TIMING   // measurement build (tools/small_batch_bench.py): stage stamps of workgroup 0, 100 MHz clock
+__device__ unsigned long long g_bwd_t[8];
+#define BWD_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_bwd_t[k] = wall_clock64(); } while (0)
+#else
+#define BWD_STAMP(k) do { } while (0)
+#endif
+
 // NEED_DW = false: data gradient only (dX of a fixed net: analytic normals at inference); no accumulators, no transposes
 // NW = waves per workgroup: 4 (one per SIMD, the whole register file) for 64-wide nets, 8 for 32-wide nets whose
 // accumulators + state fit 256 registers -- two waves per SIMD cover each other's GELU / LDS / MFMA shadows.
@@ -437,6 +461,7 @@ __global__ void __launch_bounds__(NW * 64)
   float* tbuf = lds + img + wave * WAVE_LDS;        // 16x17 transpose buffer
   float* dyb = tbuf + 16 * 17;                      // 16 floats
   float* xbuf = dyb + 16;                           // 2 x [SX][64]: layer-0 operand tiles landed by LDS-DMA
+  BWD_STAMP(0);
   {
     const int tid = threadIdx.x, nt = NW * 64;
     const int d0 = p.dims[0], d1 = p.dims[1], d2 = p.dims[2], d3 = p.dims[3];
@@ -467,6 +492,7 @@ __global__ void __launch_bounds__(NW * 64)
       }
   }
   __syncthreads();
+  BWD_STAMP(1);
   const int g = lane >> 4, c = lane & 15;
   const int K0 = p.dims[0], OUT = p.dims[p.n_layers], S0 = p.steps0;
   constexpr int TL = (T3 > 0) ? T3 : T2;
@@ -690,6 +716,7 @@ __global__ void __launch_bounds__(NW * 64)
     }
   }
   }  // ---- end of the weight image scope
+  BWD_STAMP(2);
   if constexpr (!NEED_DW) return;
   // ---------------------------------------------------------------- wave accumulators -> workgroup image -> global
   // (the weight image is dead once every wave has left the tile loop: the gradient image takes its place)
@@ -697,30 +724,41 @@ __global__ void __launch_bounds__(NW * 64)
   float* ACC = lds;
   for (int e = threadIdx.x; e < p.total; e += NW * 64) ACC[e] = 0.f;
   __syncthreads();
-  acc0.flush_layer0(ACC + p.w_off[0], ACC + p.b_off[0], S0, g, c);
-  acc1.flush_chain(ACC + p.w_off[1], ACC + p.b_off[1], g, c);
-  if constexpr (T3 > 0) acc2.flush_chain(ACC + p.w_off[2], ACC + p.b_off[2], g, c);
-  if constexpr (FINAL_DOT) {
+  BWD_STAMP(3);
+#pragma unroll 1
+  for (int r = 0; r < NW; r++) {      // rotating rounds of plain read-add-write, see LayerAcc::flush_chain
+    const int sel = (wave + r) & (NW - 1);
+    int blk = 0;
+    blk += acc0.template flush_layer0<NW>(ACC + p.w_off[0], ACC + p.b_off[0], S0, g, c, sel, blk);
+    blk += acc1.template flush_chain<NW>(ACC + p.w_off[1], ACC + p.b_off[1], g, c, sel, blk);
+    if constexpr (T3 > 0) blk += acc2.template flush_chain<NW>(ACC + p.w_off[2], ACC + p.b_off[2], g, c, sel, blk);
+    if constexpr (FINAL_DOT) {
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-      if (o < OUT) {
+      for (int o = 0; o < 4; o++) {
+        if (o < OUT) {
 #pragma unroll
-        for (int t = 0; t < TL; t++) {
-          float pr = accf[o][t];
-          pr += __shfl_xor(pr, 16, 64);
-          pr += __shfl_xor(pr, 32, 64);
-          // neuron 16t + c sits at [o][t][r = c&3][g = c>>2]
-          if (g == 0) atomicAdd(ACC + p.w_off[lf] + ((o * TL + t) * 4 + (c & 3)) * 4 + (c >> 2), pr);
+          for (int t = 0; t < TL; t++)
+            if (((blk + o * TL + t) & (NW - 1)) == sel) {
+              float pr = accf[o][t];
+              pr += __shfl_xor(pr, 16, 64);
+              pr += __shfl_xor(pr, 32, 64);
+              // neuron 16t + c sits at [o][t][r = c&3][g = c>>2]
+              if (g == 0) ACC[p.w_off[lf] + ((o * TL + t) * 4 + (c & 3)) * 4 + (c >> 2)] += pr;
+            }
+          if (((blk + 4 * TL + o) & (NW - 1)) == sel) {
+            const float sb = psdf::wave_sum(accfb[o]);
+            if (lane == 0) ACC[p.b_off[lf] + o] += sb;
+          }
         }
-        const float sb = psdf::wave_sum(accfb[o]);
-        if (lane == 0) atomicAdd(ACC + p.b_off[lf] + o, sb);
       }
+    } else {
+      acco.template flush_chain<NW>(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c, sel, blk);
     }
-  } else {
-    acco.flush_chain(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c);
+    __syncthreads();
   }
-  __syncthreads();
+  BWD_STAMP(4);
   flush_image<NW * 64>(p, a, ACC);
+  BWD_STAMP(5);
 }
 
 // ======================================================================================================
@@ -1055,26 +1093,32 @@ __global__ void __launch_bounds__(BW * 64)
   float* ACC = lds;
   for (int e = threadIdx.x; e < p.total; e += BW * 64) ACC[e] = 0.f;
   __syncthreads();
-  acc0.flush_layer0(ACC + p.w_off[0], ACC + p.b_off[0], S0, g, c);
-  acc1.flush_chain(ACC + p.w_off[1], ACC + p.b_off[1], g, c);
-  acc2.flush_chain(ACC + p.w_off[2], ACC + p.b_off[2], g, c);
-  if constexpr (FINAL_DOT) {
+#pragma unroll 1
+  for (int r = 0; r < BW; r++) {      // rotating rounds of plain read-add-write, see LayerAcc::flush_chain
+    const int sel = (wave + r) & (BW - 1);
+    int blk = 0;
+    blk += acc0.template flush_layer0<BW>(ACC + p.w_off[0], ACC + p.b_off[0], S0, g, c, sel, blk);
+    blk += acc1.template flush_chain<BW>(ACC + p.w_off[1], ACC + p.b_off[1], g, c, sel, blk);
+    blk += acc2.template flush_chain<BW>(ACC + p.w_off[2], ACC + p.b_off[2], g, c, sel, blk);
+    if constexpr (FINAL_DOT) {
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-      if (o < OUT) {
+      for (int o = 0; o < 4; o++) {
+        if (o < OUT) {
 #pragma unroll
-        for (int t = 0; t < T3; t++) {
-          float pr = accf[o][t];
-          pr += __shfl_xor(pr, 16, 64);
-          pr += __shfl_xor(pr, 32, 64);
-          if (g == 0) atomicAdd(ACC + p.w_off[lf] + ((o * T3 + t) * 4 + (c & 3)) * 4 + (c >> 2), pr);
+          for (int t = 0; t < T3; t++)
+            if (((blk + o * T3 + t) & (BW - 1)) == sel) {
+              float pr = accf[o][t];
+              pr += __shfl_xor(pr, 16, 64);
+              pr += __shfl_xor(pr, 32, 64);
+              if (g == 0) ACC[p.w_off[lf] + ((o * T3 + t) * 4 + (c & 3)) * 4 + (c >> 2)] += pr;
+            }
         }
       }
+    } else {
+      acco.template flush_chain<BW>(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c, sel, blk);  // its bias partials are zero (add_nb only)
     }
-  } else {
-    acco.flush_chain(ACC + p.w_off[lf], ACC + p.b_off[lf], g, c);  // its bias partials are zero (add_nb only)
+    __syncthreads();
   }
-  __syncthreads();
   flush_image<BW * 64>(p, a, ACC);
 }
 
@@ -1142,6 +1186,12 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
 }
 
 }  // namespace
+
+#ifdef PSDF_BWD_TIMING
+extern "C" int psdf_debug_bwd_timing(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_t), sizeof(unsigned long long) * 8);
+}
+#endif
 
 extern "C" {
 

@@ -11,7 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from permuto_sdf_amd.train_step import SyntheticReel, Trainer  # noqa: E402
 
 dev = torch.device("cuda:0")
-tr = Trainer(dev)
+if "--manual" in sys.argv:
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    tr = ManualTrainer(dev)
+else:
+    tr = Trainer(dev)
 reel = SyntheticReel(dev)
 for _ in range(15):
     tr.step(reel)
