@@ -369,7 +369,10 @@ __device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, in
 // vector spill, and the kernel waits on LDS / gathers for half of its wave cycles (profiles/r02_pmc_sq_encode_bwd.txt), so the
 // extra residents pay: bench batch 0.835 -> 0.79 ms (4 waves: no change; 6 waves spill 13 VGPRs).  The 24-KiB cache of queue
 // mode lets 5 workgroups share a CU's LDS.  (P = 4 and F = 4 would spill a few VGPRs at 5 waves: they ask for 4.)
-template <int P, int F, bool LATTICE, bool POS, bool QUEUE>
+// DBL = true: the DOUBLE backward's lattice scatter through the same machinery (see encode_dbl_bwd_kernel for the maths): the
+// coefficient of vertex r is q_r (the directional derivative of its barycentric along u = dd_positions) instead of bary_r, and
+// the kernel also writes grad_grad_sliced = sum_r q_r w lattice[row_r] (a gather of the rows it has just computed).
+template <int P, int F, bool LATTICE, bool POS, bool QUEUE, bool DBL = false>
 #if !defined(PSDF_ENC_QWAVES)
 #define PSDF_ENC_QWAVES 5
 #endif
@@ -378,7 +381,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                       const float* __restrict__ grad_sliced, float* __restrict__ grad_lattice,
-                      float* __restrict__ grad_positions, Queues Q) {
+                      float* __restrict__ grad_positions, Queues Q, const float* __restrict__ dd_positions = nullptr,
+                      float* __restrict__ grad_grad_sliced = nullptr, int pad_points = 0) {
+  static_assert(!(DBL && POS), "the double backward has no position output");
   extern __shared__ __align__(16) float lds[];
 #if defined(PSDF_ENC_PROFILE)
   const long long psdf_prof_t0 = (long long)wall_clock64();
@@ -386,6 +391,24 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
   const int level = blockIdx.y;
   const int64_t ntiles = (N + PSDF_BLOCK - 1) / PSDF_BLOCK;
   if (level >= L) {
+    if (DBL) {   // concatenated-point channels: grad_g = u_d * points_scaling
+      const int e = level - L;
+      for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
+        if (n >= N) continue;
+        float u[P];
+        load_pos<P>(dd_positions, n, u);
+#pragma unroll
+        for (int f = 0; f < F; f++) {
+          const int d = e * F + f;
+          float v = 0.f;
+#pragma unroll
+          for (int i = 0; i < P; i++)
+            if (i == d) v = u[i] * points_scaling;
+          if (d < P || pad_points) grad_grad_sliced[((int64_t)level * F + f) * N + n] = v;
+        }
+      }
+    }
     if (POS) {
       const int e = level - L;
       for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -448,14 +471,49 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
         float dbary[P + 2];
 #pragma unroll
         for (int k = 0; k <= P + 1; k++) dbary[k] = 0.f;
+        float q[P + 2], gg[F];
+        if (DBL) {   // q_r = sum_i u_i d bary_r / d pos_i: adjoint of pos -> elevated -> barycentric slots
+          float u[P];
+          load_pos<P>(dd_positions, n, u);
+          float aE[P + 1];
+#pragma unroll
+          for (int j = 0; j <= P; j++) aE[j] = 0.f;
+#pragma unroll
+          for (int k = 0; k < P; k++) {
+            const float us = u[k] * sfl[k];
+#pragma unroll
+            for (int j = 0; j <= k; j++) aE[j] = aE[j] + us;
+            aE[k + 1] = aE[k + 1] - us * (float)(k + 1);
+          }
+#pragma unroll
+          for (int k = 0; k <= P + 1; k++) q[k] = 0.f;
+          const float invp = 1.0f / (P + 1);
+#pragma unroll
+          for (int i = 0; i <= P; i++) {
+            const float t = aE[i] * invp;
+#pragma unroll
+            for (int k = 0; k <= P + 1; k++) {
+              if (k == P - s.rank[i]) q[k] = q[k] + t;
+              if (k == P + 1 - s.rank[i]) q[k] = q[k] - t;
+            }
+          }
+          q[0] = q[0] + q[P + 1];
+#pragma unroll
+          for (int f = 0; f < F; f++) gg[f] = 0.f;
+        }
         uint32_t rows[P + 1];
         vertex_rows<P>(s, capacity, rows, conv.hash_c);
 #pragma unroll
         for (int r = 0; r <= P; r++) {
           const uint32_t row = rows[r];
+          if (DBL) {
+            const float qw = q[r] * w;
+#pragma unroll
+            for (int f = 0; f < F; f++) gg[f] = gg[f] + qw * lattice[tbase + (int64_t)row * F + f];
+          }
           if (LATTICE) {
             const int c = sp * (P + 1) + r;
-            const float bw = s.bary[r] * w;
+            const float bw = (DBL ? q[r] : s.bary[r]) * w;
             crow[c] = row;
 #pragma unroll
             for (int f = 0; f < F; f++) cval[c][f] = g[f] * bw;
@@ -465,6 +523,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 #pragma unroll
             for (int f = 0; f < F; f++) dbary[r] = dbary[r] + lattice[tbase + (int64_t)row * F + f] * w * g[f];
           }
+        }
+        if (DBL) {
+#pragma unroll
+          for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = gg[f];
         }
         if (POS) {
           dbary[P + 1] = dbary[P + 1] + dbary[0];  // adjoint of bary[0] += 1 + bary[P+1]
@@ -906,7 +968,13 @@ int psdf_encode_forward_masked(int pos_dim, int nr_feat, int64_t N, int nr_level
 // table too large for 64 partitions) and psdf_encode_backward_ws behaves exactly like psdf_encode_backward.
 static bool queue_plan(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, Queues& Q, int64_t& bytes) {
   bytes = 0;
-  if (N < (int64_t)1 << 18) return false;  // below ~260k points the plain path is launch-bound anyway
+  // Below ~8 K points the fixed cost of the plan (counter memset, one resident round of binning workgroups, a reduce pass over
+  // the whole table: ~27 us for 24 levels x 2^18 rows) exceeds what the plain path (LDS cache + float atomics, ~4.7 ns per point
+  // when every level carries a gradient) spends.  Measured, tools/small_batch_enc_bench.py, lattice backward: 1 056 points
+  // 10.8 us plain / 27.1 us queued; 49 152 points 232 / 71.5 us; 262 080 points 1206 / 174.5 us.  (Until round 3 the
+  // threshold was 2^18 points: every backward of a training step -- ~49 K ray samples -- took the plain path.)
+  static const int64_t min_n = getenv("PSDF_ENC_QUEUE_MIN_N") ? atoll(getenv("PSDF_ENC_QUEUE_MIN_N")) : ((int64_t)1 << 13);
+  if (N < min_n) return false;
   // rows per partition: the reduce kernel holds a partition's slice of the table in LDS.  64-KiB slices (two reduce
   // workgroups per CU) instead of the 128 KiB that fit: the coarse levels' queues are nearly empty, so with one workgroup per
   // (level, partition) and 16 partitions only half the CUs had work (16 levels: reduce + binning 0.966 -> 0.905 ms with 32).
@@ -979,7 +1047,11 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + ((grad_positions != nullptr) ? extra_levels(pos_dim, nr_feat, concat_points) : 0);
   const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
-  dim3 grid(nb < 512u ? nb : 512u, Lt);
+  // Plain (cache + atomics) mode: a workgroup sets up and flushes a 48-KiB LDS cache, so it should walk several tiles;
+  // PSDF_ENC_BWD_WG_PER_LEVEL overrides the per-level workgroup cap (measurement switch).
+  static const int wg_cap_env = getenv("PSDF_ENC_BWD_WG_PER_LEVEL") ? atoi(getenv("PSDF_ENC_BWD_WG_PER_LEVEL")) : 0;
+  const unsigned wg_cap = wg_cap_env > 0 ? (unsigned)wg_cap_env : 512u;
+  dim3 grid(nb < wg_cap ? nb : wg_cap, Lt);
   Queues Q{};
   int64_t need = 0;
   const bool use_queue = grad_lattice && workspace && queue_plan(pos_dim, nr_feat, N, nr_levels, capacity, Q, need) &&
@@ -1124,12 +1196,15 @@ int psdf_encode_backward_positions_masked(int pos_dim, int nr_feat, int64_t N, i
   return PSDF_OK;
 }
 
-// grad_lattice must be zero-initialised (or NULL to skip); grad_grad_sliced is fully overwritten.
-int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity,
-                                const float* positions, const float* lattice, const float* scale_factor,
-                                const float* shifts, const float* window, int concat_points, float points_scaling,
-                                const float* dd_positions, const float* grad_sliced, float* grad_lattice,
-                                float* grad_grad_sliced, void* stream) {
+// grad_lattice must be zero-initialised (or NULL to skip); grad_grad_sliced is fully overwritten.  workspace: device scratch of
+// psdf_encode_backward_workspace_bytes() bytes or NULL -- with it, batches large enough for the queue plan send the lattice
+// scatter through the binning + reduce kernels of the backward (encode_bwd_kernel<.., DBL = true>) instead of float atomics:
+// measured at 49 152 ray samples, 24 levels (a training step) 269 -> ~75 us, at 262 080 samples 1.36 ms -> ~0.2 ms.
+int psdf_encode_double_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity,
+                                   const float* positions, const float* lattice, const float* scale_factor,
+                                   const float* shifts, const float* window, int concat_points, float points_scaling,
+                                   const float* dd_positions, const float* grad_sliced, float* grad_lattice,
+                                   float* grad_grad_sliced, void* workspace, int64_t workspace_bytes, void* stream) {
   if (N == 0) return PSDF_OK;
   if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !dd_positions || !grad_sliced ||
       !grad_grad_sliced || !concat_ok(concat_points))
@@ -1137,7 +1212,56 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
   const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
-  dim3 grid(nb < 512u ? nb : 512u, Lt);
+  {
+    Queues Q{};
+    int64_t need = 0;
+    if (grad_lattice && workspace && queue_plan(pos_dim, nr_feat, N, nr_levels, capacity, Q, need) && workspace_bytes >= need) {
+      queue_carve(workspace, nr_feat, nr_levels, Q);
+      hipError_t e = hipMemsetAsync(Q.tails, 0, (size_t)nr_levels * Q.np * sizeof(int), st);
+      if (e != hipSuccess) return (int)e;
+#define DBLQ(P_, F_)                                                                                                     \
+  do {                                                                                                                   \
+    auto kern = encode_bwd_kernel<P_, F_, true, false, true, true>;                                                      \
+    const size_t shm = ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                            \
+    int per_cu = 0;                                                                                                      \
+    int64_t gx = 128;                                                                                                    \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PSDF_BLOCK, shm) == hipSuccess && per_cu > 0)        \
+      gx = (int64_t)per_cu * device_cus() / nr_levels;   /* one resident round, as in psdf_encode_backward_ws */         \
+    else                                                                                                                 \
+      (void)hipGetLastError();                                                                                           \
+    const int64_t super_tiles = (N + (int64_t)PSDF_BLOCK * QUEUE_SPT - 1) / ((int64_t)PSDF_BLOCK * QUEUE_SPT);           \
+    if (gx > super_tiles) gx = super_tiles;                                                                              \
+    hipLaunchKernelGGL(kern, dim3((unsigned)(gx < 1 ? 1 : gx), Lt), dim3(PSDF_BLOCK), shm, st, N, nr_levels,             \
+                       (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,     \
+                       points_scaling, grad_sliced, grad_lattice, (float*)nullptr, Q, dd_positions, grad_grad_sliced,    \
+                       pad_points(concat_points));                                                                       \
+    const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                                    \
+    hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                                       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);                         \
+    if (e2 != hipSuccess) return (int)e2;                                                                                \
+    hipLaunchKernelGGL((encode_bwd_reduce_kernel<F_>), dim3(Q.np, nr_levels), dim3(1024), lds_b, st, (uint32_t)capacity, \
+                       Q, grad_lattice);                                                                                 \
+  } while (0)
+      if (pos_dim == 3 && nr_feat == 2)
+        DBLQ(3, 2);
+      else if (pos_dim == 4 && nr_feat == 2)
+        DBLQ(4, 2);
+      else if (pos_dim == 2 && nr_feat == 2)
+        DBLQ(2, 2);
+      else if (pos_dim == 3 && nr_feat == 4)
+        DBLQ(3, 4);
+      else
+        return PSDF_ERR_UNSUPPORTED;
+#undef DBLQ
+      PSDF_LAUNCH_CHECK();
+      return PSDF_OK;
+    }
+  }
+  // Plain (cache + atomics) mode: a workgroup sets up and flushes a 48-KiB LDS cache, so it should walk several tiles;
+  // PSDF_ENC_BWD_WG_PER_LEVEL overrides the per-level workgroup cap (measurement switch).
+  static const int wg_cap_env = getenv("PSDF_ENC_BWD_WG_PER_LEVEL") ? atoi(getenv("PSDF_ENC_BWD_WG_PER_LEVEL")) : 0;
+  const unsigned wg_cap = wg_cap_env > 0 ? (unsigned)wg_cap_env : 512u;
+  dim3 grid(nb < wg_cap ? nb : wg_cap, Lt);
 #define DBL(P_, F_)                                                                                              \
   do {                                                                                                           \
     if (grad_lattice)                                                                                            \
@@ -1163,6 +1287,16 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
 #undef DBL
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
+}
+
+int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity,
+                                const float* positions, const float* lattice, const float* scale_factor,
+                                const float* shifts, const float* window, int concat_points, float points_scaling,
+                                const float* dd_positions, const float* grad_sliced, float* grad_lattice,
+                                float* grad_grad_sliced, void* stream) {
+  return psdf_encode_double_backward_ws(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts,
+                                        window, concat_points, points_scaling, dd_positions, grad_sliced, grad_lattice,
+                                        grad_grad_sliced, nullptr, 0, stream);
 }
 
 }  // extern "C"

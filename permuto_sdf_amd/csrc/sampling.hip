@@ -149,6 +149,9 @@ __device__ __forceinline__ v3 safe_inverse(v3 d) {
   return r;
 }
 constexpr int MAX_DDA_STEPS = 4096;
+#if !defined(PSDF_MARCH_AHEAD)
+#define PSDF_MARCH_AHEAD 4     // steps the first march walks ahead of its occupancy probes (march_kernel)
+#endif
 constexpr float DDA_EPS = 1e-6f;
 
 // Occupancy as the DDA loops see it: the reference's one byte per voxel (Morton order) plus an OPTIONAL coarse mask, one
@@ -286,12 +289,14 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     // The walk of this first march does not depend on what it finds (only `occupied` does), so it runs AHEAD steps ahead of
     // its probes: AHEAD probes in flight instead of one (a training step marches a few hundred rays: nothing else hides
     // the latency).  Same float sequence, same order of the additions into `occupied`.
-    constexpr int AHEAD = 4;
+    constexpr int AHEAD = PSDF_MARCH_AHEAD;
     float t = t_start;
     int steps = 0;
     bool walking = true;
     while (walking) {
-      int vox[AHEAD] = {0, 0, 0, 0};
+      int vox[AHEAD];
+#pragma unroll
+      for (int k = 0; k < AHEAD; k++) vox[k] = 0;
       float dd[AHEAD], tt[AHEAD];
       int m = 0;
 #pragma unroll
@@ -684,8 +689,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 
 // ---------------------------------------------------------------------------------- background sampler
 // inverse-depth samples outside the bounding sphere, 3-D point (optionally contracted) + 4-D NeRF++ point
+// (thread per ray: the reference's loop; launched only for more than PSDF_BLOCK samples per ray)
 __global__ void __launch_bounds__(PSDF_BLOCK)
-    samples_bg_kernel(int nr_rays, int per_ray, const float* __restrict__ origins, const float* __restrict__ dirs,
+    samples_bg_serial_kernel(int nr_rays, int per_ray, const float* __restrict__ origins, const float* __restrict__ dirs,
                       const float* __restrict__ t_exit_p, float radius, float cx, float cy, float cz, Pcg rng,
                       int randomize, int contract, float* __restrict__ p3, float* __restrict__ p4,
                       float* __restrict__ s_dirs, float* __restrict__ s_z, float* __restrict__ s_dt,
@@ -734,6 +740,69 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   ray_fixed_dt[ray] = 0.f;
   start_end[2 * ray] = ray * per_ray;
   start_end[2 * ray + 1] = ray * per_ray + per_ray;
+}
+
+// The same samples with ONE THREAD PER SAMPLE.  What made the loop above serial is the generator: every iteration advances it
+// by ray * per_ray and draws once, so sample i sees the state (i + 1) * ray * per_ray + i steps from the launch state -- a
+// jump the generator can make directly (advance() is exact arithmetic mod 2^64).  The thread-per-ray loop spent its time in
+// 32 such jumps per ray (54 us for the ~700 rays of a training step); here a thread makes one, and the spacing to the next
+// sample comes from the neighbour through LDS.  A workgroup holds PSDF_BLOCK / per_ray whole rays.
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    samples_bg_kernel(int nr_rays, int per_ray, const float* __restrict__ origins, const float* __restrict__ dirs,
+                      const float* __restrict__ t_exit_p, float radius, float cx, float cy, float cz, Pcg rng,
+                      int randomize, int contract, float* __restrict__ p3, float* __restrict__ p4,
+                      float* __restrict__ s_dirs, float* __restrict__ s_z, float* __restrict__ s_dt,
+                      float* __restrict__ ray_fixed_dt, int* __restrict__ start_end) {
+  __shared__ float zs[PSDF_BLOCK + 1];
+  const int rpb = PSDF_BLOCK / per_ray;
+  const int lr = threadIdx.x / per_ray, i = threadIdx.x - lr * per_ray;
+  const int ray = blockIdx.x * rpb + lr;
+  const bool live = lr < rpb && ray < nr_rays;
+  const float min_t = 1e-3f;
+  const float step = (float)((1.0 - (double)min_t) / (per_ray - 1));
+  const int64_t base = (int64_t)ray * per_ray;
+  float z = 0.f;
+  if (live) {
+    const float t_exit = t_exit_p[ray];
+    const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
+    const v3 centre = mk3(cx, cy, cz);
+    float ts = (float)(1.0 - (double)(i * step));
+    if (randomize) {
+      const uint64_t delta = (uint64_t)(int64_t)(ray * per_ray);
+      rng.advance((uint64_t)(i + 1) * delta + (uint64_t)i);
+      const float rnd = rng.next_float();
+      ts += (float)((double)(step * rnd) - (double)step / 2.0);
+    }
+    ts = fmaxf(min_t, fminf(ts, 1.0f));
+    z = t_exit / ts;
+    s_z[base + i] = z;
+    v3 p = along(org, z, dir);
+    if (contract) {
+      const float tr = ts * radius;
+      const float len = sqrtf(dot3(p, p));
+      const v3 u = mk3(p.x / len, p.y / len, p.z / len);
+      p = (2 * radius - tr) * u;
+    }
+    st3(p3 + 3 * (base + i), p);
+    const v3 q = p - centre;
+    const float inv = rsqrtf(dot3(q, q));
+    const float dist = sqrtf(dot3(q, q));
+    const v3 u = q * inv;
+    float* o4 = p4 + 4 * (base + i);
+    o4[0] = u.x;
+    o4[1] = u.y;
+    o4[2] = u.z;
+    o4[3] = radius / fmaxf(1e-6f, dist);
+    st3(s_dirs + 3 * (base + i), dir);
+    if (i == 0) {
+      ray_fixed_dt[ray] = 0.f;
+      start_end[2 * ray] = ray * per_ray;
+      start_end[2 * ray + 1] = ray * per_ray + per_ray;
+    }
+  }
+  zs[threadIdx.x] = z;
+  __syncthreads();
+  if (live) s_dt[base + i] = (i == per_ray - 1) ? 1e10f : zs[threadIdx.x + 1] - z;
 }
 
 // ---------------------------------------------------------------------------------- sphere
@@ -1204,10 +1273,18 @@ int psdf_samples_bg(int nr_rays, int nr_samples_per_ray, const float* ray_origin
   if (nr_rays <= 0) return PSDF_OK;
   if (nr_samples_per_ray < 2) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(samples_bg_kernel, GRID1(nr_rays), nr_rays, nr_samples_per_ray, ray_origins, ray_dirs, ray_t_exit,
-                     sphere_radius, sphere_center[0], sphere_center[1], sphere_center[2], Pcg{rng_state, rng_inc},
-                     randomize, contract_3d_samples, samples_3d, samples_4d, samples_dirs, samples_z, samples_dt,
-                     ray_fixed_dt, ray_start_end_idx);
+  if (nr_samples_per_ray <= PSDF_BLOCK) {   // thread per sample, whole rays per workgroup
+    const int rpb = PSDF_BLOCK / nr_samples_per_ray;
+    hipLaunchKernelGGL(samples_bg_kernel, dim3(psdf_blocks(nr_rays, rpb)), dim3(PSDF_BLOCK), 0, st, nr_rays,
+                       nr_samples_per_ray, ray_origins, ray_dirs, ray_t_exit, sphere_radius, sphere_center[0],
+                       sphere_center[1], sphere_center[2], Pcg{rng_state, rng_inc}, randomize, contract_3d_samples,
+                       samples_3d, samples_4d, samples_dirs, samples_z, samples_dt, ray_fixed_dt, ray_start_end_idx);
+  } else {
+    hipLaunchKernelGGL(samples_bg_serial_kernel, GRID1(nr_rays), nr_rays, nr_samples_per_ray, ray_origins, ray_dirs,
+                       ray_t_exit, sphere_radius, sphere_center[0], sphere_center[1], sphere_center[2],
+                       Pcg{rng_state, rng_inc}, randomize, contract_3d_samples, samples_3d, samples_4d, samples_dirs,
+                       samples_z, samples_dt, ray_fixed_dt, ray_start_end_idx);
+  }
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

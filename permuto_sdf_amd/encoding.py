@@ -83,6 +83,25 @@ def encode_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, g
            L.stream())
 
 
+def _backward_workspace(cfg, N, device):
+    import ctypes
+    fn = L.lib().psdf_encode_backward_workspace_bytes
+    fn.restype = ctypes.c_int64
+    nbytes = int(fn(L.c_i(cfg.pos_dim), L.c_i(cfg.nr_feat), L.c_l(N), L.c_i(cfg.nr_levels), L.c_i(cfg.capacity)))
+    return (torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes > 0 else None), nbytes
+
+
+def encode_double_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, dd_positions, g_fm, g_lat, gg_fm):
+    """backward of the position gradient (models.py:245-251, create_graph=True): accumulates into g_lat [L,T,F] (or None) the
+    gradient w.r.t. the lattice and overwrites gg_fm [C,N] with the gradient w.r.t. the feature gradient g_fm.  Batches large
+    enough for the binned plan get its scratch from torch's caching allocator (as encode_backward_raw does)."""
+    N = positions.shape[0]
+    ws, nbytes = _backward_workspace(cfg, N, positions.device) if g_lat is not None else (None, 0)
+    L.call("psdf_encode_double_backward_ws", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor), L.ptr(shifts),
+           L.ptr(window), *_tail(cfg), L.ptr(dd_positions), L.ptr(g_fm), L.ptr(g_lat), L.ptr(gg_fm), L.ptr(ws), L.c_l(nbytes),
+           L.stream())
+
+
 def _feature_major(g):
     """[N, C] gradient (any strides) -> contiguous [C, N]."""
     gt = g.t()
@@ -214,8 +233,7 @@ class PermutoEncodingBackFunc(torch.autograd.Function):
         buffered = need_lat and tr is not None
         g_lat = tr.grad if buffered else (torch.zeros_like(lattice) if need_lat else None)
         gg = torch.empty_like(g)
-        L.call("psdf_encode_double_backward", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor),
-               L.ptr(shifts), L.ptr(window), *_tail(cfg), L.ptr(dd), L.ptr(g), L.ptr(g_lat), L.ptr(gg), L.stream())
+        encode_double_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, dd, g, g_lat, gg)
         return None, None, None, (None if buffered else g_lat), None, None, (gg.t() if need_g else None), None, None, None
 
 

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib as L
 from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
-from .encoding import _head, _tail, encode_backward_raw, encode_forward_raw
+from .encoding import encode_backward_raw, encode_double_backward_raw, encode_forward_raw
 from .mlp import mlp_backward_raw, mlp_double_backward, mlp_forward_raw, pack_params
 from .neus import eikonal_loss_raw, l1_loss_raw, neus_composite_backward_raw, neus_composite_forward_raw
 from .train_step import Trainer, map_range_val
@@ -45,10 +45,8 @@ def _enc_bwd(enc, pts, win, g_fm, want_pos=False, want_lattice=True):
 def _enc_dbl_bwd(enc, pts, win, dd_pos, g_fm):
     """backward of the position gradient: adds to the lattice buffer, returns the gradient w.r.t. the feature gradient [C, N]"""
     gg = torch.empty_like(g_fm)
-    cfg = enc.cfg
-    L.call("psdf_encode_double_backward", *_head(cfg, pts.shape[0]), L.ptr(pts), L.ptr(enc.lattice_values.detach()),
-           L.ptr(enc.scale_factor), L.ptr(enc.random_shift_per_level.detach()), L.ptr(win), *_tail(cfg), L.ptr(dd_pos), L.ptr(g_fm),
-           L.ptr(enc.touched_rows.grad), L.ptr(gg), L.stream())
+    encode_double_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
+                               dd_pos, g_fm, enc.touched_rows.grad, gg)
     return gg
 
 

@@ -143,3 +143,40 @@ def test_binned_backward_equals_atomic_backward(dev, P, F, L_, T):
     encode_backward_raw(cfg, pts[:sub].contiguous(), enc.lattice_values.detach(), enc.scale_factor,
                         enc.random_shift_per_level.detach(), w, g[:, :sub].contiguous(), gl_s, None)
     assert (gl_s.cpu() - lat.grad).abs().max() <= 1e-5 * lat.grad.abs().max() + 1e-7
+
+
+@pytest.mark.parametrize("P,F,L_,T,N", [(3, 2, 24, 2 ** 18, 49_152), (3, 2, 16, 2 ** 18, 300_001), (4, 2, 8, 2 ** 16, 40_000),
+                                       (2, 2, 8, 2 ** 14, 20_000), (3, 4, 8, 2 ** 16, 30_000)])
+def test_binned_double_backward_equals_atomic_double_backward(dev, P, F, L_, T, N):
+    """From 2^13 points on, the double backward's lattice scatter goes through the backward's binning + reduce kernels
+    (encode_bwd_kernel<.., DBL>); it must agree with the plain kernel (same operator, workspace withheld: LDS cache + float
+    atomics, the path the oracle-parity test above exercises) in both outputs -- the lattice gradient up to the order of the float
+    additions, the gradient w.r.t. the feature gradient bit for bit (a gather).  Ray-like batch: consecutive points are consecutive
+    samples of a ray, as in a training step (that is what the run combine and the LDS cache of the binning kernel see)."""
+    from permuto_sdf_amd import _lib as L
+    from permuto_sdf_amd.encoding import _head, _tail, encode_double_backward_raw
+    enc, sl, _, win = _make(P, L_, T, F, 8, seed=45, concat=True)
+    enc = enc.to(dev)
+    torch.manual_seed(2)
+    R = (N + 95) // 96
+    o = torch.rand(R, P, device=dev) - 0.5
+    d = torch.nn.functional.normalize(torch.randn(R, P, device=dev), dim=1)
+    t = torch.linspace(-0.3, 0.3, 96, device=dev)
+    pts = (o[:, None, :] + t[None, :, None] * d[:, None, :]).reshape(-1, P)[:N].contiguous()
+    g = torch.randn(enc.output_dims(), N, device=dev)
+    u = torch.randn(N, P, device=dev)
+    w = win.to(dev)
+    cfg = enc.cfg
+    lat, sf, sh = enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach()
+    gl_q, gg_q = torch.zeros_like(lat), torch.full_like(g, float("nan"))
+    encode_double_backward_raw(cfg, pts, lat, sf, sh, w, u, g, gl_q, gg_q)
+    gl_a, gg_a = torch.zeros_like(lat), torch.full_like(g, float("nan"))
+    L.call("psdf_encode_double_backward", *_head(cfg, N), L.ptr(pts), L.ptr(lat), L.ptr(sf), L.ptr(sh), L.ptr(w), *_tail(cfg),
+           L.ptr(u), L.ptr(g), L.ptr(gl_a), L.ptr(gg_a), L.stream())
+    assert torch.equal(gg_q, gg_a) and bool(torch.isfinite(gg_q).all())
+    scale = gl_a.abs().max().item()
+    assert scale > 0 and (gl_q - gl_a).abs().max().item() <= 2e-5 * scale
+    # without a lattice gradient buffer (gradient w.r.t. the feature gradient only) the plain kernel runs: same numbers
+    gg_n = torch.full_like(g, float("nan"))
+    encode_double_backward_raw(cfg, pts, lat, sf, sh, w, u, g, None, gg_n)
+    assert torch.equal(gg_n, gg_a)

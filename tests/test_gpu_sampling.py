@@ -223,11 +223,13 @@ def test_ray_sampler_fg_bg(port, world, dev, jitter):
     rs = RaySampler.compute_samples_fg(o, d, te, tx, 1e-2, 48, 0.5, torch.zeros(3, device=dev), jitter)
     ref = port.compact(port.march_samples(w["o"], w["d"], w["te"], w["tx"], 1e-2, 48, len(w["o"]) * 48, jitter=jitter, rng=st))
     compare_packed(rs, ref)
-    for contract in (False, True):
+    # 32: the training configuration; 24: rays do not fill a workgroup evenly; 300: more samples per ray than a workgroup
+    # has threads (the thread-per-ray kernel)
+    for contract, per_ray in ((False, 32), (True, 32), (True, 24), (False, 300)):
         st = (RaySampler._rng.state, RaySampler._rng.inc)
-        bg = RaySampler.compute_samples_bg(o, d, tx, 32, 0.5, [0, 0, 0], jitter, contract)
-        rb = port.samples_bg(w["o"], w["d"], w["tx"], 32, 0.5, [0, 0, 0], jitter, contract, rng=st)
-        assert bg.rays_have_equal_nr_of_samples and bg.fixed_nr_of_samples_per_ray == 32
+        bg = RaySampler.compute_samples_bg(o, d, tx, per_ray, 0.5, [0, 0, 0], jitter, contract)
+        rb = port.samples_bg(w["o"], w["d"], w["tx"], per_ray, 0.5, [0, 0, 0], jitter, contract, rng=st)
+        assert bg.rays_have_equal_nr_of_samples and bg.fixed_nr_of_samples_per_ray == per_ray
         bits_equal(bg.samples_z, rb.z)
         bits_equal(bg.samples_dt, rb.dt)
         bits_equal(bg.samples_pos, rb.pos)

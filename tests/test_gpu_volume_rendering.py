@@ -214,3 +214,69 @@ def test_importance_sampling_and_merge(port, data, dev, jitter):
     z = rc.z[:n, 0]
     for st_, en in rc.start_end[rc.counts() > 0][:200]:
         assert np.all(np.diff(z[st_:en]) >= 0)              # merged samples are sorted along each ray
+
+
+@pytest.mark.parametrize("case", ["ties", "unsorted_importance", "unsorted_uniform"])
+def test_merge_ties_and_unsorted_inputs(port, dev, case):
+    """combine_uniform_samples_with_imp is a serial two-way merge per ray in the reference (importance sample first on ties);
+    the kernel places every element by rank in parallel when both lists are sorted and walks the lists like the reference when
+    they are not.  Both branches, and z values that collide exactly, against the oracle bit for bit."""
+    from permuto_sdf import RaySamplesPacked, VolumeRendering as VR
+    rng = np.random.default_rng(11)
+    R, n_imp = 37, 16
+    o, d = scene.make_rays(R, seed=9)
+    _, te, _, tx, _ = port.sphere_intersect(0.5, [0, 0, 0], o, d)
+    counts = rng.integers(0, 90, R)
+    counts[:3] = (0, 1, 2)
+    start = np.concatenate([[0], np.cumsum(counts)])
+    M = int(start[-1])
+    s = O.Samples(R, M)
+    s.equal, s.fixed = False, 0
+    s.start_end = np.stack([start[:-1], start[1:]], 1).astype(np.int32)
+    grid = 64.0 if case == "ties" else 4096.0       # z on a coarse grid of values: many exact collisions between the two lists
+    z = np.zeros((M, 1), np.float32)
+    zi = np.zeros((R * n_imp, 1), np.float32)
+    for r in range(R):
+        a, b = float(te[r, 0]), float(tx[r, 0])
+        zu = np.sort(np.round(rng.uniform(a, b, counts[r]) * grid) / grid).astype(np.float32)
+        zr = np.sort(np.round(rng.uniform(a, b, n_imp) * grid) / grid).astype(np.float32)
+        if case == "unsorted_uniform" and counts[r] > 4 and r % 2 == 0:
+            zu[[1, 3]] = zu[[3, 1]]
+        if case == "unsorted_importance" and r % 3 == 0:
+            zr[[2, 9]] = zr[[9, 2]]
+        z[start[r]:start[r + 1], 0] = zu
+        zi[r * n_imp:(r + 1) * n_imp, 0] = zr
+    ridx = np.repeat(np.arange(R), counts)
+    s.z = z
+    s.dt = np.full((M, 1), 1e-2, np.float32)
+    s.pos = (o[ridx] + z * d[ridx]).astype(np.float32)
+    s.dirs = d[ridx].astype(np.float32)
+    s.fixed_dt = rng.uniform(5e-3, 2e-2, (R, 1)).astype(np.float32)
+    s.sdf = rng.normal(0, 1, (M, 1)).astype(np.float32)
+    s.has_sdf = True
+    ri = O.Samples(R, R * n_imp)
+    ri.equal, ri.fixed = True, n_imp
+    iidx = np.repeat(np.arange(R), n_imp)
+    ri.z, ri.pos, ri.dirs = zi, (o[iidx] + zi * d[iidx]).astype(np.float32), d[iidx].astype(np.float32)
+    ri.sdf = rng.normal(0, 1, (R * n_imp, 1)).astype(np.float32)
+    ri.has_sdf = True
+    ri.start_end = np.stack([np.arange(R) * n_imp, np.arange(R) * n_imp + n_imp], 1).astype(np.int32)
+    ri.dt = np.zeros((R * n_imp, 1), np.float32)
+    ri.fixed_dt = np.zeros((R, 1), np.float32)
+    if case == "ties":
+        assert len(np.intersect1d(z, zi)) > 20
+    rs = to_packed(s, dev)
+    imp = RaySamplesPacked(R, R * n_imp)
+    imp.rays_have_equal_nr_of_samples, imp.fixed_nr_of_samples_per_ray = True, n_imp
+    imp.samples_z, imp.samples_pos, imp.samples_dirs = T(ri.z, dev), T(ri.pos, dev), T(ri.dirs, dev)
+    imp.set_sdf(T(ri.sdf, dev))
+    comb = VR.combine_uniform_samples_with_imp(T(o, dev), T(d, dev), T(tx, dev), rs, imp)
+    rc = port.compact(port.combine(s, ri, o, d, tx))
+    n = rc.total()
+    assert n > 0 and comb.compute_exact_nr_samples() == n
+    c = comb.compact_to_valid_samples()
+    bits_equal(c.ray_start_end_idx, rc.start_end)
+    for name, arr in (("samples_pos", rc.pos), ("samples_dirs", rc.dirs), ("samples_z", rc.z), ("samples_dt", rc.dt),
+                      ("samples_sdf", rc.sdf)):
+        bits_equal(getattr(c, name), arr[:n])
+    bits_equal(c.ray_fixed_dt, rc.fixed_dt)

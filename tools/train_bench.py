@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--start-iter", type=int, default=0, help="iteration counter the run starts at: 0 = the coarse-to-fine window of "
+                    "the SDF lattice is still mostly closed (fine levels carry no gradient); 20000 = every level open")
     ap.add_argument("--manual", action="store_true", help="train_manual.ManualTrainer: hand-written backward over the raw kernels")
     args = ap.parse_args()
     rank, world, local = parallel.init()
@@ -32,6 +34,7 @@ def main():
     else:
         tr = Trainer(dev)
     reel = SyntheticReel(dev)
+    tr.iter = args.start_iter
     for _ in range(args.warmup):
         tr.step(reel)
 
@@ -69,7 +72,7 @@ def main():
                           "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                           "fg_samples_per_step_per_gpu": samples / args.steps, "rays_last_step": tr.last["nr_rays"],
-                          "scaling": "weak", "dtype": "f32", "data": "synthetic",
+                          "scaling": "weak", "dtype": "f32", "data": "synthetic", "start_iter": args.start_iter,
                           "backward": "hand-written (train_manual.py)" if args.manual else "torch autograd over the fused operators",
                           "repeats_it_per_s": [round(args.steps / r, 1) for r in reps]}))
     parallel.shutdown()
