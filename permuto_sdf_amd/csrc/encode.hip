@@ -47,9 +47,15 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     }
     return;
   }
+  const float w = window[level];
+  if (w == 0.f) {  // a level the coarse-to-fine window keeps closed (workgroup-uniform): its channels are 0 * (finite rows) = 0,
+                   // no simplex, no gathers, nothing to mark (its backward contributes nothing either)
+#pragma unroll
+    for (int f = 0; f < F; f++) sliced[((int64_t)level * F + f) * N + n] = 0.f;
+    return;
+  }
   Simplex<P> s;
   compute_simplex<P>(pos, shifts + level * P, scale_factor + level * P, s, conv.tie_later);
-  const float w = window[level];
   const float* __restrict__ table = lattice + (int64_t)level * capacity * F;
   // issue all P+1 gathers before consuming them (independent 8-B loads in flight)
   uint32_t row[P + 1];
@@ -424,6 +430,17 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
     }
     return;
   }
+  if (window[level] == 0.f) {   // closed level (workgroup-uniform, before any barrier): every contribution carries the factor 0
+    if (DBL) {
+      for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
+        if (n >= N) continue;
+#pragma unroll
+        for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = 0.f;
+      }
+    }
+    return;
+  }
   using SCache = ScatterCache<F, QUEUE ? 4096 : 8192>;
   SCache sc;
   if (LATTICE) sc.init(lds);
@@ -662,6 +679,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       shl[i] = shifts[level * P + i];
     }
     const float w = window[level];
+    if (w == 0.f) continue;   // closed level: contributes 0
     const int64_t tbase = (int64_t)level * capacity * F;
     Simplex<P> s;
     compute_simplex<P>(pos, shl, sfl, s, conv.tie_later);
@@ -791,12 +809,21 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     }
     return;
   }
+  const float w = window[level];
+  if (w == 0.f) {   // closed level: no lattice contribution, gradient w.r.t. the feature gradient 0
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
+      if (n >= N) continue;
+#pragma unroll
+      for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = 0.f;
+    }
+    return;
+  }
   ScatterCache<F> sc;
   if (LATTICE) sc.init(lds);
   bool use_cache = LATTICE;
   int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
   int hits = 0, tries = 0, iter = 0;
-  const float w = window[level];
   const int64_t tbase = (int64_t)level * capacity * F;
   float sfl[P], shl[P];
 #pragma unroll
