@@ -106,3 +106,50 @@ def test_fusion_hook_keeps_parameters_and_checkpoint_keys():
     env["PSDF_FUSE_REFERENCE_MLPS"] = "1"
     r = subprocess.run([sys.executable, "-c", FUSE_SCRIPT], capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
     assert r.returncode == 0 and "FUSE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+APEX_SCRIPT = r'''
+import os, sys, torch
+from permuto_sdf_py.utils.permuto_sdf_utils import module_exists       # the reference's own probe (train_permuto_sdf.py:60)
+if os.environ.get("PSDF_COMPAT_NO_APEX") == "1":
+    assert not module_exists("apex")
+    print("APEX_OFF")
+    sys.exit(0)
+assert module_exists("apex")
+import apex
+from permuto_sdf_amd.optim import FusedAdamW
+m = torch.nn.Linear(4, 3)
+# the reference's call, train_permuto_sdf.py:293-301: named groups with their own lr / weight decay
+opt = apex.optimizers.FusedAdam([{"params": m.parameters(), "weight_decay": 0.1, "lr": 2e-3, "name": "model_colorcal"}],
+                                amsgrad=False, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, lr=1e-3)
+assert isinstance(opt, FusedAdamW) and isinstance(opt, torch.optim.Optimizer)
+g = opt.param_groups[0]
+assert (g["name"], g["lr"], g["weight_decay"], g["betas"], g["eps"]) == ("model_colorcal", 2e-3, 0.1, (0.9, 0.99), 1e-15)
+from permuto_sdf_py.schedulers.multisteplr import MultiStepLR           # the reference's schedulers drive it like any optimiser
+from permuto_sdf_py.schedulers.warmup import GradualWarmupScheduler
+s = GradualWarmupScheduler(opt, multiplier=1, total_epoch=4, after_scheduler=MultiStepLR(opt, milestones=[2], gamma=0.3, verbose=False))
+m.weight.grad = torch.zeros_like(m.weight)
+opt.zero_grad()
+assert m.weight.grad is None                                           # apex default: set_grad_none=True
+try:
+    apex.optimizers.FusedAdam(m.parameters(), amsgrad=True)
+    raise SystemExit("amsgrad accepted")
+except RuntimeError:
+    pass
+print("APEX_OK")
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "permuto_sdf_py")), reason="reference checkout not present")
+@pytest.mark.parametrize("off", [False, True])
+def test_compat_apex_is_the_references_fused_optimizer_hook(off):
+    """train_permuto_sdf.py:60-64,300-303 takes apex.optimizers.FusedAdam when `apex` imports: compat/apex supplies it on the fused
+    AdamW kernels; PSDF_COMPAT_NO_APEX=1 hides it (the reference then builds torch.optim.AdamW)."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "compat"), REF])
+    if off:
+        env["PSDF_COMPAT_NO_APEX"] = "1"
+    else:
+        env.pop("PSDF_COMPAT_NO_APEX", None)
+    r = subprocess.run([sys.executable, "-c", APEX_SCRIPT], capture_output=True, text=True, env=env, cwd="/tmp", timeout=600)
+    assert r.returncode == 0 and ("APEX_OFF" if off else "APEX_OK") in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -32,3 +32,43 @@ def test_fused_adamw_matches_torch(dev, wd):
     FusedAdamW([p1], lr=1e-2).step()
     FusedAdamW([p2], lr=1e-2).step(grad_scale=0.25)
     assert torch.allclose(p1, p2, atol=1e-7)
+
+
+def test_compat_apex_fused_adam_matches_torch_adamw_on_the_references_groups(dev):
+    """compat/apex: `apex.optimizers.FusedAdam` as train_permuto_sdf.py:293-301 builds it (named groups with their own weight
+    decay, a group whose parameters have no gradient yet, weight decay switched on later, learning rates changed by a scheduler)
+    == torch.optim.AdamW, the reference's other branch (:303)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat"))
+    import apex
+    torch.manual_seed(1)
+
+    def make():
+        torch.manual_seed(2)
+        return [[torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes] for shapes in
+                (((24, 4096, 2), (33, 32), (33,)), ((64, 52), (65,)), ((24, 2048, 2),), ((49, 3), (49, 3)))]
+    names, wds = ("model_sdf", "model_bg", "model_rgb_only_encoding", "model_colorcal"), (0.0, 0.0, 0.0, 1e-1)
+    ra, rb = make(), make()
+    kw = dict(amsgrad=False, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0, lr=1e-3)
+    oa = torch.optim.AdamW([{"params": p, "weight_decay": w, "lr": 1e-3, "name": n} for p, w, n in zip(ra, wds, names)], **kw)
+    ob = apex.optimizers.FusedAdam([{"params": p, "weight_decay": w, "lr": 1e-3, "name": n} for p, w, n in zip(rb, wds, names)], **kw)
+    for it in range(6):
+        oa.zero_grad()
+        ob.zero_grad()
+        for gi, (ga, gb) in enumerate(zip(ra, rb)):
+            if gi == 1 and it < 2:            # the background net gets no gradient during the sphere-initialisation phase
+                continue
+            for a, b in zip(ga, gb):
+                g = torch.randn_like(a) * (1e-3 if a.dim() == 3 else 1.0)
+                a.grad, b.grad = g.clone(), g.clone()
+        for o in (oa, ob):
+            for group in o.param_groups:
+                group["lr"] = 1e-3 * (it + 1) / 6                       # a warm-up scheduler at work
+                if it >= 3 and group["name"] == "model_rgb_only_encoding":
+                    group["weight_decay"] = 1.0                         # train_permuto_sdf.py:400-403
+        oa.step()
+        ob.step()
+    for ga, gb in zip(ra, rb):
+        for a, b in zip(ga, gb):
+            assert (a - b).abs().max() <= 2e-6 * max(1.0, float(a.abs().max())), (tuple(a.shape), float((a - b).abs().max()))

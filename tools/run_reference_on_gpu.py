@@ -117,8 +117,20 @@ def main():
 
     sys.argv = ["train_permuto_sdf.py", "--dataset", "dtu", "--scene", "dtu_scan24", "--comp_name", "comp_1", "--no_viewer"]
     t0 = time.time()
+    prof_file = os.environ.get("PSDF_PROFILE_REFERENCE")   # cProfile of the whole run() -> top functions into this file
+    if prof_file:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
     T.run()
     torch.cuda.synchronize()
+    if prof_file:
+        pr.disable()
+        with open(prof_file, "w") as fh:
+            st = pstats.Stats(pr, stream=fh)
+            st.sort_stats("tottime").print_stats(60)
+            st.sort_stats("cumulative").print_stats(90)
     log["train_wall_s"] = time.time() - t0
     log["losses"] = losses
 
