@@ -51,12 +51,15 @@ def test_encode_kernels_keep_their_residency(objdir, tmp_path):
     fwd = _one(k, r"encode_fwd_kernelILi3ELi2E")
     assert fwd["vgpr_count"] <= 64 and fwd["vgpr_spill_count"] == 0 and fwd["private_segment_fixed_size"] == 0   # 8 waves / SIMD
     # queue-mode binning kernels of the SDF lattice (pos_dim 3, 2 features): 5 waves per SIMD = at most 96 registers, no spill
-    for pat in (r"encode_bwd_kernelILi3ELi2ELb1ELb0ELb1E", r"encode_bwd_kernelILi3ELi2ELb1ELb1ELb1E"):
+    # (template arguments: P, F, LATTICE, POS, QUEUE, DBL -- the last one = the double backward's scatter through the same kernel)
+    for pat in (r"encode_bwd_kernelILi3ELi2ELb1ELb0ELb1ELb0E", r"encode_bwd_kernelILi3ELi2ELb1ELb1ELb1ELb0E",
+                r"encode_bwd_kernelILi3ELi2ELb1ELb0ELb1ELb1E"):
         b = _one(k, pat)
         assert b["vgpr_count"] <= 96, b
         assert b["vgpr_spill_count"] == 0, b
     # the other instantiations ask for 4 waves (128 registers)
-    for pat in (r"encode_bwd_kernelILi4ELi2ELb1ELb0ELb1E", r"encode_bwd_kernelILi3ELi4ELb1ELb0ELb1E"):
+    for pat in (r"encode_bwd_kernelILi4ELi2ELb1ELb0ELb1ELb0E", r"encode_bwd_kernelILi3ELi4ELb1ELb0ELb1ELb0E",
+                r"encode_bwd_kernelILi4ELi2ELb1ELb0ELb1ELb1E", r"encode_bwd_kernelILi3ELi4ELb1ELb0ELb1ELb1E"):
         b = _one(k, pat)
         assert b["vgpr_count"] <= 128 and b["vgpr_spill_count"] == 0, b
     red = _one(k, r"encode_bwd_reduce_kernelILi2E")
