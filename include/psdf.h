@@ -391,6 +391,12 @@ int psdf_cumsum_over_each_ray(int nr_rays, const int* start_end, int equal, int 
 int psdf_sdf2alpha(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float*
     ray_fixed_dt, const float* samples_dt, const float* sdf, float inv_s, int dynamic_inv_s, float inv_s_multiplier,
     float* alpha, void* stream);
+/* sdf2alpha -> clip(0,1) -> 1 - alpha + 1e-7 -> cumprod_alpha2transmittance -> alpha * T -> sum_over_each_ray -> / clamp(sum, 1e-6)
+   -> compute_cdf in ONE launch: the operator chain of importance_sampling_sdf_model (permuto_sdf_py/utils/sdf_utils.py:383-423),
+   bit-identical to calling the operators one by one; cdf [M,1] (zero-filled by the caller where slots belong to no ray) */
+int psdf_sdf_importance_cdf(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float* ray_fixed_dt,
+                            const float* samples_dt, const float* sdf, float inv_s, int dynamic_inv_s, float inv_s_multiplier,
+                            float* cdf, void* stream);
 
 /* replaces: VolumeRendering::compute_dt, src/VolumeRendering.cu:135-167 */
 int psdf_compute_dt(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float*

@@ -579,6 +579,21 @@ class VolumeRendering:
         return alpha
 
     @staticmethod
+    def sdf_importance_cdf(ray_samples_packed, sdf_samples, inv_s, dynamic_inv_s, inv_s_multiplier):
+        """NOT part of the reference's API: the cdf `importance_sampling_sdf_model` (sdf_utils.py:383-423) draws from, in one launch
+        instead of the nine of
+            alpha = sdf2alpha(rs, sdf, inv_s, dynamic, mult).clip(0, 1); T, _ = cumprod_alpha2transmittance(rs, 1 - alpha + 1e-7)
+            w = alpha * T; _, s = sum_over_each_ray(rs, w); cdf = compute_cdf(rs, w / clamp(s, min=1e-6))
+        bit-identical to that chain (for trainers that own their sampling loop; the reference's Python calls the operators)."""
+        rs = ray_samples_packed
+        M = rs.samples_z.shape[0]
+        sdf = VolumeRendering._vals(sdf_samples, M, 1, "sdf_samples")
+        cdf = _per_sample(rs, (M, 1), sdf.device)
+        L.call("psdf_sdf_importance_cdf", *rs._ri(), L.ptr(_f32c(rs.ray_fixed_dt)), L.ptr(_f32c(rs.samples_dt)), L.ptr(sdf),
+               L.c_f(float(inv_s)), L.c_i(int(dynamic_inv_s)), L.c_f(float(inv_s_multiplier)), L.ptr(cdf), L.stream())
+        return cdf
+
+    @staticmethod
     def sum_over_each_ray(ray_samples_packed, sample_values):
         rs = ray_samples_packed
         R, M = rs.ray_start_end_idx.shape[0], rs.samples_z.shape[0]

@@ -205,6 +205,68 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
 }
 
+// ------------------------------------------------------------------ sdf -> cdf of the importance sampler, one launch
+// importance_sampling_sdf_model (sdf_utils.py:383-423) goes from the SDF of a ray's samples to the cdf it draws from in nine
+// launches: sdf2alpha, clip(0, 1), 1 - alpha + 1e-7 (two), cumprod_alpha2transmittance, alpha * T, sum_over_each_ray,
+// clamp(min = 1e-6), the division, compute_cdf.  The reference's Python has to (it calls the operators one by one); a trainer
+// that owns its sampling loop does not.  Same expressions, the same wave scans / reductions in the same chunk order as the
+// kernels above: bit-identical to the chain (tests/test_gpu_volume_rendering.py::test_sdf_importance_cdf_equals_the_operator_
+// chain).  `cdf` doubles as the scratch of the weights between the two sweeps (a lane re-reads what it wrote itself).
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    sdf_importance_cdf_kernel(int nr_rays, RayIndex ri, const float* __restrict__ ray_fixed_dt, const float* __restrict__ dt,
+                              const float* __restrict__ sdf, float inv_s_in, int dynamic_inv_s, float inv_s_mult,
+                              float* __restrict__ cdf) {
+  const int lane = lane_id();
+  RAY_LOOP(ray, nr_rays) {
+    int s, e;
+    ri.get(ray, s, e);
+    if (!ri.valid(s, e)) continue;
+    float inv_s = inv_s_in;
+    if (dynamic_inv_s) inv_s = map_range(ray_fixed_dt[ray], 0.0001f, 0.01f, 1024.f, 64.f);
+    inv_s = inv_s * inv_s_mult;
+    const int n = e - s;
+    float carry = 1.f, acc = 0.f;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      float a = 0.f;                                   // the last sample of a ray keeps alpha 0 (sdf2alpha)
+      if (i < n - 1) {
+        const float d = dt[s + i];
+        const float prev = sdf[s + i], next = sdf[s + i + 1];
+        const float mid = (float)((double)(prev + next) * 0.5);
+        float cosv = (next - prev) / fmaxf(d, 1e-6f);
+        cosv = clampf(cosv, -1e3f, 0.0f);
+        const float half = (float)((double)(cosv * d) * 0.5);
+        const float prev_cdf = sigmoidf((mid - half) * inv_s);
+        const float next_cdf = sigmoidf((mid + half) * inv_s);
+        a = (float)(((double)(prev_cdf - next_cdf) + 1e-6) / ((double)prev_cdf + 1e-6));
+        a = a < 0.f ? 0.f : (a > 1.f ? 1.f : a);       // torch.clip(0, 1): a NaN stays a NaN
+      }
+      const float om = (1.f - a) + 1e-7f;              // 1 - alpha + 1e-7
+      const float f = (i < n - 1) ? om : 1.f;          // cumprod_fwd_kernel: the last sample's factor never enters
+      const float incl = wave_incl_scan_mul(f);
+      float excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = 1.f;
+      const float T = carry * excl;
+      carry = carry * __shfl(incl, 63, 64);
+      if (i < n) {
+        const float w = a * T;
+        cdf[s + i] = w;
+        acc += w;                                      // sum_ray_fwd_kernel: per-lane partials over the chunks, then the wave sum
+      }
+    }
+    const float total = wave_sum(acc);
+    const float den = total < 1e-6f ? 1e-6f : total;   // torch.clamp(min = 1e-6) (NaN stays NaN)
+    float csum = 0.f;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const float v = (i < n) ? cdf[s + i] / den : 0.f;
+      const float incl = wave_incl_scan_add(v);
+      if (i < n) cdf[s + i] = csum + (incl - v);       // cumsum_kernel, exclusive
+      csum = csum + __shfl(incl, 63, 64);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(PSDF_BLOCK)
     compute_dt_kernel(int nr_rays, RayIndex ri, const float* __restrict__ z, const float* __restrict__ t_exit,
                       int use_t_exit, float* __restrict__ dt) {
@@ -646,6 +708,17 @@ int psdf_sdf2alpha(int nr_rays, const int* start_end, int equal, int fixed, int 
   hipLaunchKernelGGL(sdf2alpha_kernel, dim3(ray_grid(nr_rays)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, nr_rays,
                      mk_ri(start_end, equal, fixed, max_nr_samples), ray_fixed_dt, samples_dt, sdf, inv_s, dynamic_inv_s,
                      inv_s_multiplier, alpha);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_sdf_importance_cdf(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float* ray_fixed_dt,
+                            const float* samples_dt, const float* sdf, float inv_s, int dynamic_inv_s, float inv_s_multiplier,
+                            float* cdf, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  hipLaunchKernelGGL(sdf_importance_cdf_kernel, dim3(ray_grid(nr_rays)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, nr_rays,
+                     mk_ri(start_end, equal, fixed, max_nr_samples), ray_fixed_dt, samples_dt, sdf, inv_s, dynamic_inv_s,
+                     inv_s_multiplier, cdf);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

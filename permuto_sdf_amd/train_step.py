@@ -425,11 +425,9 @@ class Trainer:
             return fg, bg
         fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it))
         for rnd, mult in ((0, 1.0), (1, 2.0)):
-            alpha = VolumeRendering.sdf2alpha(fg, fg.samples_sdf, 512.0, True, mult).clip(0.0, 1.0)
-            T, _ = VolumeRendering.cumprod_alpha2transmittance(fg, 1 - alpha + 1e-7)
-            w = alpha * T
-            _, per_sample = VolumeRendering.sum_over_each_ray(fg, w)
-            cdf = VolumeRendering.compute_cdf(fg, w / torch.clamp(per_sample, min=1e-6))
+            # sdf2alpha -> clip -> 1 - alpha + 1e-7 -> cumprod -> alpha * T -> per-ray sum -> normalise -> cdf
+            # (sdf_utils.py:403-417), one launch, bit-identical to the nine of the operator chain
+            cdf = VolumeRendering.sdf_importance_cdf(fg, fg.samples_sdf, 512.0, True, mult)
             imp = VolumeRendering.importance_sample(o, d, fg, cdf, hp.nr_samples_imp_sampling, jitter)
             if rnd == 0:
                 imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it))

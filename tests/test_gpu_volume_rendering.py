@@ -280,3 +280,31 @@ def test_merge_ties_and_unsorted_inputs(port, dev, case):
                       ("samples_sdf", rc.sdf)):
         bits_equal(getattr(c, name), arr[:n])
     bits_equal(c.ray_fixed_dt, rc.fixed_dt)
+
+
+@pytest.mark.parametrize("mult", [1.0, 2.0])
+def test_sdf_importance_cdf_equals_the_operator_chain(data, dev, mult):
+    """VolumeRendering.sdf_importance_cdf (one launch; the trainers' sampling loop) == the nine launches of
+    importance_sampling_sdf_model's operator chain (sdf_utils.py:403-417), bit for bit: rays of 0, 1, 2, 3 .. 160 samples,
+    packed and equal-count containers, a NaN in the SDF."""
+    from permuto_sdf import VolumeRendering as VR
+    rs = data["rs"]
+    sdf = rs.samples_sdf.clone()
+    if data["M"] > 500:
+        sdf[437] = float("nan")
+
+    def chain():
+        alpha = VR.sdf2alpha(rs, sdf, 512.0, True, mult).clip(0.0, 1.0)
+        Tr, _ = VR.cumprod_alpha2transmittance(rs, 1 - alpha + 1e-7)
+        w = alpha * Tr
+        _, per_sample = VR.sum_over_each_ray(rs, w)
+        return VR.compute_cdf(rs, w / torch.clamp(per_sample, min=1e-6))
+    a, b = chain(), VR.sdf_importance_cdf(rs, sdf, 512.0, True, mult)
+    assert a.shape == b.shape
+    nan = torch.isnan(a)
+    assert torch.equal(nan, torch.isnan(b))                  # the ray with the NaN is NaN in both (sign / payload bits are not compared)
+    if data["M"] > 500:
+        assert bool(nan.any()) and not bool(nan.all())
+    assert torch.equal(a[~nan].view(torch.int32), b[~nan].view(torch.int32)), float((a[~nan] - b[~nan]).abs().max())
+    ok = torch.isfinite(a)
+    assert float(a[ok].max()) <= 1.0 + 1e-5 and float(a[ok].min()) >= 0.0
