@@ -66,12 +66,15 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
     concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced, float* grad_lattice,
     float* grad_grad_sliced, void* stream);
 /* Same, with the backward's device workspace (psdf_encode_backward_workspace_bytes; NULL = none): large batches send the
- * lattice scatter through the binning + reduce kernels instead of float atomics. */
+ * lattice scatter through the binning + reduce kernels instead of float atomics.  grad_grad_sliced may be NULL when only the
+ * lattice gradient is wanted.  grad_sliced_direct (optional, [C, N]): the lattice scatter of the PLAIN backward for this upstream
+ * gradient is added in the same pass (grad_lattice += d<sliced, grad_sliced_direct>/d lattice): a training step sends both onto
+ * the same rows. */
 int psdf_encode_double_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
                                    const float* lattice, const float* scale_factor, const float* shifts, const float* window,
                                    int concat_points, float points_scaling, const float* dd_positions, const float* grad_sliced,
-                                   float* grad_lattice, float* grad_grad_sliced, void* workspace, int64_t workspace_bytes,
-                                   void* stream);
+                                   float* grad_lattice, float* grad_grad_sliced, const float* grad_sliced_direct,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- mlp.hip, opt-in arithmetic ---- */
 /* psdf_mlp_pack / psdf_mlp_forward with TWO fp16 pieces per fp32 operand (three products on v_mfma_f32_32x32x16_f16) instead of

@@ -377,7 +377,10 @@ __device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, in
 // mode lets 5 workgroups share a CU's LDS.  (P = 4 and F = 4 would spill a few VGPRs at 5 waves: they ask for 4.)
 // DBL = true: the DOUBLE backward's lattice scatter through the same machinery (see encode_dbl_bwd_kernel for the maths): the
 // coefficient of vertex r is q_r (the directional derivative of its barycentric along u = dd_positions) instead of bary_r, and
-// the kernel also writes grad_grad_sliced = sum_r q_r w lattice[row_r] (a gather of the rows it has just computed).
+// the kernel also writes grad_grad_sliced = sum_r q_r w lattice[row_r] (a gather of the rows it has just computed; skipped
+// when the pointer is NULL).  grad_sliced2 (optional): the PLAIN backward's scatter of a second upstream gradient rides along,
+// row_r += w (q_r g + bary_r g2) -- a training step scatters both onto the same rows of the same simplices (the double backward
+// of the normals and the backward of the features), so one simplex, one run combine, one queue pass and one reduce serve both.
 template <int P, int F, bool LATTICE, bool POS, bool QUEUE, bool DBL = false>
 #if !defined(PSDF_ENC_QWAVES)
 #define PSDF_ENC_QWAVES 5
@@ -388,7 +391,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                       const float* __restrict__ grad_sliced, float* __restrict__ grad_lattice,
                       float* __restrict__ grad_positions, Queues Q, const float* __restrict__ dd_positions = nullptr,
-                      float* __restrict__ grad_grad_sliced = nullptr, int pad_points = 0) {
+                      float* __restrict__ grad_grad_sliced = nullptr, int pad_points = 0,
+                      const float* __restrict__ grad_sliced2 = nullptr) {
   static_assert(!(DBL && POS), "the double backward has no position output");
   extern __shared__ __align__(16) float lds[];
 #if defined(PSDF_ENC_PROFILE)
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 #pragma unroll
           for (int i = 0; i < P; i++)
             if (i == d) v = u[i] * points_scaling;
-          if (d < P || pad_points) grad_grad_sliced[((int64_t)level * F + f) * N + n] = v;
+          if ((d < P || pad_points) && grad_grad_sliced) grad_grad_sliced[((int64_t)level * F + f) * N + n] = v;
         }
       }
     }
@@ -431,7 +435,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
     return;
   }
   if (window[level] == 0.f) {   // closed level (workgroup-uniform, before any barrier): every contribution carries the factor 0
-    if (DBL) {
+    if (DBL && grad_grad_sliced) {
       for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
         if (n >= N) continue;
@@ -478,9 +482,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
     for (int sp = 0; sp < SPT; sp++) {
       const int64_t n = (tile * SPT + sp) * PSDF_BLOCK + threadIdx.x;
       if (n < N) {
-        float g[F];
+        float g[F], g2[F];
 #pragma unroll
-        for (int f = 0; f < F; f++) g[f] = grad_sliced[((int64_t)level * F + f) * N + n];
+        for (int f = 0; f < F; f++) {
+          g[f] = grad_sliced[((int64_t)level * F + f) * N + n];
+          g2[f] = (DBL && grad_sliced2) ? grad_sliced2[((int64_t)level * F + f) * N + n] : 0.f;
+        }
         float pos[P];
         load_pos<P>(positions, n, pos);
         Simplex<P> s;
@@ -523,7 +530,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 #pragma unroll
         for (int r = 0; r <= P; r++) {
           const uint32_t row = rows[r];
-          if (DBL) {
+          if (DBL && grad_grad_sliced) {
             const float qw = q[r] * w;
 #pragma unroll
             for (int f = 0; f < F; f++) gg[f] = gg[f] + qw * lattice[tbase + (int64_t)row * F + f];
@@ -534,6 +541,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
             crow[c] = row;
 #pragma unroll
             for (int f = 0; f < F; f++) cval[c][f] = g[f] * bw;
+            if (DBL && grad_sliced2) {
+              const float bw2 = s.bary[r] * w;
+#pragma unroll
+              for (int f = 0; f < F; f++) cval[c][f] = cval[c][f] + g2[f] * bw2;
+            }
             pending[c] = true;  // provisional: resolved after the run combine below (outside this divergent branch)
           }
           if (POS) {
@@ -541,7 +553,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
             for (int f = 0; f < F; f++) dbary[r] = dbary[r] + lattice[tbase + (int64_t)row * F + f] * w * g[f];
           }
         }
-        if (DBL) {
+        if (DBL && grad_grad_sliced) {
 #pragma unroll
           for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = gg[f];
         }
@@ -1231,10 +1243,11 @@ int psdf_encode_double_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_l
                                    const float* positions, const float* lattice, const float* scale_factor,
                                    const float* shifts, const float* window, int concat_points, float points_scaling,
                                    const float* dd_positions, const float* grad_sliced, float* grad_lattice,
-                                   float* grad_grad_sliced, void* workspace, int64_t workspace_bytes, void* stream) {
+                                   float* grad_grad_sliced, const float* grad_sliced_direct, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
   if (N == 0) return PSDF_OK;
   if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !dd_positions || !grad_sliced ||
-      !grad_grad_sliced || !concat_ok(concat_points))
+      (!grad_grad_sliced && !grad_lattice) || (grad_sliced_direct && !grad_lattice) || !concat_ok(concat_points))
     return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
@@ -1261,7 +1274,7 @@ int psdf_encode_double_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_l
     hipLaunchKernelGGL(kern, dim3((unsigned)(gx < 1 ? 1 : gx), Lt), dim3(PSDF_BLOCK), shm, st, N, nr_levels,             \
                        (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,     \
                        points_scaling, grad_sliced, grad_lattice, (float*)nullptr, Q, dd_positions, grad_grad_sliced,    \
-                       pad_points(concat_points));                                                                       \
+                       pad_points(concat_points), grad_sliced_direct);                                                   \
     const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                                    \
     hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);                         \
@@ -1283,6 +1296,18 @@ int psdf_encode_double_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_l
       PSDF_LAUNCH_CHECK();
       return PSDF_OK;
     }
+  }
+  // small batches: the plain double-backward kernel (it always writes the gathered output: give it scratch when the caller
+  // wants the lattice gradient only), and the direct part as an ordinary backward
+  if (grad_sliced_direct) {
+    const int rc = psdf_encode_backward_ws(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts,
+                                           window, concat_points, points_scaling, grad_sliced_direct, grad_lattice, nullptr,
+                                           nullptr, 0, stream);
+    if (rc != PSDF_OK) return rc;
+  }
+  if (!grad_grad_sliced) {
+    grad_grad_sliced = (float*)psdf::stream_scratch((size_t)Lt * nr_feat * N * sizeof(float), st);
+    if (!grad_grad_sliced) return PSDF_ERR_UNSUPPORTED;
   }
   // Plain (cache + atomics) mode: a workgroup sets up and flushes a 48-KiB LDS cache, so it should walk several tiles;
   // PSDF_ENC_BWD_WG_PER_LEVEL overrides the per-level workgroup cap (measurement switch).
@@ -1323,7 +1348,7 @@ int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_leve
                                 float* grad_grad_sliced, void* stream) {
   return psdf_encode_double_backward_ws(pos_dim, nr_feat, N, nr_levels, capacity, positions, lattice, scale_factor, shifts,
                                         window, concat_points, points_scaling, dd_positions, grad_sliced, grad_lattice,
-                                        grad_grad_sliced, nullptr, 0, stream);
+                                        grad_grad_sliced, nullptr, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -91,15 +91,18 @@ def _backward_workspace(cfg, N, device):
     return (torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes > 0 else None), nbytes
 
 
-def encode_double_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, dd_positions, g_fm, g_lat, gg_fm):
+def encode_double_backward_raw(cfg, positions, lattice, scale_factor, shifts, window, dd_positions, g_fm, g_lat, gg_fm,
+                               direct_fm=None):
     """backward of the position gradient (models.py:245-251, create_graph=True): accumulates into g_lat [L,T,F] (or None) the
-    gradient w.r.t. the lattice and overwrites gg_fm [C,N] with the gradient w.r.t. the feature gradient g_fm.  Batches large
-    enough for the binned plan get its scratch from torch's caching allocator (as encode_backward_raw does)."""
+    gradient w.r.t. the lattice and overwrites gg_fm [C,N] (or None: not wanted) with the gradient w.r.t. the feature gradient
+    g_fm.  direct_fm [C,N] (optional): the lattice scatter of the PLAIN backward for this upstream gradient of the features is
+    added in the same pass.  Batches large enough for the binned plan get its scratch from torch's caching allocator (as
+    encode_backward_raw does)."""
     N = positions.shape[0]
     ws, nbytes = _backward_workspace(cfg, N, positions.device) if g_lat is not None else (None, 0)
     L.call("psdf_encode_double_backward_ws", *_head(cfg, N), L.ptr(positions), L.ptr(lattice), L.ptr(scale_factor), L.ptr(shifts),
-           L.ptr(window), *_tail(cfg), L.ptr(dd_positions), L.ptr(g_fm), L.ptr(g_lat), L.ptr(gg_fm), L.ptr(ws), L.c_l(nbytes),
-           L.stream())
+           L.ptr(window), *_tail(cfg), L.ptr(dd_positions), L.ptr(g_fm), L.ptr(g_lat), L.ptr(gg_fm), L.ptr(direct_fm), L.ptr(ws),
+           L.c_l(nbytes), L.stream())
 
 
 def _feature_major(g):

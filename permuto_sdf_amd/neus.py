@@ -121,12 +121,13 @@ def neus_composite(rs, max_per_ray, sdf, gradients, rgb, inv_s, cos_anneal_ratio
     return NeusCompositeFunc.apply(rs, max_per_ray, sdf, gradients, rgb, inv_s, cos_anneal_ratio)
 
 
-def l1_loss_raw(pred, gt, mask=None, scale=None, want_grad=True):
-    """-> (loss [1], g_pred or None): loss = scale * sum |gt - pred| * mask; scale defaults to 1/numel (the reference's mean)"""
+def l1_loss_raw(pred, gt, mask=None, scale=None, want_grad=True, loss=None):
+    """-> (loss [1], g_pred or None): loss = scale * sum |gt - pred| * mask; scale defaults to 1/numel (the reference's mean).
+    `loss`: an accumulator to ADD to (the kernels add with one atomic per workgroup) instead of a fresh zero"""
     L.require_cuda(pred, gt)
     R, C = pred.shape
     scale = 1.0 / max(1, R * C) if scale is None else float(scale)
-    loss = L.zeroed_scalar(pred.device)
+    loss = L.zeroed_scalar(pred.device) if loss is None else loss
     g = torch.empty_like(pred) if want_grad else None
     m = None if mask is None else mask.reshape(-1).to(torch.uint8).contiguous()
     L.call("psdf_l1_loss", L.c_l(R), L.c_i(C), L.ptr(pred.contiguous()), L.ptr(gt.contiguous()), L.ptr(m), L.c_f(scale),
@@ -134,10 +135,10 @@ def l1_loss_raw(pred, gt, mask=None, scale=None, want_grad=True):
     return loss, g
 
 
-def eikonal_loss_raw(gradients, scale=None, want_grad=True):
+def eikonal_loss_raw(gradients, scale=None, want_grad=True, loss=None):
     N = gradients.shape[0]
     scale = 1.0 / max(1, N) if scale is None else float(scale)
-    loss = L.zeroed_scalar(gradients.device)
+    loss = L.zeroed_scalar(gradients.device) if loss is None else loss
     g = torch.empty_like(gradients) if want_grad else None
     L.call("psdf_eikonal_loss", L.c_l(N), L.ptr(gradients.contiguous()), L.c_f(scale), L.ptr(loss), L.ptr(g), L.stream())
     return loss, g

@@ -42,12 +42,19 @@ def _enc_bwd(enc, pts, win, g_fm, want_pos=False, want_lattice=True):
     return g_pos
 
 
-def _enc_dbl_bwd(enc, pts, win, dd_pos, g_fm):
-    """backward of the position gradient: adds to the lattice buffer, returns the gradient w.r.t. the feature gradient [C, N]"""
+def _enc_dbl_gather(enc, pts, win, dd_pos, g_fm):
+    """backward of the position gradient, first half: the gradient w.r.t. the feature gradient [C, N] (a gather)"""
     gg = torch.empty_like(g_fm)
     encode_double_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
-                               dd_pos, g_fm, enc.touched_rows.grad, gg)
+                               dd_pos, g_fm, None, gg)
     return gg
+
+
+def _enc_dbl_scatter(enc, pts, win, dd_pos, g_fm, direct_fm):
+    """second half, together with the plain backward of `direct_fm` (the gradient that reached the features): ONE scatter of both
+    into the lattice buffer -- they land on the same rows of the same simplices"""
+    encode_double_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
+                               dd_pos, g_fm, enc.touched_rows.grad, None, direct_fm)
 
 
 def _normalize3(x, gy=None):
@@ -85,11 +92,12 @@ class ManualTrainer(Trainer):
         """backward of  n = d sdf / d p  for an upstream g_n [N,3]: lattice and parameter gradients are accumulated; returns the
         position gradient when asked (the shifted points of the curvature term depend on n)"""
         enc, dims = self.sdf.encoding, self.sdf.mlp_sdf.dims
-        gg = _enc_dbl_bwd(enc, pts, win, g_n, dfeat)
+        gg = _enc_dbl_gather(enc, pts, win, g_n, dfeat)
         dX2, _, _ = mlp_double_backward(dims, feat, ws, bs, e0, gg, into=(gb.dWs, gb.dbs), module=self.sdf.mlp_sdf)
         if extra_dfeat is not None:
             dX2 = dX2 + extra_dfeat
-        return _enc_bwd(enc, pts, win, dX2, want_pos=want_pos)
+        _enc_dbl_scatter(enc, pts, win, g_n, dfeat, dX2)
+        return _enc_bwd(enc, pts, win, dX2, want_pos=True, want_lattice=False) if want_pos else None
 
     # ------------------------------------------------------------------ one iteration of the main phase
     def _main_phase(self, reel, it, git, eikonal_weight):
@@ -109,9 +117,10 @@ class ManualTrainer(Trainer):
             dims_s = sdfn.mlp_sdf.dims
             win = sdfn.window(it).contiguous()
             packed_s = pack_params(dims_s, ws, bs)
+            # exp(10 v) clipped, as RgbNet.neus_render computes it -- but rounded like torch's float32 exp on the device
             inv_s = torch.exp(torch.tensor(float(forced_variance) * 10.0, device=dev)).clip(1e-6, 1e6).view(1)
             rgbn.last_inv_s = inv_s.view(())
-            loss = torch.zeros((), device=dev)
+            loss = L.zeroed_scalar(dev)     # ONE accumulator: every loss kernel of the step adds its (already weighted) term to it
             # ================================================================= forward
             if n_fg:
                 pts, dirs = fg.samples_pos, fg.samples_dirs
@@ -184,13 +193,11 @@ class ManualTrainer(Trainer):
             pred_bg = VR.integrate_with_weights(bg, rgbb, w_b)
             pred = pred_fg + bgT * pred_bg
             # ---- losses (forward values; their gradients are produced by the same launches)
-            l_rgb, g_pred = l1_loss_raw(pred, gt, hit)
-            loss = loss + l_rgb.view(())
+            _, g_pred = l1_loss_raw(pred, gt, hit, loss=loss)
             g_n = None
             curv = None
             if n_fg:
-                l_e, g_n = eikonal_loss_raw(n, scale=eikonal_weight / n_fg)
-                loss = loss + l_e.view(())
+                _, g_n = eikonal_loss_raw(n, scale=eikonal_weight / n_fg, loss=loss)
                 gw = map_range_val(it, hp.iter_start_reduce_curv, hp.iter_finish_reduce_curv, 1.0, 0.0)
                 if gw > 0.0:
                     rnd = torch.randn_like(pts)
@@ -199,20 +206,16 @@ class ManualTrainer(Trainer):
                            L.stream())
                     feat_s = _enc_fwd(sdfn.encoding, shifted, win)
                     n2, dfeat_s, _ = self._sdf_gradient(feat_s, shifted, win, ws, bs)
-                    l_c = L.zeroed_scalar(dev)
                     ga, gb2 = torch.empty_like(n), torch.empty_like(n2)
-                    L.call("psdf_curvature_loss", L.c_l(n_fg), L.ptr(n), L.ptr(n2), L.c_f(hp.curvature_weight * gw / n_fg), L.ptr(l_c),
+                    L.call("psdf_curvature_loss", L.c_l(n_fg), L.ptr(n), L.ptr(n2), L.c_f(hp.curvature_weight * gw / n_fg), L.ptr(loss),
                            L.ptr(ga), L.ptr(gb2), L.stream())
-                    loss = loss + l_c.view(())
                     curv = (rnd, shifted, feat_s, dfeat_s, ga, gb2)
             off = self.sphere.rand_points_inside(1024)
             feat_o = _enc_fwd(sdfn.encoding, off, win)
             y_o = mlp_forward_raw(dims_s, feat_o, packed_s)
-            l_o = L.zeroed_scalar(dev)
             g_so = torch.empty(1024, dtype=torch.float32, device=dev)
-            L.call("psdf_offsurface_loss", L.c_l(1024), L.ptr(y_o[0].contiguous()), L.c_f(1e2), L.c_f(hp.offsurface_weight / 1024.0),
-                   L.ptr(l_o), L.ptr(g_so), L.stream())
-            loss = loss + l_o.view(())
+            L.call("psdf_offsurface_loss", L.c_l(1024), L.ptr(y_o[0]), L.c_f(1e2), L.c_f(hp.offsurface_weight / 1024.0),
+                   L.ptr(loss), L.ptr(g_so), L.stream())
             self._refresh_and_adapt(it, git, n_fg)
 
             # ================================================================= backward
@@ -286,4 +289,4 @@ class ManualTrainer(Trainer):
             for c, g in zip(rgbn.mlp.lipshitz_bound_per_layer, gs):
                 c.grad = g if c.grad is None else c.grad + g
             loss = loss + lb.detach()
-        return loss, n_fg, R, True
+        return loss.view(()), n_fg, R, True

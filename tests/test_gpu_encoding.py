@@ -180,3 +180,25 @@ def test_binned_double_backward_equals_atomic_double_backward(dev, P, F, L_, T, 
     gg_n = torch.full_like(g, float("nan"))
     encode_double_backward_raw(cfg, pts, lat, sf, sh, w, u, g, None, gg_n)
     assert torch.equal(gg_n, gg_a)
+    # the merged scatter (the training step's form): double-backward scatter + plain backward of a second upstream gradient in
+    # one pass, no gathered output == the two operators run one after the other
+    from permuto_sdf_amd.encoding import encode_backward_raw
+    g2 = torch.randn_like(g)
+    gl_m = torch.zeros_like(lat)
+    encode_double_backward_raw(cfg, pts, lat, sf, sh, w, u, g, gl_m, None, g2)
+    gl_s = gl_a.clone()
+    L.call("psdf_encode_backward", *_head(cfg, N), L.ptr(pts), L.ptr(lat), L.ptr(sf), L.ptr(sh), L.ptr(w), *_tail(cfg), L.ptr(g2),
+           L.ptr(gl_s), None, L.stream())
+    scale2 = gl_s.abs().max().item()
+    assert (gl_m - gl_s).abs().max().item() <= 2e-5 * scale2
+    # ... and below the binned plan's threshold (plain kernels, scratch for the unwanted gathered output)
+    n_small = 3000
+    gl_m2, gl_s2 = torch.zeros_like(lat), torch.zeros_like(lat)
+    ps, gs, g2s, us = pts[:n_small].contiguous(), g[:, :n_small].contiguous(), g2[:, :n_small].contiguous(), u[:n_small].contiguous()
+    encode_double_backward_raw(cfg, ps, lat, sf, sh, w, us, gs, gl_m2, None, g2s)
+    gg_tmp = torch.empty_like(gs)
+    L.call("psdf_encode_double_backward", *_head(cfg, n_small), L.ptr(ps), L.ptr(lat), L.ptr(sf), L.ptr(sh), L.ptr(w), *_tail(cfg),
+           L.ptr(us), L.ptr(gs), L.ptr(gl_s2), L.ptr(gg_tmp), L.stream())
+    L.call("psdf_encode_backward", *_head(cfg, n_small), L.ptr(ps), L.ptr(lat), L.ptr(sf), L.ptr(sh), L.ptr(w), *_tail(cfg), L.ptr(g2s),
+           L.ptr(gl_s2), None, L.stream())
+    assert (gl_m2 - gl_s2).abs().max().item() <= 2e-5 * gl_s2.abs().max().item()
