@@ -80,6 +80,18 @@ def step_seed(base_seed, rank, iteration, world=None):
     return (int(base_seed) * 1000003 + int(iteration)) * world + int(rank)
 
 
+def seed_generators(seed, device):
+    """torch.manual_seed(seed) for the two generators a training step draws from -- the CPU default generator and `device`'s --
+    without torch.manual_seed's walk over every device (which, per call, goes through torch.cuda._lazy_call and formats a
+    Python stack trace: ~90 us, twice per step)"""
+    seed = int(seed)
+    torch.default_generator.manual_seed(seed)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        torch.cuda.default_generators[idx].manual_seed(seed)
+
+
 def all_reduce_max_(t):
     """in-place MAX all-reduce of a small tensor (the touched-block byte maps); no-op for one process"""
     if world_size() == 1 or _loopback is not None:      # identical replicas: the maximum over the ranks is the value itself

@@ -473,7 +473,7 @@ class Trainer:
         hp = self.hp
         with torch.no_grad():
             if git % 8 == 0:
-                torch.manual_seed(977 + git)
+                parallel.seed_generators(977 + git, self.dev)
                 centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
                 inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
                 self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it), inv_s.view(1), 1e-4)
@@ -516,7 +516,7 @@ class Trainer:
         n0 = int(hp.nr_iter_sphere_fit) if self.reference_schedule else 0
         in_sphere_init = git < n0
         it = git if in_sphere_init else git - n0                      # iter_nr_for_anneal (permuto_sdf_utils.py:80-88)
-        torch.manual_seed(parallel.step_seed(self._seed, parallel.rank(), git))  # this rank's rays / jitter
+        parallel.seed_generators(parallel.step_seed(self._seed, parallel.rank(), git), self.dev)  # this rank's rays / jitter
         late = (not in_sphere_init) and it >= hp.iter_start_reduce_curv
         for group in self.opt.param_groups:
             if self.reference_schedule:
