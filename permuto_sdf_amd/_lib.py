@@ -63,10 +63,18 @@ def check(status, name):
             else "HIP error code"))
 
 
+_fns = {}
+
+
 def call(name, *args):
-    fn = getattr(lib(), name)
-    fn.restype = ctypes.c_int
-    check(fn(*args), name)
+    fn = _fns.get(name)
+    if fn is None:      # resolved once per entry point (the symbol lookup and the restype assignment cost ~1 us of every call)
+        fn = getattr(lib(), name)
+        fn.restype = ctypes.c_int
+        _fns[name] = fn
+    status = fn(*args)
+    if status != 0:
+        check(status, name)
 
 
 def require_cuda(*tensors):
