@@ -26,7 +26,10 @@ def main(W=512, H=512, levels=24):
     mlp = FusedMLP([enc.output_dims(), 64, 64, 64, 1]).to(dev)
     with torch.no_grad():
         mlp.layers[-1].bias.fill_(0.05)
-    packed = pack_params(mlp.dims, [l.weight for l in mlp.layers], [l.bias for l in mlp.layers])
+    # the hot path's forward arithmetic (hotpath.py): two fp16 pieces per operand for the BASELINE net unless PSDF_MLP_FWD_SPLIT=bf16
+    from permuto_sdf_amd.mlp import f16_forward_supported
+    f16 = os.environ.get("PSDF_MLP_FWD_SPLIT", "f16") != "bf16" and f16_forward_supported(mlp.dims)
+    packed = pack_params(mlp.dims, [l.weight for l in mlp.layers], [l.bias for l in mlp.layers], f16=f16)
     win = torch.ones(levels, device=dev)
     grid = OccupancyGrid(256, 1.0, [0, 0, 0])
     c = grid.compute_grid_points(False)
@@ -43,7 +46,7 @@ def main(W=512, H=512, levels=24):
         M = rs.samples_pos.shape[0]
         feat = encode_forward_raw(enc.cfg, rs.samples_pos, enc.lattice_values.detach(), enc.scale_factor,
                                   enc.random_shift_per_level.detach(), win)
-        sdf = mlp_forward_raw(mlp.dims, feat, packed)
+        sdf = mlp_forward_raw(mlp.dims, feat, packed, f16=f16)
         alpha = VolumeRendering.sdf2alpha(rs, sdf.view(-1, 1), 512.0, True, 1.0)
         T, _ = VolumeRendering.cumprod_alpha2transmittance(rs, 1.0 - alpha + 1e-7)
         w = alpha * T
@@ -72,7 +75,8 @@ def main(W=512, H=512, levels=24):
         ms = (time.perf_counter() - t0) * 200
         res[name] = {"ms_per_image": round(ms, 3), "samples": tot, "Msamples_per_s": round(tot / ms / 1e3, 1),
                      "Mrays_per_s": round(W * H / ms / 1e3, 2)}
-    print(json.dumps({"cfg": 3, "image": "%dx%d" % (W, H), "L": levels, "net": "-".join(map(str, mlp.dims)), **res}))
+    print(json.dumps({"cfg": 3, "image": "%dx%d" % (W, H), "L": levels, "net": "-".join(map(str, mlp.dims)),
+                      "mlp_forward": "two fp16 pieces" if f16 else "three bf16 pieces", **res}))
 
 
 if __name__ == "__main__":
