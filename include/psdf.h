@@ -165,6 +165,10 @@ int psdf_eikonal_loss(int64_t N, const float* gradients, float scale, float* los
 /* replaces: F.normalize(x, dim=-1) and its autograd backward (torch), used on the SDF gradients at
    permuto_sdf_py/models/models.py:272,280,367: grad_y == NULL -> out = x / max(|x|, 1e-12); else out = d/dx applied to grad_y */
 int psdf_normalize3(int64_t N, const float* x, const float* grad_y, float* out, void* stream);
+/* sigmoid at the end of the colour heads (models.py:386,525), fused with the layout change the compositing operators need:
+   y [N, C] = sigmoid(x_fm [C, N]);  grad_x_fm [C, N] = grad_y [N, C] * y * (1 - y);  C <= 16 */
+int psdf_sigmoid_rows(int64_t N, int C, const float* x_fm, float* y, void* stream);
+int psdf_sigmoid_rows_backward(int64_t N, int C, const float* grad_y, const float* y, float* grad_x_fm, void* stream);
 /* replaces: the shifted points of the curvature loss, models.py:266-277: out = points + epsilon * cross(normalize(gradients),
    normalize(rand_directions)) (grad_shifted == NULL), or the gradient of that w.r.t. `gradients` applied to grad_shifted */
 int psdf_curvature_shift(int64_t N, const float* points, const float* gradients, const float* rand_directions, float

@@ -141,7 +141,9 @@ class RaySamplesPacked:
                 bad = se[:, 1] > n
                 out.ray_start_end_idx = torch.where(bad[:, None], torch.zeros_like(se), se)
                 out.ray_fixed_dt = torch.where(bad[:, None], torch.zeros_like(self.ray_fixed_dt), self.ray_fixed_dt)
-            out.cur_nr_samples = torch.full((1,), n, dtype=torch.int32, device=self.samples_pos.device)
+            # (the producer's counter IS the count unless the pool overflowed: no new tensor, no fill launch)
+            out.cur_nr_samples = (self.cur_nr_samples if n == cur else
+                                  torch.full((1,), n, dtype=torch.int32, device=self.samples_pos.device))
             out._exact = True
             out._dense = cur <= self.max_nr_samples     # (an overflowing pool leaves slots of dropped rays behind)
             return out

@@ -153,6 +153,24 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
 }
 
+// The colour heads end in a sigmoid applied to a 3-row feature-major MLP output that the compositing kernels want as [N, 3]:
+// forward  y[n][c] = sigmoid(x_fm[c][n])            (transpose + sigmoid in one pass instead of a copy and an elementwise launch)
+// backward out_fm[c][n] = g[n][c] y[n][c] (1 - y[n][c])   (three elementwise launches and a transposing copy otherwise)
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    sigmoid_rows_kernel(int64_t N, int C, const float* __restrict__ x_fm, const float* __restrict__ g, const float* __restrict__ y,
+                        float* __restrict__ out) {
+  for (int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x; n < N; n += (int64_t)gridDim.x * PSDF_BLOCK) {
+    for (int c = 0; c < C; c++) {
+      if (x_fm) {
+        out[n * C + c] = 1.0f / (1.0f + expf(-x_fm[(int64_t)c * N + n]));
+      } else {
+        const float yv = y[n * C + c];
+        out[(int64_t)c * N + n] = g[n * C + c] * yv * (1.0f - yv);
+      }
+    }
+  }
+}
+
 // forward (g_shifted == NULL): out = points + eps * cross(normalize(g), normalize(rnd));  backward: out = d / d g applied
 // to g_shifted (points and rnd carry no gradient)
 __global__ void __launch_bounds__(PSDF_BLOCK)
@@ -283,6 +301,24 @@ int psdf_normalize3(int64_t N, const float* x, const float* grad_y, float* out, 
   if (N == 0) return PSDF_OK;
   if (N < 0 || !x || !out) return PSDF_ERR_ARG;
   hipLaunchKernelGGL(normalize3_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, x, grad_y, out);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_sigmoid_rows(int64_t N, int C, const float* x_fm, float* y, void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || C < 1 || C > 16 || !x_fm || !y) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(sigmoid_rows_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, C, x_fm,
+                     (const float*)nullptr, (const float*)nullptr, y);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+int psdf_sigmoid_rows_backward(int64_t N, int C, const float* grad_y, const float* y, float* grad_x_fm, void* stream) {
+  if (N == 0) return PSDF_OK;
+  if (N < 0 || C < 1 || C > 16 || !grad_y || !y || !grad_x_fm) return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(sigmoid_rows_kernel, dim3(stream_grid(N)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, N, C,
+                     (const float*)nullptr, grad_y, y, grad_x_fm);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

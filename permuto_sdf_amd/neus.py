@@ -307,3 +307,19 @@ def nerf_alpha(raw_density, dt):
     """alpha = 1 - exp(-softplus(raw_density) * dt) and 1 - alpha + 1e-7 (shaped like raw_density) -- NerfHash's density activation
     (models.py:520) followed by VolumeRenderingNerf.compute_weights' first lines (volume_rendering_modules.py:72-86)"""
     return _NerfAlpha.apply(raw_density, dt)
+
+
+def sigmoid_rows_raw(x_fm):
+    """[C, N] feature-major MLP output -> sigmoid as [N, C] (one launch: transpose + sigmoid)"""
+    C, N = x_fm.shape
+    y = torch.empty((N, C), dtype=torch.float32, device=x_fm.device)
+    L.call("psdf_sigmoid_rows", L.c_l(N), L.c_i(C), L.ptr(x_fm), L.ptr(y), L.stream())
+    return y
+
+
+def sigmoid_rows_backward_raw(g_y, y):
+    """gradient w.r.t. the feature-major pre-activation [C, N] from dL/dy [N, C] and y = sigmoid(.) [N, C]"""
+    N, C = y.shape
+    g = torch.empty((C, N), dtype=torch.float32, device=y.device)
+    L.call("psdf_sigmoid_rows_backward", L.c_l(N), L.c_i(C), L.ptr(g_y.contiguous()), L.ptr(y), L.ptr(g), L.stream())
+    return g

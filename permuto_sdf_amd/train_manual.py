@@ -24,7 +24,8 @@ from . import _lib as L
 from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
 from .encoding import encode_backward_raw, encode_double_backward_raw, encode_forward_raw
 from .mlp import mlp_backward_raw, mlp_double_backward, mlp_forward_raw, pack_params
-from .neus import eikonal_loss_raw, l1_loss_raw, neus_composite_backward_raw, neus_composite_forward_raw
+from .neus import (eikonal_loss_raw, l1_loss_raw, neus_composite_backward_raw, neus_composite_forward_raw, sigmoid_rows_backward_raw,
+                   sigmoid_rows_raw)
 from .train_step import Trainer, map_range_val
 
 
@@ -141,17 +142,17 @@ class ManualTrainer(Trainer):
                            L.ptr(o_), L.stream())
                     wn.append(o_)
                 bsr = [b.detach() for b in m.biases_per_layer]
-                rgb_raw = mlp_forward_raw(m.dims, x_rgb, pack_params(m.dims, wn, bsr)).t().contiguous()        # [N, 3]
+                rgb_fm = mlp_forward_raw(m.dims, x_rgb, pack_params(m.dims, wn, bsr))                            # [3, N]
                 if cc is not None:
+                    rgb_raw = rgb_fm.t().contiguous()                                                            # [N, 3]
                     ridx_fg = RaySamplesPacked.compute_per_sample_ray_idx(fg.ray_start_end_idx, n_fg).long()
                     cam = img_idx.long()
                     fixed = (cam == cc.idx_with_fixed_calib)[:, None]
                     cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
                     cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
-                    rgb_pre = rgb_raw * cw.index_select(0, ridx_fg) + cb.index_select(0, ridx_fg)
+                    rgb = torch.sigmoid(rgb_raw * cw.index_select(0, ridx_fg) + cb.index_select(0, ridx_fg))
                 else:
-                    rgb_pre = rgb_raw
-                rgb = torch.sigmoid(rgb_pre)
+                    rgb = sigmoid_rows_raw(rgb_fm)
                 per_ray = hp.max_nr_samples_per_ray + 2 * hp.nr_samples_imp_sampling
                 sdf_col = y[0].view(-1, 1)
                 pred_fg, bgT, _ = neus_composite_forward_raw(fg, sdf_col, n, rgb, inv_s, cos_r)
@@ -172,18 +173,18 @@ class ManualTrainer(Trainer):
             l2b = list(bgn.mlp_rgb.layers)
             w2b, b2b = [l.weight for l in l2b], [l.bias for l in l2b]
             d2 = bgn.mlp_rgb.dims
-            rgbb_raw = mlp_forward_raw(d2, x2, pack_params(d2, w2b, b2b)).t().contiguous()    # [M, 3]
+            rgbb_fm = mlp_forward_raw(d2, x2, pack_params(d2, w2b, b2b))                      # [3, M]
             if cc is not None:
+                rgbb_raw = rgbb_fm.t().contiguous()                                           # [M, 3]
                 ridx_bg = RaySamplesPacked.compute_per_sample_ray_idx(bg.ray_start_end_idx, M).long()
                 if not n_fg:
                     cam = img_idx.long()
                     fixed = (cam == cc.idx_with_fixed_calib)[:, None]
                     cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
                     cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
-                rgbb_pre = rgbb_raw * cw.index_select(0, ridx_bg) + cb.index_select(0, ridx_bg)
+                rgbb = torch.sigmoid(rgbb_raw * cw.index_select(0, ridx_bg) + cb.index_select(0, ridx_bg))
             else:
-                rgbb_pre = rgbb_raw
-            rgbb = torch.sigmoid(rgbb_pre)
+                rgbb = sigmoid_rows_raw(rgbb_fm)
             raw_den = fd[0].contiguous()
             dt_b = bg.samples_dt.reshape(-1).contiguous()
             alpha_b, om_b = torch.empty_like(raw_den), torch.empty_like(raw_den)
@@ -231,13 +232,15 @@ class ManualTrainer(Trainer):
             g_raw = torch.empty_like(raw_den)
             L.call("psdf_nerf_alpha_backward", L.c_l(M), L.ptr(raw_den), L.ptr(dt_b), L.ptr(g_alb.reshape(-1).contiguous()),
                    L.ptr(g_omb.reshape(-1).contiguous()), L.ptr(g_raw), L.stream())
-            g_pre_b = g_rgbb * rgbb * (1.0 - rgbb)                                            # sigmoid
             g_cw = g_cb = None
             if cc is not None:
+                g_pre_b = g_rgbb * rgbb * (1.0 - rgbb)                                        # sigmoid
                 g_cb = torch.zeros(R, 3, device=dev).index_add_(0, ridx_bg, g_pre_b)
                 g_cw = torch.zeros(R, 3, device=dev).index_add_(0, ridx_bg, g_pre_b * rgbb_raw)
-                g_pre_b = g_pre_b * cw.index_select(0, ridx_bg)
-            dX2b, dW2b, db2b = mlp_backward_raw(d2, x2, w2b, b2b, g_pre_b.t().contiguous(), need_dx=True)
+                g_pre_b_fm = (g_pre_b * cw.index_select(0, ridx_bg)).t().contiguous()
+            else:
+                g_pre_b_fm = sigmoid_rows_backward_raw(g_rgbb, rgbb)                          # [3, M], one launch
+            dX2b, dW2b, db2b = mlp_backward_raw(d2, x2, w2b, b2b, g_pre_b_fm, need_dx=True)
             _set_grads(l2b, dW2b, db2b)
             g_fd = torch.cat([g_raw.view(1, -1), torch.ops.aten.gelu_backward(dX2b[:64], fd[1:65])], 0)      # [65, M]
             dX4, dW1b, db1b = mlp_backward_raw(d1, feat4, w1b, b1b, g_fd, need_dx=True)
@@ -247,12 +250,14 @@ class ManualTrainer(Trainer):
             if n_fg:
                 g_sdf, g_nc, g_rgb, _ = neus_composite_backward_raw(fg, per_ray, g_pred.contiguous(), g_bgT.contiguous(), sdf_col, n,
                                                                     rgb, inv_s, cos_r, need_grad=True, need_rgb=True, need_inv_s=False)
-                g_pre = g_rgb * rgb * (1.0 - rgb)
                 if cc is not None:
+                    g_pre = g_rgb * rgb * (1.0 - rgb)
                     g_cb.index_add_(0, ridx_fg, g_pre)
                     g_cw.index_add_(0, ridx_fg, g_pre * rgb_raw)
-                    g_pre = g_pre * cw.index_select(0, ridx_fg)
-                dXr, dWn, dbr = mlp_backward_raw(m.dims, x_rgb, wn, bsr, g_pre.t().contiguous(), need_dx=True)
+                    g_pre_fm = (g_pre * cw.index_select(0, ridx_fg)).t().contiguous()
+                else:
+                    g_pre_fm = sigmoid_rows_backward_raw(g_rgb, rgb)
+                dXr, dWn, dbr = mlp_backward_raw(m.dims, x_rgb, wn, bsr, g_pre_fm, need_dx=True)
                 for i, (w, c) in enumerate(zip(m.weights_per_layer, m.lipshitz_bound_per_layer)):
                     dw = torch.empty_like(w)
                     dc = torch.zeros_like(c)

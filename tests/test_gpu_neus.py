@@ -272,3 +272,17 @@ def test_fused_compositing_equals_the_operator_chain_and_the_oracle(dev, mode):
     from permuto_sdf_amd._lib import PsdfError
     with pytest.raises(PsdfError):
         neus_composite_backward_raw(rs, 300, g_pred, g_bg, sdf_d, grad_d, rgb_d, inv_s, ratio)
+
+
+@pytest.mark.parametrize("N,C", [(1, 3), (5000, 3), (70001, 4)])
+def test_sigmoid_rows_and_backward(dev, N, C):
+    """psdf_sigmoid_rows / _backward (the colour heads' sigmoid fused with the [C, N] <-> [N, C] layout change) against torch"""
+    from permuto_sdf_amd.neus import sigmoid_rows_backward_raw, sigmoid_rows_raw
+    torch.manual_seed(N)
+    x = torch.randn(C, N, device=dev) * 4
+    y = sigmoid_rows_raw(x)
+    ref = torch.sigmoid(x.t())
+    assert y.shape == (N, C) and float((y - ref).abs().max()) <= 2e-7
+    g = torch.randn(N, C, device=dev)
+    gx = sigmoid_rows_backward_raw(g, y)
+    assert gx.shape == (C, N) and float((gx - (g * y * (1 - y)).t()).abs().max()) <= 1e-7 * float(g.abs().max())
