@@ -102,6 +102,20 @@ int psdf_neus_composite_backward(int nr_rays, const int* start_end, int equal, i
     const float* rgb, const float* inv_s, float cos_anneal_ratio, int reference_compat, float* grad_sdf, float* grad_gradients,
     float* grad_rgb, float* grad_inv_s, void* stream);
 
+/* Background NeRF (NerfHash + VolumeRenderingNerf.compute_weights + integrate: models.py:520, volume_rendering_modules.py:72-86,
+   176-190) and the composition with the foreground (train_permuto_sdf.py:160-165), one launch per direction:
+   density = softplus(raw_density); alpha = 1 - exp(-density dt); T = exclusive cumprod(1 - alpha + 1e-7); w = alpha T;
+   pred_bg [R,3] = sum w rgb; with fg_pred [R,3] and fg_bg [R] (both or neither) also pred [R,3] = fg_pred + fg_bg * pred_bg. */
+int psdf_nerf_composite_forward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float* raw_density,
+                                const float* dt, const float* rgb, const float* fg_pred, const float* fg_bg, float* pred_bg,
+                                float* pred, void* stream);
+/* its backward for grad_pred [R,3] (of the composed radiance when fg_bg is given, else of pred_bg): grad_raw_density [M], grad_rgb
+   [M,3], optional grad_fg_bg [R] = <grad_pred, pred_bg>; rays of at most max_per_ray <= 256 samples (-2 beyond) */
+int psdf_nerf_composite_backward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, int max_per_ray,
+                                 const float* grad_pred, const float* fg_bg, const float* raw_density, const float* dt,
+                                 const float* rgb, int reference_compat, float* grad_raw_density, float* grad_rgb,
+                                 float* grad_fg_bg, void* stream);
+
 /* ---- debug query (mlp_bwd.hip) ---- */
 /* Which kernel variant the LAST call of an operator family dispatched to (host only, no device work): lets a parity test
    assert that the configuration it compares with the oracle ran the kernels the benchmark times.  No reference counterpart.

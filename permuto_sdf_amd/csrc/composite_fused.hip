@@ -185,9 +185,190 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
 }
 
+// ------------------------------------------------------------------------------------------------ background NeRF
+// NerfHash + VolumeRenderingNerf.compute_weights + integrate (models.py:520, volume_rendering_modules.py:72-86,176-190) and the
+// composition with the foreground (train_permuto_sdf.py:160-165, pred = pred_fg + bg_transmittance_fg * pred_bg), one launch
+// per direction: density = softplus(raw) -> alpha = 1 - exp(-density dt) -> 1 - alpha + 1e-7 -> exclusive product scan ->
+// w = alpha T -> sum w rgb.  The expressions and scan orders of nerf_alpha_kernel (neus.hip), cumprod_fwd_kernel,
+// integrate_fwd_kernel; the backward mirrors neus_composite_bwd_kernel with the NeRF opacity in the place of the NeuS one.
+__device__ __forceinline__ float softplus20c(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    nerf_composite_fwd_kernel(int nr_rays, RayIndex ri, const float* __restrict__ raw, const float* __restrict__ dt,
+                              const float* __restrict__ rgb, const float* __restrict__ fg_pred, const float* __restrict__ fg_bg,
+                              float* __restrict__ pred_bg, float* __restrict__ pred) {
+  const int lane = lane_id();
+  RAY_LOOP(ray, nr_rays) {
+    int s, e;
+    ri.get(ray, s, e);
+    float r = 0.f, g = 0.f, b = 0.f;
+    if (ri.valid(s, e)) {
+      const int n = e - s;
+      float carry = 1.f;
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool in = i < n;
+        const int64_t m = s + (in ? i : n - 1);
+        const float a = 1.0f - expf(-softplus20c(raw[m]) * dt[m]);
+        const float om = (1.0f - a) + 1e-7f;
+        const float fac = (i < n - 1) ? om : 1.f;
+        const float incl = wave_incl_scan_mul(fac);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        carry = carry * __shfl(incl, 63, 64);
+        if (in) {
+          const float w = a * T;
+          r += w * rgb[3 * m];
+          g += w * rgb[3 * m + 1];
+          b += w * rgb[3 * m + 2];
+        }
+      }
+      r = wave_sum(r);
+      g = wave_sum(g);
+      b = wave_sum(b);
+    }
+    if (lane == 0) {
+      pred_bg[3 * ray] = r;
+      pred_bg[3 * ray + 1] = g;
+      pred_bg[3 * ray + 2] = b;
+      if (pred) {
+        const float t = fg_bg[ray];
+        pred[3 * ray] = fg_pred[3 * ray] + t * r;
+        pred[3 * ray + 1] = fg_pred[3 * ray + 1] + t * g;
+        pred[3 * ray + 2] = fg_pred[3 * ray + 2] + t * b;
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    nerf_composite_bwd_kernel(int nr_rays, RayIndex ri, const float* __restrict__ g_pred, const float* __restrict__ fg_bg,
+                              const float* __restrict__ raw, const float* __restrict__ dt, const float* __restrict__ rgb,
+                              int compat, float* __restrict__ g_raw, float* __restrict__ g_rgb, float* __restrict__ g_fg_bg) {
+  const int lane = lane_id();
+  RAY_LOOP(ray, nr_rays) {
+    int s, e;
+    ri.get(ray, s, e);
+    const float t = fg_bg ? fg_bg[ray] : 1.f;
+    const float ux = g_pred[3 * ray], uy = g_pred[3 * ray + 1], uz = g_pred[3 * ray + 2];   // dL/d pred
+    if (!ri.valid(s, e)) {
+      if (g_fg_bg && lane == 0) g_fg_bg[ray] = 0.f;
+      continue;
+    }
+    const int n = e - s;
+    const float gx = t * ux, gy = t * uy, gz = t * uz;                                       // dL/d pred_bg
+    float a_[K], T_[K], gw_[K], v_[K], e_[K];
+    float carry = 1.f, pr = 0.f, pg = 0.f, pb = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const int i = 64 * k + lane;
+      const bool in = i < n;
+      const int64_t m = s + (in ? i : n - 1);
+      a_[k] = T_[k] = gw_[k] = v_[k] = e_[k] = 0.f;
+      if (64 * k < n) {     // wave-uniform
+        const float ex = expf(-softplus20c(raw[m]) * dt[m]);
+        const float a = 1.0f - ex;
+        const float om = (1.0f - a) + 1e-7f;
+        const float fac = (i < n - 1) ? om : 1.f;
+        const float incl = wave_incl_scan_mul(fac);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.f;
+        const float T = carry * excl;
+        carry = carry * __shfl(incl, 63, 64);
+        if (in) {
+          const float cx = rgb[3 * m], cy = rgb[3 * m + 1], cz_true = rgb[3 * m + 2];
+          const float cz = compat ? cy : cz_true;
+          const float w = a * T;
+          pr += w * cx;
+          pg += w * cy;
+          pb += w * cz_true;
+          const float gw = gx * cx + gy * cy + gz * cz;
+          g_rgb[3 * m] = gx * w;
+          g_rgb[3 * m + 1] = gy * w;
+          g_rgb[3 * m + 2] = gz * w;
+          a_[k] = a;
+          T_[k] = T;
+          gw_[k] = gw;
+          e_[k] = ex;
+          v_[k] = (gw * a) * T;
+        }
+      }
+    }
+    if (g_fg_bg) {   // dL/d (foreground bg transmittance) = <dL/d pred, pred_bg>
+      pr = wave_sum(pr);
+      pg = wave_sum(pg);
+      pb = wave_sum(pb);
+      if (lane == 0) g_fg_bg[ray] = (ux * pr + uy * pg) + uz * pb;
+    }
+    float tail = 0.f;
+#pragma unroll
+    for (int k = K - 1; k >= 0; k--) {
+      if (64 * k >= n) continue;       // wave-uniform
+      const int i = 64 * k + lane;
+      const bool in = i < n;
+      const int64_t m = s + (in ? i : n - 1);
+      const float suf = wave_incl_suffix_add(v_[k]) + tail;
+      float cs_next = __shfl_down(suf, 1, 64);
+      if (lane == 63) cs_next = tail;
+      tail = __shfl(suf, 0, 64);
+      if (in) {
+        float g_om = 0.f;
+        if (i < n - 1) g_om = cs_next / fmaxf((1.0f - a_[k]) + 1e-7f, 1e-6f);
+        const float g_alpha = gw_[k] * T_[k] - g_om;                 // alpha enters as w = alpha T and as 1 - alpha + 1e-7
+        const float x = raw[m];
+        const float g_dens = g_alpha * e_[k] * dt[m];                // alpha = 1 - exp(-dens dt)
+        g_raw[m] = g_dens * (x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x)));
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// Background NeRF rendering + composition with the foreground in one launch per direction (see the kernels): raw_density [M],
+// dt [M], rgb [M,3] of the background container; fg_pred [R,3] / fg_bg [R] (both or neither): pred [R,3] = fg_pred + fg_bg *
+// pred_bg; pred_bg [R,3] always written (zeros for empty rays).
+int psdf_nerf_composite_forward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float* raw_density,
+                                const float* dt, const float* rgb, const float* fg_pred, const float* fg_bg, float* pred_bg,
+                                float* pred, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  if (!raw_density || !dt || !rgb || !pred_bg || (!equal && !start_end) || ((fg_pred || fg_bg || pred) && !(fg_pred && fg_bg && pred)))
+    return PSDF_ERR_ARG;
+  hipLaunchKernelGGL(nerf_composite_fwd_kernel, dim3(ray_grid(nr_rays)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, nr_rays,
+                     RayIndex{start_end, equal, fixed, max_nr_samples}, raw_density, dt, rgb, fg_pred, fg_bg, pred_bg, pred);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// Backward for dL/d pred [R,3] (of the COMPOSED radiance when fg_bg is given, else of pred_bg): grad_raw_density [M], grad_rgb
+// [M,3], and (optional, with fg_bg) grad_fg_bg [R] = <dL/d pred, pred_bg>.  max_per_ray as in psdf_neus_composite_backward.
+int psdf_nerf_composite_backward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, int max_per_ray,
+                                 const float* grad_pred, const float* fg_bg, const float* raw_density, const float* dt,
+                                 const float* rgb, int reference_compat, float* grad_raw_density, float* grad_rgb,
+                                 float* grad_fg_bg, void* stream) {
+  if (nr_rays <= 0) return PSDF_OK;
+  if (!grad_pred || !raw_density || !dt || !rgb || !grad_raw_density || !grad_rgb || (!equal && !start_end) || max_per_ray < 1)
+    return PSDF_ERR_ARG;
+  if (max_per_ray > 256) return PSDF_ERR_UNSUPPORTED;
+  const RayIndex ri{start_end, equal, fixed, max_nr_samples};
+#define GO(K_)                                                                                                          \
+  hipLaunchKernelGGL(nerf_composite_bwd_kernel<K_>, dim3(ray_grid(nr_rays)), dim3(PSDF_BLOCK), 0, (hipStream_t)stream,  \
+                     nr_rays, ri, grad_pred, fg_bg, raw_density, dt, rgb, reference_compat, grad_raw_density, grad_rgb, \
+                     grad_fg_bg)
+  if (max_per_ray <= 64)
+    GO(1);
+  else if (max_per_ray <= 128)
+    GO(2);
+  else
+    GO(4);
+#undef GO
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
 
 // pred [R,3] (rows of invalid / empty rays keep their contents: pass zeros), bg [R] optional (bg transmittance; pass ones),
 // weights [N] optional (alpha T per sample).  Ray-index arguments as everywhere (include/psdf.h).

@@ -323,3 +323,29 @@ def sigmoid_rows_backward_raw(g_y, y):
     g = torch.empty((C, N), dtype=torch.float32, device=y.device)
     L.call("psdf_sigmoid_rows_backward", L.c_l(N), L.c_i(C), L.ptr(g_y.contiguous()), L.ptr(y), L.ptr(g), L.stream())
     return g
+
+
+def nerf_composite_forward_raw(rs, raw_density, rgb, fg_pred=None, fg_bg=None):
+    """csrc/composite_fused.hip: softplus density -> opacity -> transmittance -> weights -> radiance of the background container,
+    and (given the foreground's radiance [R,3] and bg transmittance [R,1]) the composed radiance, in one launch.
+    -> (pred_bg [R,3], pred [R,3] or None)"""
+    R, dev = rs.ray_start_end_idx.shape[0], raw_density.device
+    pred_bg = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    pred = torch.empty((R, 3), dtype=torch.float32, device=dev) if fg_pred is not None else None
+    L.call("psdf_nerf_composite_forward", *rs._ri(), L.ptr(raw_density), L.ptr(rs.samples_dt), L.ptr(rgb), L.ptr(fg_pred), L.ptr(fg_bg),
+           L.ptr(pred_bg), L.ptr(pred), L.stream())
+    return pred_bg, pred
+
+
+def nerf_composite_backward_raw(rs, max_per_ray, g_pred, raw_density, rgb, fg_bg=None):
+    """-> (g_raw_density [M], g_rgb [M,3], g_fg_bg [R,1] or None) for dL/d pred [R,3] of the composed radiance (fg_bg given) or of
+    the background radiance alone"""
+    from .bridge import VolumeRendering, _per_sample
+    M, R, dev = raw_density.shape[0], rs.ray_start_end_idx.shape[0], raw_density.device
+    g_raw = _per_sample(rs, (M,), dev)
+    g_rgb = _per_sample(rs, (M, 3), dev)
+    g_fg = torch.empty((R, 1), dtype=torch.float32, device=dev) if fg_bg is not None else None
+    L.call("psdf_nerf_composite_backward", *rs._ri(), L.c_i(int(max_per_ray)), L.ptr(g_pred), L.ptr(fg_bg), L.ptr(raw_density),
+           L.ptr(rs.samples_dt), L.ptr(rgb), L.c_i(int(VolumeRendering.reference_compat)), L.ptr(g_raw), L.ptr(g_rgb), L.ptr(g_fg),
+           L.stream())
+    return g_raw, g_rgb, g_fg

@@ -24,8 +24,8 @@ from . import _lib as L
 from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
 from .encoding import encode_backward_raw, encode_double_backward_raw, encode_forward_raw
 from .mlp import mlp_backward_raw, mlp_double_backward, mlp_forward_raw, pack_params
-from .neus import (eikonal_loss_raw, l1_loss_raw, neus_composite_backward_raw, neus_composite_forward_raw, sigmoid_rows_backward_raw,
-                   sigmoid_rows_raw)
+from .neus import (eikonal_loss_raw, l1_loss_raw, nerf_composite_backward_raw, nerf_composite_forward_raw, neus_composite_backward_raw,
+                   neus_composite_forward_raw, sigmoid_rows_backward_raw, sigmoid_rows_raw)
 from .train_step import Trainer, map_range_val
 
 
@@ -185,14 +185,9 @@ class ManualTrainer(Trainer):
                 rgbb = torch.sigmoid(rgbb_raw * cw.index_select(0, ridx_bg) + cb.index_select(0, ridx_bg))
             else:
                 rgbb = sigmoid_rows_raw(rgbb_fm)
-            raw_den = fd[0].contiguous()
-            dt_b = bg.samples_dt.reshape(-1).contiguous()
-            alpha_b, om_b = torch.empty_like(raw_den), torch.empty_like(raw_den)
-            L.call("psdf_nerf_alpha_forward", L.c_l(M), L.ptr(raw_den), L.ptr(dt_b), L.ptr(alpha_b), L.ptr(om_b), L.stream())
-            T_b, bgT_b = VR.cumprod_alpha2transmittance(bg, om_b.view(-1, 1))
-            w_b = alpha_b.view(-1, 1) * T_b
-            pred_bg = VR.integrate_with_weights(bg, rgbb, w_b)
-            pred = pred_fg + bgT * pred_bg
+            raw_den = fd[0]                                                                   # [M], a row of the feature-major output
+            # softplus -> opacity -> transmittance -> weights -> background radiance -> pred = pred_fg + bgT * pred_bg: one launch
+            _, pred = nerf_composite_forward_raw(bg, raw_den, rgbb, pred_fg, bgT)
             # ---- losses (forward values; their gradients are produced by the same launches)
             _, g_pred = l1_loss_raw(pred, gt, hit, loss=loss)
             g_n = None
@@ -220,18 +215,8 @@ class ManualTrainer(Trainer):
             self._refresh_and_adapt(it, git, n_fg)
 
             # ================================================================= backward
-            # pred = pred_fg + bgT * pred_bg
-            g_bgT = (g_pred * pred_bg).sum(1, keepdim=True)
-            g_pred_bg = bgT * g_pred
-            # ---- background branch
-            g_rgbb, g_wb = VR.integrate_with_weights_backward(g_pred_bg, bg, rgbb, w_b, None)
-            g_Tb = g_wb * alpha_b.view(-1, 1)
-            cs = VR.cumsum_over_each_ray(bg, g_Tb * T_b, True)
-            g_omb = VR.cumprod_alpha2transmittance_backward(g_Tb, torch.zeros_like(bgT_b), bg, om_b.view(-1, 1), T_b, bgT_b, cs)
-            g_alb = g_wb * T_b
-            g_raw = torch.empty_like(raw_den)
-            L.call("psdf_nerf_alpha_backward", L.c_l(M), L.ptr(raw_den), L.ptr(dt_b), L.ptr(g_alb.reshape(-1).contiguous()),
-                   L.ptr(g_omb.reshape(-1).contiguous()), L.ptr(g_raw), L.stream())
+            # pred = pred_fg + bgT * pred_bg and the whole background compositing, one launch
+            g_raw, g_rgbb, g_bgT = nerf_composite_backward_raw(bg, hp.nr_samples_bg, g_pred, raw_den, rgbb, bgT)
             g_cw = g_cb = None
             if cc is not None:
                 g_pre_b = g_rgbb * rgbb * (1.0 - rgbb)                                        # sigmoid

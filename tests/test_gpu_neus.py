@@ -286,3 +286,67 @@ def test_sigmoid_rows_and_backward(dev, N, C):
     g = torch.randn(N, C, device=dev)
     gx = sigmoid_rows_backward_raw(g, y)
     assert gx.shape == (C, N) and float((gx - (g * y * (1 - y)).t()).abs().max()) <= 1e-7 * float(g.abs().max())
+
+
+@pytest.mark.parametrize("layout", ["equal32", "packed"])
+def test_nerf_composite_equals_the_operator_chain(dev, layout):
+    """psdf_nerf_composite_forward / _backward (background NeRF rendering + composition with the foreground, one launch per
+    direction) against the chain of operators they replace: nerf_alpha -> cumprod_alpha2transmittance -> alpha * T ->
+    integrate_with_weights -> pred_fg + bgT * pred_bg, and its backward through the reference's autograd Functions' kernels."""
+    from permuto_sdf import RaySamplesPacked, VolumeRendering as VR
+    from permuto_sdf_amd import _lib as L
+    from permuto_sdf_amd.neus import nerf_composite_backward_raw, nerf_composite_forward_raw
+    torch.manual_seed(5)
+    R = 300
+    if layout == "equal32":
+        counts = torch.full((R,), 32, dtype=torch.int64)
+    else:
+        counts = torch.randint(0, 150, (R,))
+        counts[:3] = torch.tensor([0, 1, 2])
+    start = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)])
+    M = int(start[-1])
+    rs = RaySamplesPacked(R, M)
+    rs.ray_start_end_idx = torch.stack([start[:-1], start[1:]], 1).to(torch.int32).to(dev)
+    if layout == "equal32":
+        rs.rays_have_equal_nr_of_samples, rs.fixed_nr_of_samples_per_ray = True, 32
+    rs.samples_dt = (torch.rand(M, 1, device=dev) * 0.05 + 1e-3)
+    rs.cur_nr_samples.fill_(M)
+    rs._exact = True
+    rs._dense = True
+    raw = torch.randn(M, device=dev) * 3
+    rgb = torch.rand(M, 3, device=dev)
+    fg_pred, fg_bg = torch.rand(R, 3, device=dev), torch.rand(R, 1, device=dev)
+    g_pred = torch.randn(R, 3, device=dev)
+
+    def chain():
+        dtv = rs.samples_dt.reshape(-1).contiguous()
+        alpha, om = torch.empty_like(raw), torch.empty_like(raw)
+        L.call("psdf_nerf_alpha_forward", L.c_l(M), L.ptr(raw), L.ptr(dtv), L.ptr(alpha), L.ptr(om), L.stream())
+        T, bgT = VR.cumprod_alpha2transmittance(rs, om.view(-1, 1))
+        w = alpha.view(-1, 1) * T
+        pred_bg = VR.integrate_with_weights(rs, rgb, w)
+        pred = fg_pred + fg_bg * pred_bg
+        g_fg = (g_pred * pred_bg).sum(1, keepdim=True)
+        g_rgb, g_w = VR.integrate_with_weights_backward((fg_bg * g_pred).contiguous(), rs, rgb, w, None)
+        g_T = g_w * alpha.view(-1, 1)
+        cs = VR.cumsum_over_each_ray(rs, g_T * T, True)
+        g_om = VR.cumprod_alpha2transmittance_backward(g_T, torch.zeros_like(bgT), rs, om.view(-1, 1), T, bgT, cs)
+        g_raw = torch.empty_like(raw)
+        L.call("psdf_nerf_alpha_backward", L.c_l(M), L.ptr(raw), L.ptr(dtv), L.ptr((g_w * T).reshape(-1).contiguous()),
+               L.ptr(g_om.reshape(-1).contiguous()), L.ptr(g_raw), L.stream())
+        return pred_bg, pred, g_raw, g_rgb, g_fg
+    pb, p, gr, gc, gf = chain()
+    pb2, p2 = nerf_composite_forward_raw(rs, raw, rgb, fg_pred, fg_bg)
+    gr2, gc2, gf2 = nerf_composite_backward_raw(rs, int(counts.max()), g_pred, raw, rgb, fg_bg)
+
+    def close(a, b, tol=2e-6):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= tol * max(1.0, float(a.abs().max())), float((a - b).abs().max())
+    close(pb, pb2)
+    close(p, p2)
+    close(gf, gf2, 5e-6)
+    close(gc, gc2)
+    close(gr, gr2, 1e-5)
+    # alone (no foreground): gradient of the background radiance itself
+    pb3, none = nerf_composite_forward_raw(rs, raw, rgb)
+    assert none is None
+    close(pb, pb3)
