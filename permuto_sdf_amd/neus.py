@@ -349,3 +349,28 @@ def nerf_composite_backward_raw(rs, max_per_ray, g_pred, raw_density, rgb, fg_bg
            L.ptr(rs.samples_dt), L.ptr(rgb), L.c_i(int(VolumeRendering.reference_compat)), L.ptr(g_raw), L.ptr(g_rgb), L.ptr(g_fg),
            L.stream())
     return g_raw, g_rgb, g_fg
+
+
+class NerfCompositeFunc(torch.autograd.Function):
+    """(raw_density, rgb, fg_pred, fg_bg) -> pred = fg_pred + fg_bg * render(background): NerfHash's density activation,
+    VolumeRenderingNerf.compute_weights + integrate and the composition of train_permuto_sdf.py:160-165 as one launch per
+    direction; gradients flow to all four inputs."""
+
+    @staticmethod
+    def forward(ctx, rs, max_per_ray, raw_density, rgb, fg_pred, fg_bg):
+        raw, c, fp, fb = _c(raw_density).reshape(-1), _c(rgb), _c(fg_pred), _c(fg_bg).view(-1, 1)
+        _, pred = nerf_composite_forward_raw(rs, raw, c, fp, fb)
+        ctx.save_for_backward(raw, c, fb)
+        ctx.rs, ctx.max_per_ray, ctx.raw_shape, ctx.bg_shape = rs, int(max_per_ray), raw_density.shape, fg_bg.shape
+        return pred
+
+    @staticmethod
+    def backward(ctx, g_pred):
+        raw, c, fb = ctx.saved_tensors
+        g_pred = g_pred.contiguous()
+        g_raw, g_rgb, g_fb = nerf_composite_backward_raw(ctx.rs, ctx.max_per_ray, g_pred, raw, c, fb)
+        return None, None, g_raw.view(ctx.raw_shape), g_rgb, g_pred, g_fb.view(ctx.bg_shape)
+
+
+def nerf_composite(rs, max_per_ray, raw_density, rgb, fg_pred, fg_bg):
+    return NerfCompositeFunc.apply(rs, max_per_ray, raw_density, rgb, fg_pred, fg_bg)

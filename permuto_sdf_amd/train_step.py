@@ -39,8 +39,8 @@ from .bridge import OccupancyGrid, PermutoSDF, RaySampler, Sphere, VolumeRenderi
 from .encoding import Coarse2Fine, PermutoEncoding
 from .fused import encode_mlp_forward_raw
 from .mlp import FusedMLP, LipshitzMLP, pack_params
-from .neus import (curvature_loss, curvature_shift, eikonal_loss, l1_loss, nerf_alpha, neus_alpha, neus_composite, normalize3,
-                   offsurface_loss)
+from .neus import (curvature_loss, curvature_shift, eikonal_loss, l1_loss, nerf_alpha, nerf_composite, neus_alpha, neus_composite,
+                   normalize3, offsurface_loss)
 from .optim import FusedAdamW
 
 
@@ -456,7 +456,10 @@ class Trainer:
                 w, _, bgT = self.rgb.neus_weights(fg, sdf, sdf_grad, cos_anneal_ratio, forced_variance)
                 pred = _Integrate.apply(fg, rgb, w)
         rgb_bg, dens = self.bg(bg.samples_pos_4d, bg.samples_dirs, cc, img_indices, bg.ray_start_end_idx)
-        pred = pred + bgT.view(-1, 1) * _Integrate.apply(bg, rgb_bg, BgNet.nerf_weights(bg, dens.view(-1, 1)))
+        if self.hp.nr_samples_bg <= 256:    # density activation, weights, integration and the composition: one launch per direction
+            pred = nerf_composite(bg, self.hp.nr_samples_bg, dens, rgb_bg, pred, bgT.view(-1, 1))
+        else:
+            pred = pred + bgT.view(-1, 1) * _Integrate.apply(bg, rgb_bg, BgNet.nerf_weights(bg, dens.view(-1, 1)))
         return pred, sdf_grad, fg
 
     def _sphere_init_loss(self, it):
