@@ -157,6 +157,11 @@ int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float
 int psdf_lipshitz_normalize_forward(int out, int in, const float* W, const float* c, float* Wn, void* stream);
 int psdf_lipshitz_normalize_backward(int out, int in, const float* W, const float* c, const float* grad_Wn, float* grad_W,
     float* grad_c, void* stream);
+/* all layers of a LipshitzMLP (n_layers <= 8) in one launch per direction: W[l] [out[l], in[l]], c[l] [1] on the device */
+int psdf_lipshitz_normalize_forward_multi(int n_layers, const int* out, const int* in, const float* const* W, const float* const* c,
+                                          float* const* Wn, void* stream);
+int psdf_lipshitz_normalize_backward_multi(int n_layers, const int* out, const int* in, const float* const* W, const float* const* c,
+                                           const float* const* grad_Wn, float* const* grad_W, float* const* grad_c, void* stream);
 
 /* ---- neus.hip ---- */
 /* replaces: the torch elementwise chain of VolumeRenderingNeus.compute_weights, permuto_sdf_py/volume_rendering/

@@ -296,15 +296,23 @@ __global__ void mlp_wide_reduce_kernel(const float* __restrict__ partial, int ni
   else { if (e - GI::B4 < a.dims[4]) atomicAdd(&db3[e - GI::B4], s); }
 }
 
-// zero-padded copies of the weights in the two orientations the kernel streams: Wp [out_pad][in_pad], WTp [in_pad][out_pad]
-__global__ void mlp_wide_pack_kernel(int out, int in, int out_pad, int in_pad, const float* __restrict__ W,
-                                     float* __restrict__ Wp, float* __restrict__ WTp) {
+// zero-padded copies of the weights in the two orientations the kernel streams: Wp [out_pad][in_pad], WTp [in_pad][out_pad];
+// all four layers in one launch (blockIdx.y = layer)
+struct PackLayers {
+  int out[4], in[4], out_pad[4], in_pad[4];
+  const float* W[4];
+  float* Wp[4];
+  float* WTp[4];
+};
+__global__ void mlp_wide_pack_kernel(PackLayers p) {
+  const int l = blockIdx.y;
+  const int out = p.out[l], in = p.in[l], out_pad = p.out_pad[l], in_pad = p.in_pad[l];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= out_pad * in_pad) return;
   const int o = e / in_pad, i = e % in_pad;
-  const float v = (o < out && i < in) ? W[o * in + i] : 0.f;
-  Wp[e] = v;
-  WTp[i * out_pad + o] = v;
+  const float v = (o < out && i < in) ? p.W[l][o * in + i] : 0.f;
+  p.Wp[l][e] = v;
+  p.WTp[l][i * out_pad + o] = v;
 }
 
 // Lipschitz weight normalisation of one layer (models.py:98-104): Wn[r][:] = W[r][:] * min(1, softplus(c) / sum_j |W[r][j]|).
@@ -350,6 +358,54 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// All layers of a LipshitzMLP in one launch (blockIdx.y = layer, blockIdx.x = row): what the training step needs every
+// iteration -- four forward and four backward launches otherwise.
+constexpr int LIP_MAX_LAYERS = 8;
+struct LipLayers {
+  int out[LIP_MAX_LAYERS], in[LIP_MAX_LAYERS];
+  const float* W[LIP_MAX_LAYERS];
+  const float* c[LIP_MAX_LAYERS];
+  const float* G[LIP_MAX_LAYERS];   // backward: dL/dWn
+  float* Wn[LIP_MAX_LAYERS];        // forward output / backward: dW
+  float* dc[LIP_MAX_LAYERS];
+};
+__global__ void __launch_bounds__(64) lipshitz_norm_multi_kernel(LipLayers p, int backward) {
+  const int l = blockIdx.y, r = blockIdx.x, lane = threadIdx.x;
+  if (r >= p.out[l]) return;
+  const int in = p.in[l];
+  const float* __restrict__ W = p.W[l];
+  if (!backward) {
+    float a = 0.f;
+    for (int j = lane; j < in; j += 64) a += fabsf(W[r * in + j]);
+    a = psdf::wave_sum(a);
+    const float scale = fminf(softplus_t(p.c[l][0]) / a, 1.0f);
+    for (int j = lane; j < in; j += 64) p.Wn[l][r * in + j] = W[r * in + j] * scale;
+    return;
+  }
+  const float* __restrict__ G = p.G[l];
+  float a = 0.f, gw = 0.f;
+  for (int j = lane; j < in; j += 64) {
+    const float w = W[r * in + j];
+    a += fabsf(w);
+    gw += G[r * in + j] * w;
+  }
+  a = psdf::wave_sum(a);
+  gw = psdf::wave_sum(gw);
+  const float x = p.c[l][0];
+  const float sp = softplus_t(x);
+  const float ratio = sp / a;
+  const bool active = ratio < 1.0f;
+  for (int j = lane; j < in; j += 64) {
+    const float w = W[r * in + j], g = G[r * in + j];
+    const float sgn = w > 0.f ? 1.f : (w < 0.f ? -1.f : 0.f);
+    p.Wn[l][r * in + j] = active ? g * ratio - gw * sp / (a * a) * sgn : g;
+  }
+  if (active && lane == 0) {
+    const float sig = 1.0f / (1.0f + expf(-x));
+    atomicAdd(p.dc[l], gw / a * (x > 20.f ? 1.0f : sig));
+  }
+}
+
 // pack (both weight orientations, zero padded), main launch, summing launch
 template <int TI0, int T1, int T2, int T3, int T4>
 int wide_launch(const int* dims, int64_t N, const float* X, const float* const* weights, const float* const* biases,
@@ -363,18 +419,22 @@ int wide_launch(const int* dims, int64_t N, const float* X, const float* const* 
   char* scratch = (char*)psdf::stream_scratch((wfloats + (size_t)blocks * GI::TOTAL) * sizeof(float), st);  // NULL while capturing
   if (!scratch) return PSDF_ERR_UNSUPPORTED;
   WideArgs a;
+  PackLayers pk;
   float* wp = reinterpret_cast<float*>(scratch);
+  int nmax = 0;
   for (int l = 0; l < 4; l++) {
     const int n = pads[l] * pads[l + 1];
     float* Wp = wp;
     float* WTp = wp + n;
     wp += 2 * n;
-    hipLaunchKernelGGL(mlp_wide_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dims[l + 1], dims[l], pads[l + 1],
-                       pads[l], weights[l], Wp, WTp);
+    pk.out[l] = dims[l + 1], pk.in[l] = dims[l], pk.out_pad[l] = pads[l + 1], pk.in_pad[l] = pads[l];
+    pk.W[l] = weights[l], pk.Wp[l] = Wp, pk.WTp[l] = WTp;
+    nmax = n > nmax ? n : nmax;
     a.W[l] = Wp;
     a.WT[l] = WTp;
     a.b[l] = biases[l];
   }
+  hipLaunchKernelGGL(mlp_wide_pack_kernel, dim3((nmax + 255) / 256, 4), dim3(256), 0, st, pk);
   for (int i = 0; i < 5; i++) a.dims[i] = dims[i];
   float* partial = wp;
   const size_t lds_bytes = (size_t)((TI0 + 2 * T1 + 2 * T2 + 2 * T3 + T4) * 16) * RS * sizeof(float);
@@ -407,6 +467,40 @@ int psdf_lipshitz_normalize_backward(int out, int in, const float* W, const floa
   if (out <= 0 || in <= 0) return PSDF_OK;
   if (!W || !c || !grad_Wn || !grad_W || !grad_c) return PSDF_ERR_ARG;
   hipLaunchKernelGGL(lipshitz_norm_bwd_kernel, dim3(out), dim3(64), 0, (hipStream_t)stream, in, W, c, grad_Wn, grad_W, grad_c);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// every layer of the net in one launch: W[l] [out[l], in[l]], c[l] [1], Wn[l] like W[l]; n_layers <= 8
+int psdf_lipshitz_normalize_forward_multi(int n_layers, const int* out, const int* in, const float* const* W, const float* const* c,
+                                          float* const* Wn, void* stream) {
+  if (n_layers <= 0) return PSDF_OK;
+  if (n_layers > LIP_MAX_LAYERS || !out || !in || !W || !c || !Wn) return PSDF_ERR_ARG;
+  LipLayers p{};
+  int rows = 0;
+  for (int l = 0; l < n_layers; l++) {
+    if (out[l] <= 0 || in[l] <= 0 || !W[l] || !c[l] || !Wn[l]) return PSDF_ERR_ARG;
+    p.out[l] = out[l], p.in[l] = in[l], p.W[l] = W[l], p.c[l] = c[l], p.Wn[l] = Wn[l];
+    rows = out[l] > rows ? out[l] : rows;
+  }
+  hipLaunchKernelGGL(lipshitz_norm_multi_kernel, dim3(rows, n_layers), dim3(64), 0, (hipStream_t)stream, p, 0);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// grad_W[l] is written, grad_c[l] [1] is ACCUMULATED into
+int psdf_lipshitz_normalize_backward_multi(int n_layers, const int* out, const int* in, const float* const* W, const float* const* c,
+                                           const float* const* grad_Wn, float* const* grad_W, float* const* grad_c, void* stream) {
+  if (n_layers <= 0) return PSDF_OK;
+  if (n_layers > LIP_MAX_LAYERS || !out || !in || !W || !c || !grad_Wn || !grad_W || !grad_c) return PSDF_ERR_ARG;
+  LipLayers p{};
+  int rows = 0;
+  for (int l = 0; l < n_layers; l++) {
+    if (out[l] <= 0 || in[l] <= 0 || !W[l] || !c[l] || !grad_Wn[l] || !grad_W[l] || !grad_c[l]) return PSDF_ERR_ARG;
+    p.out[l] = out[l], p.in[l] = in[l], p.W[l] = W[l], p.c[l] = c[l], p.G[l] = grad_Wn[l], p.Wn[l] = grad_W[l], p.dc[l] = grad_c[l];
+    rows = out[l] > rows ? out[l] : rows;
+  }
+  hipLaunchKernelGGL(lipshitz_norm_multi_kernel, dim3(rows, n_layers), dim3(64), 0, (hipStream_t)stream, p, 1);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

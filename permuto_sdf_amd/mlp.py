@@ -480,6 +480,53 @@ class _LipshitzNormFunc(torch.autograd.Function):
         return dw, dc
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def lipshitz_normalize_all_raw(weights, bounds):
+    """LipshitzMLP.normalization (models.py:98-104) of EVERY layer in one launch -> [Wn_l]"""
+    ws, cs = [w.detach().contiguous() for w in weights], [c.detach().contiguous() for c in bounds]
+    outs = [torch.empty_like(w) for w in ws]
+    n = len(ws)
+    L.call("psdf_lipshitz_normalize_forward_multi", L.c_i(n), (ctypes.c_int * n)(*[w.shape[0] for w in ws]),
+           (ctypes.c_int * n)(*[w.shape[1] for w in ws]), _ptr_array(ws), _ptr_array(cs), _ptr_array(outs), L.stream())
+    return outs
+
+
+def lipshitz_normalize_all_backward_raw(weights, bounds, grads):
+    """-> ([dW_l], [dc_l]) for dL/dWn_l = grads[l], one launch"""
+    ws, cs = [w.detach().contiguous() for w in weights], [c.detach().contiguous() for c in bounds]
+    gs = [g.contiguous() for g in grads]
+    dws = [torch.empty_like(w) for w in ws]
+    dc_flat = torch.zeros(4 * len(cs), dtype=torch.float32, device=ws[0].device)   # one fill; every [1] slice 16-byte aligned
+    dcs = [dc_flat[4 * i:4 * i + 1] for i in range(len(cs))]                        # (the fused optimiser batches aligned tensors)
+    n = len(ws)
+    L.call("psdf_lipshitz_normalize_backward_multi", L.c_i(n), (ctypes.c_int * n)(*[w.shape[0] for w in ws]),
+           (ctypes.c_int * n)(*[w.shape[1] for w in ws]), _ptr_array(ws), _ptr_array(cs), _ptr_array(gs), _ptr_array(dws),
+           _ptr_array(dcs), L.stream())
+    return dws, dcs
+
+
+class _LipshitzNormAllFunc(torch.autograd.Function):
+    """(W_0, .., W_{n-1}, c_0, .., c_{n-1}) -> (Wn_0, .., Wn_{n-1}): one launch per direction for the whole net"""
+
+    @staticmethod
+    def forward(ctx, n, *params):
+        ws, cs = params[:n], params[n:]
+        ctx.n = n
+        ctx.save_for_backward(*[w.detach() for w in ws], *[c.detach() for c in cs])
+        return tuple(lipshitz_normalize_all_raw(ws, cs))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n = ctx.n
+        ws, cs = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        grads = [g if g is not None else torch.zeros_like(w) for g, w in zip(grads, ws)]
+        dws, dcs = lipshitz_normalize_all_backward_raw(ws, cs, grads)
+        return (None, *dws, *[dc.view_as(c) for dc, c in zip(dcs, cs)])
+
+
 class LipshitzMLP(torch.nn.Module):
     """Lipschitz-regularised MLP of the colour network (reference: permuto_sdf_py/models/models.py:54-129, used at
     :349-350 as 111 -> 128 -> 128 -> 64 -> 3): every layer's weight is rescaled per row by
@@ -518,7 +565,7 @@ class LipshitzMLP(torch.nn.Module):
 
     def forward(self, x):
         if x.is_cuda:
-            ws = [_LipshitzNormFunc.apply(w, c) for w, c in zip(self.weights_per_layer, self.lipshitz_bound_per_layer)]
+            ws = list(_LipshitzNormAllFunc.apply(self.n_layers, *self.weights_per_layer, *self.lipshitz_bound_per_layer))
         else:   # parameter bookkeeping on the CPU (checkpoint tests); compute is GPU only and raises below
             ws = [self.normalization(w, torch.nn.functional.softplus(c))
                   for w, c in zip(self.weights_per_layer, self.lipshitz_bound_per_layer)]

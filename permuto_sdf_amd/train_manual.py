@@ -23,7 +23,8 @@ import torch
 from . import _lib as L
 from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
 from .encoding import encode_backward_raw, encode_double_backward_raw, encode_forward_raw
-from .mlp import mlp_backward_raw, mlp_double_backward, mlp_forward_raw, pack_params
+from .mlp import (lipshitz_normalize_all_backward_raw, lipshitz_normalize_all_raw, mlp_backward_raw, mlp_double_backward, mlp_forward_raw,
+                  pack_params)
 from .neus import (eikonal_loss_raw, l1_loss_raw, nerf_composite_backward_raw, nerf_composite_forward_raw, neus_composite_backward_raw,
                    neus_composite_forward_raw, sigmoid_rows_backward_raw, sigmoid_rows_raw)
 from .train_step import Trainer, map_range_val
@@ -135,12 +136,7 @@ class ManualTrainer(Trainer):
                 x_rgb = torch.cat([feat2, sh.t(), nn.t(), y[1:]], 0)                         # [111, N]
                 c_enc, c_sh = feat2.shape[0], feat2.shape[0] + sh.shape[1]
                 m = rgbn.mlp
-                wn = []
-                for w, c in zip(m.weights_per_layer, m.lipshitz_bound_per_layer):
-                    o_ = torch.empty_like(w)
-                    L.call("psdf_lipshitz_normalize_forward", L.c_i(w.shape[0]), L.c_i(w.shape[1]), L.ptr(w.detach()), L.ptr(c.detach()),
-                           L.ptr(o_), L.stream())
-                    wn.append(o_)
+                wn = lipshitz_normalize_all_raw(m.weights_per_layer, m.lipshitz_bound_per_layer)      # all four layers, one launch
                 bsr = [b.detach() for b in m.biases_per_layer]
                 rgb_fm = mlp_forward_raw(m.dims, x_rgb, pack_params(m.dims, wn, bsr))                            # [3, N]
                 if cc is not None:
@@ -243,12 +239,9 @@ class ManualTrainer(Trainer):
                 else:
                     g_pre_fm = sigmoid_rows_backward_raw(g_rgb, rgb)
                 dXr, dWn, dbr = mlp_backward_raw(m.dims, x_rgb, wn, bsr, g_pre_fm, need_dx=True)
+                dws, dcs = lipshitz_normalize_all_backward_raw(m.weights_per_layer, m.lipshitz_bound_per_layer, dWn)
                 for i, (w, c) in enumerate(zip(m.weights_per_layer, m.lipshitz_bound_per_layer)):
-                    dw = torch.empty_like(w)
-                    dc = torch.zeros_like(c)
-                    L.call("psdf_lipshitz_normalize_backward", L.c_i(w.shape[0]), L.c_i(w.shape[1]), L.ptr(w.detach()), L.ptr(c.detach()),
-                           L.ptr(dWn[i]), L.ptr(dw), L.ptr(dc), L.stream())
-                    w.grad, c.grad, m.biases_per_layer[i].grad = dw, dc, dbr[i]
+                    w.grad, c.grad, m.biases_per_layer[i].grad = dws[i], dcs[i].view_as(c), dbr[i]
                 _enc_bwd(rgbn.encoding, pts, rgbn._win, dXr[:c_enc])
                 g_n = g_n + g_nc + _normalize3(n, dXr[c_sh:c_sh + 3].t().contiguous())
                 g_y = torch.cat([g_sdf.view(1, -1), dXr[c_sh + 3:]], 0)                           # [33, N]
