@@ -201,16 +201,25 @@ class SdfNet(torch.nn.Module):
         return _SplitHead.apply(self.mlp_sdf(self.encoding(points, self.window(it))))
 
     @torch.no_grad()
-    def sdf_only(self, points, it):
-        """[N,1]; the SDF is row 0 of the last layer (models.py:190)"""
+    def sdf_only(self, points, it, key=None):
+        """[N,1]; the SDF is row 0 of the last layer (models.py:190).  `key`: anything that changes whenever the parameters do
+        (the trainer passes its iteration counter): calls with the same key share one packed weight image instead of packing
+        it again (three evaluations per training step)."""
         lin = list(self.mlp_sdf.layers)
-        ws, bs = [l.weight for l in lin], [l.bias for l in lin]
-        ws[-1], bs[-1] = ws[-1][0:1].contiguous(), bs[-1][0:1].contiguous()
         dims = [lin[0].in_features, 32, 32, 32, 1]
+        if key is not None:      # torch-level writes (load_state_dict, copy_) bump _version; the fused optimiser's do not: hence both
+            key = (key, tuple(p._version for l in lin for p in (l.weight, l.bias)))
+        cached = getattr(self, "_sdf_only_packed", None)
+        if key is not None and cached is not None and cached[0] == key:
+            packed = cached[1]
+        else:
+            ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+            ws[-1], bs[-1] = ws[-1][0:1].contiguous(), bs[-1][0:1].contiguous()
+            packed = pack_params(dims, ws, bs)
+            self._sdf_only_packed = (key, packed) if key is not None else None
         e = self.encoding
         y, _ = encode_mlp_forward_raw(e.cfg, points.contiguous(), e.lattice_values.detach(), e.scale_factor,
-                                      e.random_shift_per_level.detach(), self.window(it).contiguous(), dims,
-                                      pack_params(dims, ws, bs))
+                                      e.random_shift_per_level.detach(), self.window(it).contiguous(), dims, packed)
         return y.view(-1, 1)
 
     def sdf_and_gradient(self, points, it):  # models.py:236-251
@@ -423,14 +432,14 @@ class Trainer:
                                            jitter, False)
         if fg.samples_pos.shape[0] == 0:
             return fg, bg
-        fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it))
+        fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it, key=self.iter))
         for rnd, mult in ((0, 1.0), (1, 2.0)):
             # sdf2alpha -> clip -> 1 - alpha + 1e-7 -> cumprod -> alpha * T -> per-ray sum -> normalise -> cdf
             # (sdf_utils.py:403-417), one launch, bit-identical to the nine of the operator chain
             cdf = VolumeRendering.sdf_importance_cdf(fg, fg.samples_sdf, 512.0, True, mult)
             imp = VolumeRendering.importance_sample(o, d, fg, cdf, hp.nr_samples_imp_sampling, jitter)
             if rnd == 0:
-                imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it))
+                imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it, key=self.iter))
             else:
                 fg.remove_sdf()
             fg = VolumeRendering.combine_uniform_samples_with_imp(o, d, tx, fg, imp).compact_to_valid_samples()
@@ -479,7 +488,7 @@ class Trainer:
                 parallel.seed_generators(977 + git, self.dev)
                 centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
                 inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
-                self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it), inv_s.view(1), 1e-4)
+                self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it, key=self.iter), inv_s.view(1), 1e-4)
             if n_fg:  # the count is already on the host
                 self.nr_rays = max(64, min(8192, int(self.nr_rays * hp.target_nr_of_samples / n_fg)))
 
