@@ -88,8 +88,8 @@ int psdf_mlp_forward_f16(int n_layers, const int* dims, int64_t N, const float* 
 /* ---- composite_fused.hip ---- */
 /* replaces, fused: VolumeRenderingNeus.compute_weights + integrate (permuto_sdf_py/volume_rendering/volume_rendering_modules.py:
    129-190), i.e. the chain psdf_neus_alpha_forward -> psdf_cumprod_alpha2transmittance -> (alpha * T) ->
-   psdf_integrate_with_weights in ONE launch: pred [R,3] (pass zeros: invalid / empty rays keep them), bg [R] (optional; pass
-   ones), weights [N] (optional).  Same arithmetic and summation order as the separate entry points. */
+   psdf_integrate_with_weights in ONE launch: pred [R,3] (every ray written: 0 for invalid / empty rays), bg [R] (optional; 1 for
+   such rays), weights [N] (optional).  Same arithmetic and summation order as the separate entry points. */
 int psdf_neus_composite_forward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float* sdf,
     const float* dirs, const float* gradients, const float* dt, const float* rgb, const float* inv_s, float cos_anneal_ratio,
     float* pred, float* bg, float* weights, void* stream);

@@ -37,7 +37,13 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   RAY_LOOP(ray, nr_rays) {
     int s, e;
     ri.get(ray, s, e);
-    if (!ri.valid(s, e)) continue;          // pred / bg keep what the caller put there (zeros / ones), as in the separate kernels
+    if (!ri.valid(s, e)) {                  // an empty / overflowed ray renders nothing: radiance 0, everything transmitted
+      if (lane == 0) {                      // (what zero- / one-initialised outputs of the separate kernels hold for it)
+        pred[3 * ray] = pred[3 * ray + 1] = pred[3 * ray + 2] = 0.f;
+        if (bg) bg[ray] = 1.f;
+      }
+      continue;
+    }
     const int n = e - s;
     float carry = 1.f, r = 0.f, g = 0.f, b = 0.f;
     for (int base = 0; base < n; base += 64) {
@@ -370,7 +376,7 @@ int psdf_nerf_composite_backward(int nr_rays, const int* start_end, int equal, i
   return PSDF_OK;
 }
 
-// pred [R,3] (rows of invalid / empty rays keep their contents: pass zeros), bg [R] optional (bg transmittance; pass ones),
+// pred [R,3] (rows of invalid / empty rays: 0), bg [R] optional (bg transmittance; 1 for such rays),
 // weights [N] optional (alpha T per sample).  Ray-index arguments as everywhere (include/psdf.h).
 int psdf_neus_composite_forward(int nr_rays, const int* start_end, int equal, int fixed, int max_nr_samples, const float* sdf,
                                 const float* dirs, const float* gradients, const float* dt, const float* rgb, const float* inv_s,

@@ -65,8 +65,8 @@ def neus_composite_forward_raw(rs, sdf, gradients, rgb, inv_s, cos_anneal_ratio,
     -> pred [R,3], bg transmittance [R,1], weights [N,1] or None"""
     R, N, dev = rs.ray_start_end_idx.shape[0], sdf.shape[0], sdf.device
     L.require_cuda(sdf, gradients, rgb, inv_s)
-    pred = torch.zeros((R, 3), dtype=torch.float32, device=dev)
-    bg = torch.ones((R, 1), dtype=torch.float32, device=dev)
+    pred = torch.empty((R, 3), dtype=torch.float32, device=dev)       # the kernel writes every ray (0 / 1 for empty ones)
+    bg = torch.empty((R, 1), dtype=torch.float32, device=dev)
     w = torch.zeros((N, 1), dtype=torch.float32, device=dev) if want_weights else None
     L.call("psdf_neus_composite_forward", *rs._ri(), L.ptr(sdf), L.ptr(rs.samples_dirs), L.ptr(gradients), L.ptr(rs.samples_dt),
            L.ptr(rgb), L.ptr(inv_s), L.c_f(float(cos_anneal_ratio)), L.ptr(pred), L.ptr(bg), L.ptr(w), L.stream())
