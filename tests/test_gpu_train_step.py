@@ -130,13 +130,21 @@ def test_manual_backward_equals_autograd(dev, mode):
     for i, (x, y) in enumerate(zip(ga["dense"], gm["dense"])):
         scale = float(x.abs().max())
         err = float((x - y).abs().max())
-        assert err <= 2e-4 * scale + 1e-9, ("dense gradient %d" % i, tuple(x.shape), err, scale)
+        tol = 2e-4 if mode == "late" else 2e-3        # (the SDF net's gradients carry the curvature term: see below)
+        assert err <= tol * scale + 1e-9, ("dense gradient %d" % i, tuple(x.shape), err, scale)
+    # The lattice buffers are sums of many signed contributions added by float atomics in launch-dependent order.  On top of
+    # that the SDF lattice (index 0) carries the curvature term, whose gradient is ill conditioned by construction: acos of the
+    # dot product of two normals 1e-4 apart, derivative 1 / sqrt(1 - d^2) with 1 - d ~ 1e-6, so the last-bit noise of the normals
+    # (atomic order of the encoding's position backward) moves single samples' gradients by per cent.  Measured run-to-run spread
+    # of that buffer for ONE trainer on identical inputs: up to 7e-4 relative L2, sporadically 2e-3 on one level
+    # (tools/trainer_gradient_noise.py; the scatter kernels themselves repeat to 1e-6: tools/enc_bwd_determinism.py).  So: tight
+    # where the curvature term is off (mode "late": every other path of the step), a few times the noise where it is on.
     for i, (x, y) in enumerate(zip(ga["lattices"], gm["lattices"])):
         scale = float(x.abs().max())
         err = float((x - y).abs().max())
         rel = float((x - y).norm() / x.norm())
-        # (elements are sums of many signed contributions added by float atomics in launch-dependent order)
-        assert scale > 0 and err <= 1e-3 * scale and rel <= 2e-4, ("lattice %d" % i, err, scale, rel)
+        tol_rel, tol_max = (2e-4, 1e-3) if (mode == "late" or i > 0) else (4e-3, 2e-2)
+        assert scale > 0 and err <= tol_max * scale and rel <= tol_rel, ("lattice %d" % i, err, scale, rel)
 
 
 def test_manual_trainer_learns_constant_colour(dev):
