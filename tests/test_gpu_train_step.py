@@ -160,3 +160,23 @@ def test_manual_trainer_learns_constant_colour(dev):
     assert sum(losses[-10:]) / 10 < 0.6 * sum(losses[:5]) / 5, (losses[:5], losses[-10:])
     t = tr.sdf.encoding.touched_rows
     assert float(t.grad.abs().max()) == 0.0 and int(t.touched.sum()) == 0
+
+
+@pytest.mark.parametrize("manual", [False, True])
+def test_step_without_foreground_samples(dev, manual):
+    """an empty occupancy grid: no foreground samples at all -- the step renders the background only, both trainers agree on the
+    gradients, the SDF lattice gets the off-surface term alone"""
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel, Trainer
+    hp = HyperParams()
+    hp.nr_rays, hp.target_nr_of_samples = 128, 128 * 96
+    tr = (ManualTrainer if manual else Trainer)(dev, hp)
+    tr.grid.set_grid_occupancy(torch.zeros_like(tr.grid.get_grid_occupancy()))
+    reel = SyntheticReel(dev, nr_images=2, height=40, width=60)
+    tr.capture_grads = {}
+    loss = float(tr.step(reel))
+    assert loss == loss and tr.last["nr_fg_samples"] == 0
+    lat = tr.capture_grads["lattices"]
+    assert float(lat[2].abs().max()) > 0          # background lattice
+    assert float(lat[1].abs().max()) == 0.0       # colour lattice: nothing rendered
+    assert float(lat[0].abs().max()) > 0          # SDF lattice: off-surface points
