@@ -749,7 +749,12 @@ __global__ void __launch_bounds__(1024)
   const int64_t qb = ((int64_t)level * Q.np + part) * Q.cap;
   const uint16_t* __restrict__ rows = Q.rows + qb;
   const float* __restrict__ vals = Q.vals + qb * F;
-  constexpr int U = 8;  // queue entries in flight per thread (the loop is HBM-latency bound otherwise)
+#if !defined(PSDF_ENC_REDUCE_U)
+#define PSDF_ENC_REDUCE_U 8
+#endif
+  // queue entries in flight per thread (the loop is HBM-latency bound otherwise); measured on the bench step, encode backward
+  // pair: U = 4 0.847 ms, 8 0.742, 12 0.742, 16 0.750
+  constexpr int U = PSDF_ENC_REDUCE_U;
   int hot = 0;
   for (int base = 0; base < n; base += U * (int)blockDim.x) {
     int row[U];
