@@ -105,6 +105,22 @@ def encode_double_backward_raw(cfg, positions, lattice, scale_factor, shifts, wi
            L.c_l(nbytes), L.stream())
 
 
+def morton_order(positions, lo=None, hi=None):
+    """Permutation that sorts unordered points [N, P <= 3] along a 10-bit-per-axis Morton curve of their bounding box: for point
+    clouds that are NOT ray ordered (cfg 2's "points in a ball") neighbouring lanes then share simplices -- and table rows -- at
+    the coarse and medium levels, as consecutive samples of a ray do.  The operator itself never reorders its input (outputs are
+    per point, in the caller's order); a caller that can evaluate in any order does `perm = morton_order(p); f = enc(p[perm])`."""
+    p = positions.detach().float()
+    lo = p.min(0).values if lo is None else lo
+    hi = p.max(0).values if hi is None else hi
+    q = ((p - lo) / (hi - lo).clamp_min(1e-20) * 1023.0).clamp(0, 1023).to(torch.int64)
+    code = torch.zeros(p.shape[0], dtype=torch.int64, device=p.device)
+    for b in range(10):
+        for a in range(p.shape[1]):
+            code |= ((q[:, a] >> b) & 1) << (p.shape[1] * b + a)
+    return torch.argsort(code)
+
+
 def _feature_major(g):
     """[N, C] gradient (any strides) -> contiguous [C, N]."""
     gt = g.t()

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from permuto_sdf_amd import FusedMLP, PermutoEncoding  # noqa: E402
-from permuto_sdf_amd.encoding import encode_backward_raw, encode_forward_raw  # noqa: E402
+from permuto_sdf_amd.encoding import encode_backward_raw, encode_forward_raw, morton_order  # noqa: E402
 from permuto_sdf_amd.mlp import mlp_backward_raw, mlp_forward_raw, pack_params  # noqa: E402
 
 
@@ -33,6 +33,7 @@ def main():
     N = 2 ** 21
     torch.manual_seed(0)
     ball = 0.5 * torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=1) * torch.rand(N, 1, device=dev) ** (1 / 3)
+    ball_sorted = ball[morton_order(ball)].contiguous()
     o = torch.nn.functional.normalize(torch.randn(16384, 1, 3, device=dev), dim=2) * 0.5
     d = torch.nn.functional.normalize(-o + 0.2 * torch.randn(16384, 1, 3, device=dev), dim=2)
     rays = (o + d * torch.linspace(0, 1, 128, device=dev).view(1, 128, 1)).reshape(-1, 3).contiguous()
@@ -44,7 +45,7 @@ def main():
             ws, bs = [l.weight for l in mlp.layers], [l.bias for l in mlp.layers]
             win = torch.ones(L_, device=dev)
             lat = enc.lattice_values.detach()
-            for name, x in (("ball", ball), ("rays", rays)):
+            for name, x in (("ball", ball), ("ball, Morton-sorted by the caller", ball_sorted), ("rays", rays)):
                 a = (enc.cfg, x, lat, enc.scale_factor, enc.random_shift_per_level.detach(), win)
                 gy = torch.ones(net[-1], N, device=dev)
 
