@@ -212,3 +212,72 @@ def test_overlap_schedule_is_race_free_under_an_asynchronous_backend(dev):
         # grad_scale = 1 / world: the update of two identical ranks equals the single-rank update
         for a, b in zip(p1, p2):
             assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, mode
+
+
+def test_cfg3_size_importance_sampling_and_merge(dev):
+    """The SDF-driven importance sampling of sdf_utils.py:383-423 at the full image size of cfg 3 (262 144 rays in ONE pool,
+    ~5 M uniform samples + 16 importance samples per ray): the one-launch cdf equals the operator chain bit for bit at this
+    size, the rank merge produces sorted rays of exactly uniform + 16 samples with consistent positions / dt, and the merged
+    samples of a 400-ray subset equal the oracle's serial merge of the same inputs bit for bit."""
+    from permuto_sdf import OccupancyGrid, RaySamplesPacked, Sphere, VolumeRendering as VR
+    port = O.Oracle("port")
+    n, res = 256, 512
+    occ = scene.shell_occupancy(port, n, r0=0.3, width=0.02, drop=0.0)
+    grid = OccupancyGrid(n, 1.0, [0, 0, 0])
+    grid.set_grid_occupancy(torch.from_numpy(occ).to(dev))
+    grid.max_nr_samples = res * res * 128
+    sphere = Sphere(0.5, [0, 0, 0])
+    o, d = camera_rays(res, dev)
+    _, te, _, tx, _ = sphere.ray_intersection(o, d)
+    fg = grid.compute_samples_in_occupied_regions(o, d, te, tx, 1e-4, 128, True).compact_to_valid_samples()
+    M = fg.samples_pos.shape[0]
+    assert M > 2_000_000
+    fg.set_sdf(fg.samples_pos.norm(dim=1, keepdim=True) - 0.3)
+    # one launch == nine launches
+    alpha = VR.sdf2alpha(fg, fg.samples_sdf, 512.0, True, 1.0).clip(0.0, 1.0)
+    T, _ = VR.cumprod_alpha2transmittance(fg, 1 - alpha + 1e-7)
+    w = alpha * T
+    _, per_sample = VR.sum_over_each_ray(fg, w)
+    cdf_chain = VR.compute_cdf(fg, w / torch.clamp(per_sample, min=1e-6))
+    cdf = VR.sdf_importance_cdf(fg, fg.samples_sdf, 512.0, True, 1.0)
+    assert torch.equal(cdf.view(torch.int32), cdf_chain.view(torch.int32))
+    st = (VR._rng.state, VR._rng.inc)
+    imp = VR.importance_sample(o, d, fg, cdf, 16, True)
+    imp.set_sdf(imp.samples_pos.norm(dim=1, keepdim=True) - 0.3)
+    comb = VR.combine_uniform_samples_with_imp(o, d, tx, fg, imp)
+    c = comb.compact_to_valid_samples()
+    se_u, se_c = fg.ray_start_end_idx.long(), c.ray_start_end_idx.long()
+    cnt_u, cnt_c = se_u[:, 1] - se_u[:, 0], se_c[:, 1] - se_c[:, 0]
+    assert torch.equal(cnt_c, torch.where(cnt_u > 1, cnt_u + 16, torch.zeros_like(cnt_u)))
+    Mc = c.samples_pos.shape[0]
+    assert Mc == int(cnt_c.sum())
+    ridx = RaySamplesPacked.compute_per_sample_ray_idx(c.ray_start_end_idx, Mc).long()
+    z = c.samples_z.view(-1)
+    same = ridx[1:] == ridx[:-1]
+    assert bool((z[1:][same] >= z[:-1][same]).all())                                   # sorted along every ray
+    assert torch.equal(c.samples_pos, o[ridx] + z[:, None] * c.samples_dirs)
+    dt = c.samples_dt.view(-1)
+    fixed = c.ray_fixed_dt.view(-1)[ridx]
+    assert bool((dt >= 0).all()) and bool((dt <= fixed).all())
+    assert torch.equal(dt[:-1][same], torch.minimum(z[1:][same] - z[:-1][same], fixed[:-1][same]))   # dt = min(next z - z, fixed dt)
+    assert torch.equal(c.samples_sdf, c.samples_pos.norm(dim=1, keepdim=True) - 0.3) or \
+        float((c.samples_sdf - (c.samples_pos.norm(dim=1, keepdim=True) - 0.3)).abs().max()) < 1e-6   # sdf travels with its sample
+    # oracle: the serial merge of the same uniform / importance samples, rays [1000, 1400) of the image centre rows
+    r0, r1 = 131072 + 56, 131072 + 456
+    u0, u1 = int(se_u[r0, 0]), int(se_u[r1 - 1, 1])
+    s = O.Samples(r1 - r0, u1 - u0)
+    s.start_end = (se_u[r0:r1] - u0).to(torch.int32).cpu().numpy()
+    for name, src in (("z", fg.samples_z), ("dt", fg.samples_dt), ("pos", fg.samples_pos), ("dirs", fg.samples_dirs), ("sdf", fg.samples_sdf)):
+        setattr(s, name, src[u0:u1].cpu().numpy())
+    s.fixed_dt, s.has_sdf = fg.ray_fixed_dt[r0:r1].cpu().numpy(), True
+    ri = O.Samples(r1 - r0, (r1 - r0) * 16)
+    ri.equal, ri.fixed, ri.has_sdf = True, 16, True
+    for name, src in (("z", imp.samples_z), ("pos", imp.samples_pos), ("dirs", imp.samples_dirs), ("sdf", imp.samples_sdf)):
+        setattr(ri, name, src[r0 * 16:r1 * 16].cpu().numpy())
+    rc = port.compact(port.combine(s, ri, o[r0:r1].cpu().numpy(), d[r0:r1].cpu().numpy(), tx[r0:r1].cpu().numpy()))
+    k = rc.total()
+    c0 = int(se_c[r0, 0])
+    assert k == int(se_c[r1 - 1, 1]) - c0 and k > 10_000
+    for name, arr in (("samples_z", rc.z), ("samples_dt", rc.dt), ("samples_pos", rc.pos), ("samples_sdf", rc.sdf)):
+        got = getattr(c, name)[c0:c0 + k].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), arr[:k].view(np.uint32)), name
