@@ -281,3 +281,21 @@ def test_cfg3_size_importance_sampling_and_merge(dev):
     for name, arr in (("samples_z", rc.z), ("samples_dt", rc.dt), ("samples_pos", rc.pos), ("samples_sdf", rc.sdf)):
         got = getattr(c, name)[c0:c0 + k].cpu().numpy()
         assert np.array_equal(got.view(np.uint32), arr[:k].view(np.uint32)), name
+
+
+def test_background_sampler_at_full_ray_count(dev):
+    """compute_samples_bg with jitter for 300 000 rays x 32 samples: the thread-per-sample kernel reaches sample i of ray r with ONE
+    generator jump of (i + 1) r per_ray + i steps where the reference advances r per_ray and draws, i times over -- equal only if
+    the jump arithmetic is exact for the largest offsets too.  z, dt and the 3-D points against the oracle, bit for bit."""
+    from permuto_sdf import RaySampler, Sphere
+    port = O.Oracle("port")
+    R = 300_000
+    o_np, d_np = scene.make_rays(R, seed=17)
+    o, d = torch.from_numpy(o_np).to(dev), torch.from_numpy(d_np).to(dev)
+    _, _, _, tx, _ = Sphere(0.5, [0, 0, 0]).ray_intersection(o, d)
+    st = (RaySampler._rng.state, RaySampler._rng.inc)
+    bg = RaySampler.compute_samples_bg(o, d, tx, 32, 0.5, [0, 0, 0], True, False)
+    ref = port.samples_bg(o_np, d_np, tx.cpu().numpy(), 32, 0.5, [0, 0, 0], True, False, rng=st)
+    for got, want in ((bg.samples_z, ref.z), (bg.samples_dt, ref.dt), (bg.samples_pos, ref.pos)):
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.abs(bg.samples_pos_4d.cpu().numpy() - ref.pos4).max() < 1e-6
