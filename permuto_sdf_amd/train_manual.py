@@ -74,6 +74,11 @@ class ManualTrainer(Trainer):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         assert self.touched, "ManualTrainer accumulates the lattice gradients in the touched-rows buffers"
+        hp = self.hp
+        if hp.nr_samples_bg > 256 or hp.max_nr_samples_per_ray + 2 * hp.nr_samples_imp_sampling > 256:
+            raise ValueError("ManualTrainer uses the fused compositing kernels: at most 256 samples per ray (foreground: "
+                             "max_nr_samples_per_ray + 2 * nr_samples_imp_sampling; background: nr_samples_bg); "
+                             "train_step.Trainer handles longer rays through the per-operator chain")
 
     def _unit_row(self, rows, N):
         """[rows, N] feature-major upstream gradient that selects output 0 (d sdf / d .)"""
