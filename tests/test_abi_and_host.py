@@ -232,3 +232,19 @@ def test_lr_schedule_is_the_closed_form_of_the_reference_schedulers():
             if it >= hp.nr_iter_sphere_fit:
                 warm.step()
     assert lr_schedule(hp.iter_finish_training, hp) == hp.lr * hp.lr_gamma ** 3
+
+
+def test_morton_order_is_a_locality_preserving_permutation():
+    """encoding.morton_order (a caller-side helper for unordered point clouds): a permutation; consecutive points of the sorted
+    cloud are much closer to each other than consecutive points of the unsorted one"""
+    import torch
+    from permuto_sdf_amd.encoding import morton_order
+    torch.manual_seed(0)
+    p = torch.rand(20000, 3) - 0.5
+    perm = morton_order(p)
+    assert sorted(perm.tolist()) == list(range(p.shape[0]))
+    step_sorted = (p[perm][1:] - p[perm][:-1]).norm(dim=1).median()
+    step_unsorted = (p[1:] - p[:-1]).norm(dim=1).median()
+    assert float(step_sorted) < 0.15 * float(step_unsorted)
+    p2 = torch.rand(1000, 2)
+    assert sorted(morton_order(p2).tolist()) == list(range(1000))
