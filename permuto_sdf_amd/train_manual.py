@@ -74,11 +74,15 @@ class ManualTrainer(Trainer):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         assert self.touched, "ManualTrainer accumulates the lattice gradients in the touched-rows buffers"
+
+    def _hand_written_step_applies(self):
+        """The hand-written step is built on the fused compositing kernels (at most 256 samples per ray: foreground
+        max_nr_samples_per_ray + 2 * nr_samples_imp_sampling, background nr_samples_bg) and on the reference's default mode
+        (background network, no mask loss).  Anything else runs `Trainer._main_phase`: the same step as an autograd graph over
+        the per-operator chain -- slower, any ray length, `--with_mask` included."""
         hp = self.hp
-        if hp.nr_samples_bg > 256 or hp.max_nr_samples_per_ray + 2 * hp.nr_samples_imp_sampling > 256:
-            raise ValueError("ManualTrainer uses the fused compositing kernels: at most 256 samples per ray (foreground: "
-                             "max_nr_samples_per_ray + 2 * nr_samples_imp_sampling; background: nr_samples_bg); "
-                             "train_step.Trainer handles longer rays through the per-operator chain")
+        return (not self.with_mask and hp.nr_samples_bg <= 256
+                and hp.max_nr_samples_per_ray + 2 * hp.nr_samples_imp_sampling <= 256)
 
     def _unit_row(self, rows, N):
         """[rows, N] feature-major upstream gradient that selects output 0 (d sdf / d .)"""
@@ -108,11 +112,13 @@ class ManualTrainer(Trainer):
 
     # ------------------------------------------------------------------ one iteration of the main phase
     def _main_phase(self, reel, it, git, eikonal_weight):
+        if not self._hand_written_step_applies():
+            return Trainer._main_phase(self, reel, it, git, eikonal_weight)
         hp, dev = self.hp, self.dev
         cos_r = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
         forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
         with torch.no_grad():
-            o, d, gt, hit, img_idx = self._draw_rays(reel)
+            o, d, gt, hit, img_idx, _ = self._draw_rays(reel)
             fg, bg = self._samples(o, d, it, True)
             R = o.shape[0]
             n_fg = fg.samples_pos.shape[0]

@@ -72,6 +72,7 @@ class HyperParams:
     use_color_calibration = True
     eikonal_weight_late = 0.01           # from iter_start_reduce_curv on (:405)
     rgb_lattice_weight_decay_late = 1.0  # (:402-403)
+    mask_weight = 0.1                    # (:85) weight of the mask loss of `--with_mask` runs (:381-383)
     colorcal_weight_decay = 1e-1         # (:299)
 
 
@@ -358,12 +359,16 @@ class SyntheticReel:
 
 # ------------------------------------------------------------------------------------------------------ trainer
 class Trainer:
-    def __init__(self, device, hp=None, seed=0, touched_rows=True, reference_schedule=False, nr_images=49):
+    def __init__(self, device, hp=None, seed=0, touched_rows=True, reference_schedule=False, nr_images=49, with_mask=False):
         """reference_schedule: run the reference's whole schedule (sphere phase, LR warm-up / decay, late switches, colour
-        calibration over `nr_images` cameras: see the module docstring); False = the steady-state step only."""
+        calibration over `nr_images` cameras: see the module docstring); False = the steady-state step only.
+        with_mask: the reference's `--with_mask` mode (train_permuto_sdf.py:153-154,381-383; nerf_utils.py:519-522): no
+        background samples and no background network evaluation, the rendered colour is the foreground's alone, and the
+        per-ray weight sum is held to the mask of the image reel by a binary cross entropy (weight `mask_weight`)."""
         self.hp = hp or HyperParams()
         self.dev = torch.device(device)
         self.reference_schedule = bool(reference_schedule)
+        self.with_mask = bool(with_mask)
         torch.manual_seed(seed)  # identical replicas on every rank
         self.sdf, self.rgb, self.bg = SdfNet(self.hp).to(self.dev), RgbNet(self.hp).to(self.dev), BgNet().to(self.dev)
         self.colorcal = (Colorcal(nr_images, 0).to(self.dev)
@@ -395,6 +400,7 @@ class Trainer:
         self.nr_rays = self.hp.nr_rays
         self.iter = 0
         self.capture_grads = None     # set to {} to have step() record the gradients it hands to the optimiser
+        self._colour_window_t = 1.0   # the t the colour / background lattices' windows (`_win`, ones) currently hold
         self._late_seen = False       # set by the first iteration at / after iter_start_reduce_curv (acts from the next one on)
         self.last = {}
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
@@ -428,8 +434,8 @@ class Trainer:
         _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
         fg = self.grid.compute_samples_in_occupied_regions(o, d, te, tx, hp.min_dist_between_samples,
                                                            hp.max_nr_samples_per_ray, jitter).compact_to_valid_samples()
-        bg = RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius, self.sphere.m_center_tensor,
-                                           jitter, False)
+        bg = None if self.with_mask else RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius,
+                                                                       self.sphere.m_center_tensor, jitter, False)
         if fg.samples_pos.shape[0] == 0:
             return fg, bg
         fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it, key=self.iter))
@@ -451,25 +457,29 @@ class Trainer:
         fg, bg = self._samples(o, d, it, jitter)
         cc = self.colorcal if img_indices is not None else None
         R = o.shape[0]
+        w_sum = None
         if fg.samples_pos.shape[0] == 0:
             pred = torch.zeros(R, 3, device=self.dev)
             sdf_grad, bgT = torch.zeros(0, 3, device=self.dev), torch.ones(R, 1, device=self.dev)
+            w_sum = torch.zeros(R, 1, device=self.dev)
         else:
             sdf, sdf_grad, feat = self.sdf.sdf_and_gradient(fg.samples_pos, it)
             rgb = self.rgb(fg.samples_pos, fg.samples_dirs, sdf_grad, feat, cc, img_indices, fg.ray_start_end_idx)
             # a ray holds at most max_nr_samples_per_ray uniform + 2 rounds of importance samples
             per_ray = self.hp.max_nr_samples_per_ray + 2 * self.hp.nr_samples_imp_sampling
-            if per_ray <= 256:
+            if per_ray <= 256 and not self.with_mask:
                 pred, bgT = self.rgb.neus_render(fg, per_ray, sdf, sdf_grad, rgb, cos_anneal_ratio, forced_variance)
-            else:
-                w, _, bgT = self.rgb.neus_weights(fg, sdf, sdf_grad, cos_anneal_ratio, forced_variance)
+            else:       # the operator chain: any ray length, and the per-ray weight sum the mask loss needs
+                w, w_sum, bgT = self.rgb.neus_weights(fg, sdf, sdf_grad, cos_anneal_ratio, forced_variance)
                 pred = _Integrate.apply(fg, rgb, w)
+        if bg is None:                      # --with_mask: no background model (train_permuto_sdf.py:153-154)
+            return pred, sdf_grad, fg, w_sum
         rgb_bg, dens = self.bg(bg.samples_pos_4d, bg.samples_dirs, cc, img_indices, bg.ray_start_end_idx)
         if self.hp.nr_samples_bg <= 256:    # density activation, weights, integration and the composition: one launch per direction
             pred = nerf_composite(bg, self.hp.nr_samples_bg, dens, rgb_bg, pred, bgT.view(-1, 1))
         else:
             pred = pred + bgT.view(-1, 1) * _Integrate.apply(bg, rgb_bg, BgNet.nerf_weights(bg, dens.view(-1, 1)))
-        return pred, sdf_grad, fg
+        return pred, sdf_grad, fg, w_sum
 
     def _sphere_init_loss(self, it):
         """loss_sphere_init (permuto_sdf_utils.py:53-77 -> sdf_utils.py:60-83, dataset dtu): fit the SDF of a radius-0.3 sphere
@@ -494,9 +504,9 @@ class Trainer:
 
     def _draw_rays(self, reel):
         with torch.no_grad():
-            o, d, gt, _, img_idx = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
+            o, d, gt, mask, img_idx = PermutoSDF.random_rays_from_reel(reel, self.nr_rays)
             _, _, _, _, hit = self.sphere.ray_intersection(o, d)
-        return o, d, gt, hit, img_idx
+        return o, d, gt, hit, img_idx, mask
 
     def _main_phase(self, reel, it, git, eikonal_weight):
         """forward + losses of one iteration of the main phase as an autograd graph -> (loss, n_fg, nr_rays, False): the caller
@@ -504,9 +514,9 @@ class Trainer:
         hp = self.hp
         cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
         forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
-        o, d, gt, hit, img_idx = self._draw_rays(reel)
-        pred, sdf_grad, fg = self._render(o, d, it, cos_anneal_ratio, forced_variance,
-                                          img_indices=img_idx if self.colorcal is not None else None)
+        o, d, gt, hit, img_idx, gt_mask = self._draw_rays(reel)
+        pred, sdf_grad, fg, w_sum = self._render(o, d, it, cos_anneal_ratio, forced_variance,
+                                                 img_indices=img_idx if self.colorcal is not None else None)
         loss = l1_loss(pred, gt, hit)                                                      # rgb_loss, one launch
         n_fg = fg.samples_pos.shape[0]
         if n_fg:
@@ -519,6 +529,8 @@ class Trainer:
         loss = loss + offsurface_loss(sdf_off, 1e2) * hp.offsurface_weight
         if it >= hp.iter_start_reduce_curv:
             loss = loss + self.rgb.mlp.lipshitz_bound_full().mean() * hp.lipshitz_weight
+        if self.with_mask:                                                                 # train_permuto_sdf.py:381-383
+            loss = loss + F.binary_cross_entropy(w_sum.clip(1e-3, 1.0 - 1e-3), gt_mask) * hp.mask_weight
         self._refresh_and_adapt(it, git, n_fg)
         return loss, n_fg, o.shape[0], False
 
@@ -544,6 +556,14 @@ class Trainer:
         if in_sphere_init:
             loss = self._sphere_init_loss(it)
         else:
+            # rgb_nr_iters_for_c2f = background_nr_iters_for_c2f = 1 (train_permuto_sdf.py:102-103; models.py:368,496): the colour and
+            # background lattices see the window of t = 0.3 at annealing iteration 0 and are fully open from iteration 1 on
+            t_col = map_range_val(it, 0.0, 1.0, 0.3, 1.0)
+            if t_col != self._colour_window_t:
+                w = Coarse2Fine(24)(t_col).to(self.dev)
+                self.rgb._win.copy_(w)
+                self.bg._win.copy_(w)
+                self._colour_window_t = t_col
             loss, n_fg, nr_rays_used, grads_done = self._main_phase(reel, it, git, eikonal_weight)
             if late:
                 self._late_seen = True

@@ -143,3 +143,88 @@ def test_cfg2_full_batch_subset_matches_oracle(dev):
     mask = torch.ones(N, dtype=torch.bool, device=dev)
     mask[sub] = False
     assert float(d_feat[:, mask].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dy_kind", ["normal", "six_decades_and_an_outlier"])
+def test_cfg2_full_batch_dense_gradient_against_float64(dev, dy_kind):
+    """The error budget of the TIMED arithmetic with every one of the 2 097 152 samples carrying a non-zero upstream gradient
+    (the subset test above zeroes dY outside 65 536 samples): features -> split-fp16 MLP forward -> split-fp16 MLP backward
+    (dX, dW, db: accumulated over the whole batch) -> encode backward (lattice gradient), against a float64 evaluation of the
+    same chain on the GPU (torch float64 autograd through the unmodified Linear/GELU stack in chunks; float64 scatter of the
+    float64 feature gradient with the oracle's vertex rows and barycentric weights).  Bar: 5e-5 of the largest entry of each
+    gradient -- half the north_star tolerance (1e-4) -- so that the two-piece arithmetic keeps a margin at the benchmark size;
+    the measured margins are printed."""
+    import bench
+    from permuto_sdf_amd.encoding import encode_backward_raw, encode_forward_raw
+    from permuto_sdf_amd.hotpath import SdfHotPath
+    from permuto_sdf_amd.mlp import mlp_backward_raw, mlp_forward_raw, pack_params
+    L_, F_, T_ = 16, 2, 2 ** 18
+    hp = SdfHotPath(nr_levels=L_, hidden=64, out_channels=1, capacity=T_, device=dev, seed=9)
+    rs, _, _ = bench.make_batch(dev, 34)
+    pos = rs.samples_pos
+    N = pos.shape[0]
+    assert N == 2097152
+    cfg, enc, mlp = hp.enc.cfg, hp.enc, hp.mlp
+    with torch.no_grad():      # a lattice with visible magnitudes (the initialisation's 1e-5 would leave the features ~ 0)
+        enc.lattice_values.copy_(torch.randn(enc.lattice_values.shape, generator=torch.Generator().manual_seed(3)).to(dev) * 0.1)
+    win = torch.ones(L_, device=dev)
+    ws_d, bs_d = [l.weight for l in mlp.layers], [l.bias for l in mlp.layers]
+    g = torch.Generator().manual_seed(8)
+    dy = torch.randn(N, generator=g)
+    if dy_kind != "normal":
+        dy = dy * 10.0 ** (torch.rand(N, generator=g) * 6.0 - 3.0)
+        dy[123457] = 50.0 * float(dy.abs().max())
+    assert int((dy == 0).sum()) == 0
+    dY = dy.view(1, N).to(dev)
+    # ---- the timed kernels, full size, in one piece
+    feat = encode_forward_raw(cfg, pos, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win)
+    from permuto_sdf_amd.mlp import f16_forward_supported
+    f16 = hp.fwd_f16 and f16_forward_supported(mlp.dims)          # what SdfHotPath.forward (the bench) runs
+    sdf = mlp_forward_raw(mlp.dims, feat, pack_params(mlp.dims, ws_d, bs_d, f16=f16), f16=f16)
+    d_feat, dWs, dbs = mlp_backward_raw(mlp.dims, feat, ws_d, bs_d, dY, need_dx=True)
+    g_lat = torch.zeros_like(enc.lattice_values)
+    encode_backward_raw(cfg, pos, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
+                        d_feat, g_lat, None)
+    torch.cuda.synchronize()
+    assert last_path(2) in (2, 3) and last_path(0) == 2 and last_path(1) in (2, 4)
+    # ---- float64 on the GPU, chunked
+    mods = []
+    for i, l in enumerate(mlp.layers):
+        lin = torch.nn.Linear(l.weight.shape[1], l.weight.shape[0]).to(dev).double()
+        lin.weight.data.copy_(l.weight.detach().double())
+        lin.bias.data.copy_(l.bias.detach().double())
+        mods += [lin] + ([torch.nn.GELU()] if i < len(mlp.layers) - 1 else [])
+    net = torch.nn.Sequential(*mods)
+    lins = [m for m in mods if isinstance(m, torch.nn.Linear)]
+    g64 = torch.zeros(L_, T_, F_, dtype=torch.float64, device=dev)
+    sf = po.scale_factors(enc.scale_per_level, 3)
+    shifts = enc.random_shift_per_level.detach().cpu()
+    e_sdf = e_dx = 0.0
+    dx_max = 0.0
+    CH = 1 << 17
+    for c0 in range(0, N, CH):
+        sl = slice(c0, c0 + CH)
+        x = feat[:, sl].t().double().requires_grad_(True)
+        y = net(x)
+        y.backward(dY[:, sl].t().double())
+        e_sdf = max(e_sdf, float((sdf[0, sl].double() - y[:, 0]).abs().max()))
+        e_dx = max(e_dx, float((d_feat[:, sl].t().double() - x.grad).abs().max()))
+        dx_max = max(dx_max, float(x.grad.abs().max()))
+        pc = pos[sl].cpu()
+        for l in range(L_):
+            rem0, rank, bary = po.simplex(pc, shifts[l], sf[l])
+            idx = po.vertex_indices(rem0, rank, T_).to(dev)
+            bw = bary[:, :4].to(dev).double()
+            gl = x.grad[:, l * F_:(l + 1) * F_]
+            for r in range(4):
+                g64[l].index_add_(0, idx[:, r], gl * bw[:, r:r + 1])
+    errs = {"sdf": e_sdf / float(sdf.abs().max()), "d_features": e_dx / dx_max,
+            "lattice_grad": float((g_lat.double() - g64).abs().max() / g64.abs().max())}
+    for i, lin in enumerate(lins):
+        errs["dW%d" % i] = float((dWs[i].double() - lin.weight.grad).abs().max() / lin.weight.grad.abs().max())
+        errs["db%d" % i] = float((dbs[i].double() - lin.bias.grad).abs().max() / lin.bias.grad.abs().max())
+    per_level = [float((g_lat[l].double() - g64[l]).abs().max() / g64[l].abs().max()) for l in range(L_)]
+    print("cfg 2, all 2 097 152 samples carry gradient (%s), kernels (fwd %d, bwd %d) vs float64: %s; lattice per level max %.1e"
+          % (dy_kind, last_path(2), last_path(1), " ".join("%s %.1e" % kv for kv in errs.items()), max(per_level)))
+    assert max(errs.values()) < 5e-5, errs
+    assert max(per_level) < TOL, per_level

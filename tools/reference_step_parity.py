@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""BASELINE config 4, one optimisation step, THREE ways on identical weights / rays / random streams:
+
+  reference : the reference's own step -- the lines `TIME_START("run_net")` .. `loss+=loss_mask*...` of train()
+              (permuto_sdf_py/train_permuto_sdf.py:338-383), cut out of the UNMODIFIED source file by their markers, executed
+              with the reference's own `run_net`, model classes (`SDF`, `RGB`, `NerfHash`, `Colorcal`: torch.nn.Sequential MLPs,
+              the reference's autograd Functions of volume_rendering_funcs.py) over this repository's drop-in operators,
+              UNFUSED (PSDF_FUSE_REFERENCE_MLPS off), differentiated by `loss.backward()` -- torch autograd;
+  manual    : permuto_sdf_amd.train_manual.ManualTrainer.step (hand-written forward + backward over the raw kernels);
+  autograd  : permuto_sdf_amd.train_step.Trainer.step (torch autograd over the fused operators).
+
+Compared: the loss, every dense parameter gradient, the three lattice gradients -- as the optimiser is about to see them.
+Also the sphere-initialisation step (train_permuto_sdf.py:322-330: the reference's own `loss_sphere_init`).
+
+What is shared: the networks' state (written in the reference's checkpoint layout and loaded by the reference's classes),
+the occupancy grid, the rays (`PermutoSDF.random_rays_from_reel` drawn once), torch's generators (seeded alike before each
+run: the curvature term's `randn_like` and `rand_points_inside` draw the same numbers) and the three PCG32 jitter generators
+of the samplers.  What is NOT shared: everything downstream -- each runner makes its own samples, importance samples, networks
+evaluations and gradients.
+
+The reference checkout is found at $PSDF_REFERENCE, /root/reference or <repo>/_refcopy.  Prints one JSON object.
+
+    python tools/reference_step_parity.py [--out FILE] [--modes early,late,mask,sphere]
+"""
+import argparse
+import contextlib
+import importlib.util
+import json
+import os
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find_reference():
+    for c in (os.environ.get("PSDF_REFERENCE"), "/root/reference", os.path.join(ROOT, "_refcopy")):
+        if c and os.path.isdir(os.path.join(c, "permuto_sdf_py")):
+            return c
+    return None
+
+
+def setup_paths(ref):
+    for p in (ref, os.path.join(ROOT, "compat"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    spec = importlib.util.spec_from_file_location("psdf_compat_sitecustomize", os.path.join(ROOT, "compat", "sitecustomize.py"))
+    spec.loader.exec_module(importlib.util.module_from_spec(spec))
+
+
+def extract_loss_block(path):
+    """the reference's step between `TIME_START("run_net")` and the no-grad bookkeeping block that follows the losses
+    (`with torch.set_grad_enabled(False):` + `#update occupancy`): source text, first and last line number (1-based)"""
+    src = open(path).read().splitlines()
+    i0 = next(i for i, l in enumerate(src) if l.strip() == 'TIME_START("run_net")')
+    i1 = next(i for i in range(i0, len(src) - 1)
+              if src[i].strip() == "with torch.set_grad_enabled(False):" and "#update occupancy" in src[i + 1])
+    block = textwrap.dedent("\n".join(src[i0:i1]))
+    assert "run_net(args, hyperparams" in block and "rgb_loss(gt_selected, pred_rgb" in block and "loss_mask" in block
+    return block, i0 + 1, i1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--modes", default="early,late,mask,sphere")
+    ap.add_argument("--sphere-iters", type=int, default=200, help="sphere-initialisation iterations before the snapshot")
+    ap.add_argument("--warm-iters", type=int, default=17, help="main-phase iterations before the snapshot (>= 9: one grid refresh)")
+    a = ap.parse_args()
+    ref = find_reference()
+    if ref is None:
+        print(json.dumps({"skipped": "no reference checkout (PSDF_REFERENCE, /root/reference, <repo>/_refcopy)"}))
+        return
+    os.environ.pop("PSDF_FUSE_REFERENCE_MLPS", None)          # the reference's evaluators stay torch.nn
+    setup_paths(ref)
+    import torch
+    assert torch.cuda.is_available(), "needs the GPU"
+    dev = torch.device("cuda", 0)
+    from permuto_sdf_amd import checkpoint, parallel
+    from permuto_sdf_amd.bridge import OccupancyGrid, PermutoSDF, RaySampler, VolumeRendering
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel, Trainer
+
+    # ---- our trainers (built under torch's normal defaults), a short schedule up to a snapshot
+    def make(cls, with_mask):
+        hp = HyperParams()
+        hp.nr_iter_sphere_fit = a.sphere_iters
+        return cls(dev, hp=hp, seed=0, reference_schedule=True, nr_images=12, with_mask=with_mask)
+
+    reel = SyntheticReel(dev, nr_images=12, height=200, width=300)
+    reel.mask_reel = (torch.rand(reel.mask_reel.shape, generator=torch.Generator().manual_seed(5)) > 0.4).float().to(dev)
+    pcgs = (OccupancyGrid._rng, RaySampler._rng, VolumeRendering._rng)
+
+    import permuto_sdf_py.train_permuto_sdf as T          # module level: torch.manual_seed(0), default tensor type -> cuda
+
+    @contextlib.contextmanager
+    def default_tensor(cuda):
+        torch.set_default_tensor_type(torch.cuda.FloatTensor if cuda else torch.FloatTensor)
+        try:
+            yield
+        finally:
+            torch.set_default_tensor_type(torch.cuda.FloatTensor)
+
+    block, l0, l1 = extract_loss_block(os.path.join(ref, "permuto_sdf_py", "train_permuto_sdf.py"))
+    code = compile(block, "<reference train_permuto_sdf.py:%d-%d>" % (l0, l1), "exec")
+    out = {"reference": ref, "reference_block_lines": [l0, l1], "device": torch.cuda.get_device_name(0), "cases": {}}
+
+    def rel(x, y):
+        x, y = x.detach().double().flatten(), y.detach().double().flatten()
+        d = (x - y).abs()
+        return {"max_rel": float(d.max() / y.abs().max().clamp_min(1e-30)), "l2_rel": float(d.norm() / y.norm().clamp_min(1e-30)),
+                "ref_absmax": float(y.abs().max())}
+
+    def our_named_grads(tr):
+        names = {}
+        for prefix, m in (("sdf", tr.sdf), ("rgb", tr.rgb), ("bg", tr.bg), ("colorcal", tr.colorcal)):
+            if m is not None:
+                for k, p in m.named_parameters():
+                    names[id(p)] = prefix + "." + k
+        cap = tr.capture_grads
+        buffered = {id(m.encoding.lattice_values) for m in (tr.sdf, tr.rgb, tr.bg)}
+        dense = [p for p in tr.params if id(p) not in buffered]
+        g = {names[id(p)]: gr for p, gr in zip(dense, cap["dense"])}
+        for m, gr in zip((tr.sdf, tr.rgb, tr.bg), cap["lattices"]):
+            g[names[id(m.encoding.lattice_values)]] = gr
+        return g, float(cap["loss"])
+
+    def ref_named_grads(models):
+        g = {}
+        for kind, m in models.items():
+            if m is None:
+                continue
+            d = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters() if p.requires_grad}
+            if kind != "colorcal":
+                d = checkpoint.from_reference_keys(kind, d)
+            for k, v in d.items():
+                g[kind + "." + k] = v
+        return g
+
+    for with_mask in (False, True):
+        modes = [m for m in a.modes.split(",") if (m == "mask") == with_mask]
+        if not modes:
+            continue
+        with default_tensor(False):
+            trm, tra = make(ManualTrainer, with_mask), make(Trainer, with_mask)
+            reel.has_mask = with_mask
+            for p in pcgs:
+                p.__init__()
+            for _ in range(a.sphere_iters + a.warm_iters):
+                trm.step(reel)
+            n0 = a.sphere_iters
+            # ---- snapshot: networks (reference checkpoint layout), grid, ray count, generators
+            state = {k: {n: v.detach().clone() for n, v in m.state_dict().items()}
+                     for k, m in (("sdf", trm.sdf), ("rgb", trm.rgb), ("bg", trm.bg), ("colorcal", trm.colorcal))}
+            grid_v, grid_o = trm.grid.get_grid_values().clone(), trm.grid.get_grid_occupancy().clone()
+            pcg_state = [(p.state, p.inc) for p in pcgs]
+            nr_rays = trm.nr_rays
+            parallel.seed_generators(12345, dev)
+            o, d, gt, mask, img_idx = PermutoSDF.random_rays_from_reel(reel, nr_rays)
+            _, _, _, _, hit = trm.sphere.ray_intersection(o, d)
+            rays = (o, d, gt, mask, img_idx, hit)
+
+        def restore(tr):
+            for k, m in (("sdf", tr.sdf), ("rgb", tr.rgb), ("bg", tr.bg), ("colorcal", tr.colorcal)):
+                m.load_state_dict(state[k])
+            tr.grid.set_grid_values(grid_v.clone())
+            tr.grid.set_grid_occupancy(grid_o.clone())
+            for p, (s, i) in zip(pcgs, pcg_state):
+                p.state, p.inc = s, i
+            tr.nr_rays = nr_rays
+            tr._late_seen = False
+            tr._draw_rays = lambda reel_: (o, d, gt, hit, img_idx, mask)
+            for t in tr.touched:
+                t.grad.zero_()
+                t.touched.zero_()
+            for gb in tr.grad_buffers:
+                gb.zero()
+
+        for mode in modes:
+            it = {"early": 2001, "late": 52001, "mask": 2001, "sphere": None}[mode]
+            git = (n0 + it) if it is not None else 101        # neither is a multiple of 8: no grid refresh inside the step
+            assert git % 8 != 0
+            seed = parallel.step_seed(trm._seed, 0, git)
+            ours = {}
+            with default_tensor(False):
+                for name, tr in (("manual", trm), ("autograd", tra)):
+                    restore(tr)
+                    tr.iter = git
+                    tr.capture_grads = {}
+                    tr.step(reel)
+                    torch.cuda.synchronize()
+                    ours[name] = our_named_grads(tr)
+                    ours[name] += (dict(tr.last),)
+                    tr.capture_grads = None
+            # ---- the reference
+            with default_tensor(True):
+                for p, (s, i) in zip(pcgs, pcg_state):
+                    p.state, p.inc = s, i
+                aabb = T.create_bb_for_dataset("dtu")
+                hp = T.hyperparams
+                model_sdf = T.SDF(in_channels=3, boundary_primitive=aabb, geom_feat_size_out=hp.sdf_geom_feat_size,
+                                  nr_iters_for_c2f=hp.sdf_nr_iters_for_c2f).to("cuda")
+                model_rgb = T.RGB(in_channels=3, boundary_primitive=aabb, geom_feat_size_in=hp.sdf_geom_feat_size,
+                                  nr_iters_for_c2f=hp.rgb_nr_iters_for_c2f).to("cuda")
+                model_bg = T.NerfHash(4, boundary_primitive=aabb, nr_iters_for_c2f=hp.background_nr_iters_for_c2f).to("cuda")
+                model_colorcal = T.Colorcal(reel.rgb_reel.shape[0], 0)
+                assert type(model_sdf.mlp_sdf) is torch.nn.Sequential, "the reference's evaluators must stay unfused here"
+                model_sdf.load_state_dict(checkpoint.to_reference_keys("sdf", state["sdf"]))
+                model_rgb.load_state_dict(checkpoint.to_reference_keys("rgb", state["rgb"]))
+                model_bg.load_state_dict(checkpoint.to_reference_keys("bg", state["bg"]))
+                model_colorcal.load_state_dict(state["colorcal"])
+                occupancy_grid = T.OccupancyGrid(256, 1.0, [0, 0, 0])
+                occupancy_grid.set_grid_values(grid_v.clone())
+                occupancy_grid.set_grid_occupancy(grid_o.clone())
+                for m in (model_sdf, model_rgb, model_bg):
+                    m.train(True)
+                parallel.seed_generators(seed, dev)
+                models = {"sdf": model_sdf, "rgb": model_rgb, "bg": model_bg, "colorcal": model_colorcal}
+                terms = {}
+                if mode == "sphere":
+                    loss, loss_sdf, loss_eik = T.loss_sphere_init("dtu", 30000, aabb, model_sdf, git)    # :323
+                    terms = {"loss_sdf": float(loss_sdf), "loss_eikonal": float(loss_eik)}
+                else:
+                    args = argparse.Namespace(with_mask=with_mask, dataset="dtu")
+                    ns = dict(vars(T))
+                    loss0, loss_rgb, loss_eikonal, loss_curvature, loss_lipshitz = T.init_losses()
+                    ns.update(args=args, hyperparams=hp, ray_origins=o, ray_dirs=d, img_indices=img_idx, gt_selected=gt, gt_mask=mask,
+                              does_ray_intersect_box=hit, model_sdf=model_sdf, model_rgb=model_rgb, model_bg=model_bg,
+                              model_colorcal=model_colorcal, occupancy_grid=occupancy_grid, iter_nr_for_anneal=it,
+                              cos_anneal_ratio=T.map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0),
+                              forced_variance=T.map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish),
+                              loss=loss0, loss_rgb=loss_rgb, loss_eikonal=loss_eikonal, loss_curvature=loss_curvature,
+                              loss_lipshitz=loss_lipshitz)
+                    old_eik = hp.eikonal_weight
+                    exec(code, ns)
+                    assert hp.eikonal_weight == old_eik
+                    loss = ns["loss"]
+                    for k in ("loss_rgb", "loss_eikonal", "loss_curvature", "loss_offsurface_high_sdf", "loss_mask"):
+                        if k in ns and torch.is_tensor(ns[k]):
+                            terms[k] = float(ns[k].mean())
+                    terms["nr_fg_samples"] = int(ns["fg_ray_samples_packed"].samples_pos.shape[0])
+                loss.backward()
+                torch.cuda.synchronize()
+                gref = ref_named_grads(models)
+            case = {"iter_nr_for_anneal": it, "global_iter": git, "nr_rays": int(o.shape[0]), "reference_loss": float(loss),
+                    "reference_terms": terms}
+            for name, (g, l, last) in ours.items():
+                rows = {}
+                for k in sorted(gref):
+                    if k not in g:
+                        rows[k] = {"missing": True}
+                        continue
+                    if float(gref[k].abs().max()) == 0.0 and float(g[k].abs().max()) == 0.0:
+                        continue          # no gradient on either side (forced variance, colour nets in the sphere phase ...)
+                    rows[k] = rel(g[k], gref[k])
+                extra = sorted(set(g) - set(gref))
+                case[name] = {"loss": l, "loss_rel": abs(l - float(loss)) / abs(float(loss)), "nr_fg_samples": last.get("nr_fg_samples"),
+                              "grads": rows, "not_in_reference": extra,
+                              "worst_dense": max((v["max_rel"] for k, v in rows.items() if "lattice" not in k and "max_rel" in v), default=0.0),
+                              "worst_lattice": max((v["max_rel"] for k, v in rows.items() if "lattice" in k and "max_rel" in v), default=0.0),
+                              "worst_lattice_l2": max((v["l2_rel"] for k, v in rows.items() if "lattice" in k and "l2_rel" in v), default=0.0)}
+            out["cases"][mode] = case
+            del gref
+    s = json.dumps(out, indent=1)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        open(a.out, "w").write(s)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -192,7 +192,7 @@ def main():
         report[name] = {"keys": len(sd), "identical_after_round_trip": bool(same)}
     log["checkpoint_round_trip_reference_classes"] = report
     print("[checkpoints]", report, flush=True)
-    pred2, _, fg2 = trainer._render(o, d, it_eval, cos_anneal, forced_var, jitter=False)
+    pred2, _, fg2, _ = trainer._render(o, d, it_eval, cos_anneal, forced_var, jitter=False)
     num = (pred2.detach() - pred_rgb.detach()).abs()
     log["run_net_vs_trainer_render"] = {
         "max_abs": float(num.max()), "max_rel_to_max": float(num.max() / pred_rgb.abs().max()),

@@ -14,6 +14,56 @@ from permuto_sdf_amd import parallel  # noqa: E402
 from permuto_sdf_amd.train_step import SyntheticReel, Trainer  # noqa: E402
 
 
+def measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=0):
+    """it/s of the cfg-4 step on `dev` for THIS process group (parallel.init() already called): every rank runs it, the
+    returned dict is complete on rank 0.  The timed block is repeated and the median repetition reported (the step is host
+    bound: the rate moves by +-10 % with the state of the box's CPU); max over ranks per repetition."""
+    rank, world = parallel.rank(), parallel.world_size()
+    if manual:
+        from permuto_sdf_amd.train_manual import ManualTrainer
+        tr = ManualTrainer(dev)
+    else:
+        tr = Trainer(dev)
+    reel = SyntheticReel(dev)
+    tr.iter = start_iter
+    for _ in range(warmup):
+        tr.step(reel)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    reps = []
+    samples = 0
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        samples = 0
+        for _ in range(steps):
+            tr.step(reel)
+            samples += tr.last["nr_fg_samples"]
+        barrier()
+        e = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(e, op=torch.distributed.ReduceOp.MAX)
+        reps.append(float(e.item()))
+    el = sorted(reps)[len(reps) // 2]
+    if world > 1:   # replicas must have stayed identical: same parameters on every rank after the run
+        chk = torch.stack([p.detach().double().sum() for p in tr.params]).to(dev)
+        lo, hi = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        assert torch.equal(lo, hi), "replicas diverged"
+    return {"metric": "train iters/sec (cfg 4: SDF + colour + background step, synthetic reel)",
+            "value": steps / el, "unit": "it/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": el / steps * 1e3,
+            "fg_samples_per_step_per_gpu": samples / steps, "rays_last_step": tr.last["nr_rays"],
+            "scaling": "weak", "dtype": "f32", "data": "synthetic", "start_iter": start_iter,
+            "backward": "hand-written (train_manual.py)" if manual else "torch autograd over the fused operators",
+            "repeats_it_per_s": [round(steps / r, 1) for r in reps]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=60)
@@ -28,53 +78,9 @@ def main():
         local = 0   # development aid (with PSDF_DIST_BACKEND=gloo): every rank on cuda:0, exercises the N>1 path
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if args.manual:
-        from permuto_sdf_amd.train_manual import ManualTrainer
-        tr = ManualTrainer(dev)
-    else:
-        tr = Trainer(dev)
-    reel = SyntheticReel(dev)
-    tr.iter = args.start_iter
-    for _ in range(args.warmup):
-        tr.step(reel)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-    # the step is host bound: the rate moves by +-10 % with the state of the box's CPU, so the timed block is repeated and
-    # the line reports the median repetition (all of them under "repeats_it_per_s")
-    reps = []
-    samples = 0
-    for _ in range(args.repeats):
-        barrier()
-        t0 = time.perf_counter()
-        samples = 0
-        for _ in range(args.steps):
-            tr.step(reel)
-            samples += tr.last["nr_fg_samples"]
-        barrier()
-        e = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
-            torch.distributed.all_reduce(e, op=torch.distributed.ReduceOp.MAX)
-        reps.append(float(e.item()))
-    el = torch.tensor([sorted(reps)[len(reps) // 2]], dtype=torch.float64, device=dev)
-    if world > 1:   # replicas must have stayed identical: same parameters on every rank after the run
-        chk = torch.stack([p.detach().double().sum() for p in tr.params]).cpu()
-        lo, hi = chk.clone(), chk.clone()
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        assert torch.equal(lo, hi), "replicas diverged"
+    res = measure(dev, args.manual, args.steps, args.warmup, args.repeats, args.start_iter)
     if rank == 0:
-        el = float(el.item())
-        print(json.dumps({"metric": "train iters/sec (cfg 4: SDF + colour + background step, synthetic reel)",
-                          "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-                          "fg_samples_per_step_per_gpu": samples / args.steps, "rays_last_step": tr.last["nr_rays"],
-                          "scaling": "weak", "dtype": "f32", "data": "synthetic", "start_iter": args.start_iter,
-                          "backward": "hand-written (train_manual.py)" if args.manual else "torch autograd over the fused operators",
-                          "repeats_it_per_s": [round(args.steps / r, 1) for r in reps]}))
+        print(json.dumps(res))
     parallel.shutdown()
 
 
