@@ -378,6 +378,10 @@ def main():
         if world > 1:
             from permuto_sdf_amd.parallel import _mode_default
             out["dp"] = {"per_rank": per_rank, "reduce": _mode_default() + (" (reduce-scatter + all-gather per bucket)" if _mode_default() == "reduce_scatter" else ""),
+                         "optimizer": (hp.last_dp or {}).get("optimizer", "replicated"),
+                         "optimizer_note": "sharded: the lattice gradient is reduce-scattered in place, every rank runs AdamW on the "
+                                           "1/world of the table it owns and the PARAMETERS are all-gathered (parallel.ShardedUpdate; "
+                                           "PSDF_DP_OPTIMIZER=replicated: gradient all-gather, every rank updates everything)",
                          "bucket_bytes": getattr(hp, "last_bucket_bytes", None), "backend": torch.distributed.get_backend(),
                          "note": "buckets: MLP gradients first (overlap the encode backward), then the lattice gradient in two level "
                                  "ranges (the first range travels while the second is computed); comm_wait_ms = what the step still "

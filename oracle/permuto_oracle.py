@@ -216,9 +216,11 @@ def simplex(points, shift, sf):
     """Vectorised `simplex_scalar` for one level.  points [N,P] fp32 (may require grad).
     Returns rem0 [N,P+1] int64, rank [N,P+1] int64, bary [N,P+2] fp32 (differentiable wrt points)."""
     N, P = points.shape
+    dev = points.device      # (tests may run the restatement on a GPU tensor: same IEEE operations, elementwise, no contraction)
+    shift, sf = torch.as_tensor(shift).to(dev), torch.as_tensor(sf).to(dev)
     x = (points + shift) * sf
     cols = [None] * (P + 1)
-    sm = torch.zeros(N, dtype=points.dtype)
+    sm = torch.zeros(N, dtype=points.dtype, device=dev)
     for i in range(P, 0, -1):
         cf = x[:, i - 1]
         cols[i] = sm - float(i) * cf
@@ -234,7 +236,7 @@ def simplex(points, shift, sf):
         rem0 = torch.where((up - Ed) < (Ed - down), up, down).to(torch.int64)
         s = torch.div(rem0.sum(1), P + 1, rounding_mode="trunc")
         d = Ed - rem0.float()
-        rank = torch.zeros(N, P + 1, dtype=torch.int64)
+        rank = torch.zeros(N, P + 1, dtype=torch.int64, device=dev)
         for i in range(P):
             for j in range(i + 1, P + 1):
                 lt = (d[:, i] < d[:, j]) if _tie_later() else (d[:, i] <= d[:, j])
@@ -245,8 +247,8 @@ def simplex(points, shift, sf):
         big = rank > P
         rank = rank + neg * (P + 1) - big * (P + 1)
         rem0 = rem0 + neg * (P + 1) - big * (P + 1)
-    bary = torch.zeros(N, P + 2, dtype=points.dtype)
-    rows = torch.arange(N)
+    bary = torch.zeros(N, P + 2, dtype=points.dtype, device=dev)
+    rows = torch.arange(N, device=dev)
     for i in range(P + 1):
         delta = ((E[:, i] - rem0[:, i].float()).double() * inv).to(points.dtype)
         plus = torch.zeros_like(bary)
@@ -265,7 +267,7 @@ def vertex_indices(rem0, rank, capacity):
     P = P1 - 1
     idx = []
     for r in range(P + 1):
-        h = torch.zeros(N, dtype=torch.int64)
+        h = torch.zeros(N, dtype=torch.int64, device=rem0.device)
         for i in range(P):
             k = rem0[:, i] + r - (rank[:, i] > (P - r)).to(torch.int64) * (P + 1)
             h = (h + (k & U32)) & U32

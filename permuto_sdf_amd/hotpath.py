@@ -46,6 +46,9 @@ class SdfHotPath:
         self.want_rgb_grad = True
         import os
         self.fwd_f16 = os.environ.get("PSDF_MLP_FWD_SPLIT", "f16") != "bf16"
+        # data parallel: the lattice is updated by its owners and the PARAMETERS are all-gathered (parallel.ShardedUpdate)
+        self.shard_optimizer = parallel.sharded_optimizer_default()
+        self.last_dp = None
 
     @staticmethod
     def _max_per_ray(rs):
@@ -119,6 +122,26 @@ class SdfHotPath:
         if self.events is not None:
             self.events["mlp_bwd"][1].record()
         buckets = parallel.GradientBuckets()
+        su = parallel.ShardedUpdate()
+        sharded = reduce and optimizer_step and self.shard_optimizer and parallel.collectives_active()
+        lat_owned, lat_mine = [], []           # element ranges of the flat lattice: updated here / all-gathered from here
+        per_level = self.enc.lattice_values[0].numel()
+
+        def reduce_lattice(l0, l1):
+            """the gradient of levels [l0, l1) is final: send it on its way"""
+            if not reduce:
+                return
+            own = su.reduce_scatter(g_lat[l0:l1].view(-1), unit=4) if sharded else None
+            base = l0 * per_level
+            if own is None:                    # replicated for this range: all ranks get the sum and update all of it
+                buckets.reduce([g_lat[l0:l1]])
+                if sharded:
+                    lat_owned.append((base, l1 * per_level))
+            else:
+                n = (l1 - l0) * per_level
+                lat_owned.extend((base + lo, base + hi) for lo, hi in
+                                 (parallel.shard_bounds(n, 4, rank_=r) for r in su.virtual_ranks()))
+                lat_mine.append((base, l1 * per_level, own))
         if reduce:
             buckets.reduce(dWs + dbs)          # small bucket first: overlaps the encoding backward
         g_lat = torch.zeros_like(self.enc.lattice_values)
@@ -139,13 +162,11 @@ class SdfHotPath:
             cut = max(1, min(L_ - 1, (3 * L_ + 4) // 8))
             for l0, l1 in ((0, cut), (cut, L_)):
                 self._encode_backward_levels(rs.samples_pos, d_feat, g_lat, l0, l1)
-                if reduce:
-                    buckets.reduce([g_lat[l0:l1]])
+                reduce_lattice(l0, l1)
         else:
             encode_backward_raw(cfg, rs.samples_pos, self.enc.lattice_values, self.enc.scale_factor,
                                 self.enc.random_shift_per_level, self.window, d_feat, g_lat, None)
-            if reduce:
-                buckets.reduce([g_lat])
+            reduce_lattice(0, cfg.nr_levels)
         if self.events is not None:
             self.events["enc_bwd"][1].record()
         if reduce:
@@ -154,14 +175,22 @@ class SdfHotPath:
             if self.events is not None and "comm_wait" in self.events:
                 self.events["comm_wait"][0].record()
             buckets.finish()
+            su.wait()
             if self.events is not None and "comm_wait" in self.events:
                 self.events["comm_wait"][1].record()
-            self.last_bucket_bytes = list(buckets.bytes)
+            self.last_bucket_bytes = list(buckets.bytes) + list(su.bytes)
         grads = [g_lat] + [t for pair in zip(dWs, dbs) for t in pair]
         if optimizer_step:
             for p, g in zip(self.params, grads):
                 p.grad = g
-            self.opt.step(grad_scale=1.0 / parallel.world_size())
+            lat = self.enc.lattice_values
+            self.opt.step(grad_scale=1.0 / parallel.world_size(), owned={lat: lat_owned} if (sharded and lat_owned) else None)
+            if sharded and lat_mine:           # the owners' bytes to everybody (g_lat outside a rank's own ranges is NOT the sum)
+                flat = lat.data.view(-1)
+                for b0, b1, own in lat_mine:
+                    su.all_gather(flat[b0:b1], own)
+                su.wait()
+            self.last_dp = {"optimizer": "sharded" if (sharded and lat_mine) else "replicated"}
         return dict(g_rgb=g_rgb, g_one_minus=g_om, g_alpha=g_alpha, g_sdf=g_sdf, grads=grads)
 
     def _encode_backward_levels(self, pos, d_feat, g_lat, l0, l1):

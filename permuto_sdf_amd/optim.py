@@ -8,6 +8,7 @@ from . import _lib as L
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.generation = 0     # bumped by every step(): the kernels write the parameters behind torch's version counters
 
     SMALL = 1 << 16  # tensors below this many elements are batched into one launch (64 per launch)
 
@@ -40,8 +41,15 @@ class FusedAdamW(torch.optim.Optimizer):
             self._rebuild_active(p)
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, owned=None):
+        """owned (data parallel, parallel.ShardedUpdate): {param: [(lo, hi), ...]} -- element ranges of the FLAT parameter that
+        this rank updates; the rest of such a parameter is left alone (its owner's bytes arrive with the all-gather that follows)
+        and, for a touched-rows parameter, the gradient buffer and touched map outside the ranges are cleared (they hold this
+        rank's local contributions, which the reduce-scatter has already delivered to their owners).  Ranges are 4-element
+        aligned (touched-rows parameters: block aligned).  Moments of ranges a rank never owns stay zero and are never read."""
         import ctypes
+        owned = owned or {}
+        self.generation += 1
         for group in self.param_groups:
             b1, b2 = group["betas"]
             small = {}   # step count -> [(p, g, m, v)]
@@ -59,18 +67,33 @@ class FusedAdamW(torch.optim.Optimizer):
                         # the buffer (the forward marked its row blocks already), so that no gradient is ever silently lost
                         tr.grad.add_(p.grad)
                         p.grad = None
-                    if group["weight_decay"] != 0.0:       # every row moves: dense update from the same buffer
-                        L.call("psdf_adamw_step", L.c_l(p.numel()), L.ptr(p), L.ptr(tr.grad), L.ptr(st["exp_avg"]),
-                               L.ptr(st["exp_avg_sq"]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
-                               L.c_f(group["weight_decay"]), L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())
-                        tr.grad.zero_()
-                        tr.active.fill_(1)
-                        tr.touched.zero_()
-                    else:
-                        L.call("psdf_adamw_step_blocks", L.c_l(tr.touched.numel()), L.c_i(tr.block_elems), L.ptr(p),
-                               L.ptr(tr.grad), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), L.ptr(tr.touched),
-                               L.ptr(tr.active), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
-                               L.c_i(st["step"]), L.c_f(float(grad_scale)), L.c_i(1), L.stream())
+                    be = tr.block_elems
+                    ranges = owned.get(p, [(0, p.numel())])
+                    pf, gf, mf, vf = p.view(-1), tr.grad.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1)
+                    tf, af = tr.touched.view(-1), tr.active.view(-1)
+                    for lo, hi in ranges:
+                        if lo % be or hi % be:
+                            raise L.PsdfError("owned ranges of a touched-rows parameter must be aligned to its row blocks")
+                        blo, bhi = lo // be, hi // be
+                        if group["weight_decay"] != 0.0:       # every row moves: dense update from the same buffer
+                            L.call("psdf_adamw_step", L.c_l(hi - lo), L.ptr(pf[lo:hi]), L.ptr(gf[lo:hi]), L.ptr(mf[lo:hi]),
+                                   L.ptr(vf[lo:hi]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
+                                   L.c_f(group["weight_decay"]), L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())
+                            gf[lo:hi].zero_()
+                            af[blo:bhi].fill_(1)
+                            tf[blo:bhi].zero_()
+                        else:
+                            L.call("psdf_adamw_step_blocks", L.c_l(bhi - blo), L.c_i(be), L.ptr(pf[lo:hi]), L.ptr(gf[lo:hi]),
+                                   L.ptr(mf[lo:hi]), L.ptr(vf[lo:hi]), L.ptr(tf[blo:bhi]), L.ptr(af[blo:bhi]),
+                                   L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
+                                   L.c_i(st["step"]), L.c_f(float(grad_scale)), L.c_i(1), L.stream())
+                    if p in owned:      # what lies outside: local contributions whose sums live with their owners
+                        prev = 0
+                        for lo, hi in sorted(ranges) + [(p.numel(), p.numel())]:
+                            if lo > prev:
+                                gf[prev:lo].zero_()
+                                tf[prev // be:lo // be].zero_()
+                            prev = max(prev, hi)
                     continue
                 if p.grad is None:
                     continue
@@ -83,6 +106,15 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if p in owned:          # sharded dense update: this rank's ranges only
+                    pf, gf, mf, vf = p.view(-1), g.view(-1), st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1)
+                    for lo, hi in owned[p]:
+                        if lo % 4 or hi % 4:
+                            raise L.PsdfError("owned ranges must be aligned to 4 elements")
+                        L.call("psdf_adamw_step", L.c_l(hi - lo), L.ptr(pf[lo:hi]), L.ptr(gf[lo:hi]), L.ptr(mf[lo:hi]),
+                               L.ptr(vf[lo:hi]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
+                               L.c_f(group["weight_decay"]), L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())
+                    continue
                 aligned = all(t.data_ptr() % 16 == 0 for t in (p, g, st["exp_avg"], st["exp_avg_sq"]))
                 if p.numel() < self.SMALL and aligned:
                     small.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))

@@ -302,6 +302,98 @@ class GradientBuckets:
         self.pending = []
 
 
+def shard_bounds(n, unit=1, world=None, rank_=None):
+    """[lo, hi) of this rank's share when `n` elements are cut into `world` equal, contiguous, `unit`-aligned parts -- or None
+    when they cannot be (n is not a multiple of world * unit): the caller then keeps the replicated update for that tensor."""
+    world = world_size() if world is None else int(world)
+    r = rank() if rank_ is None else int(rank_)
+    if n % (world * unit) != 0:
+        return None
+    per = n // world
+    return r * per, (r + 1) * per
+
+
+def sharded_optimizer_default():
+    """PSDF_DP_OPTIMIZER = sharded (default) | replicated"""
+    return os.environ.get("PSDF_DP_OPTIMIZER", "sharded") == "sharded"
+
+
+class ShardedUpdate:
+    """The optimiser SHARDED over the ranks for the large tensors (the lattices; ZeRO-1 in the usual vocabulary).
+
+    Replicated update (GradientBuckets): reduce-scatter the gradient, all-gather the GRADIENT, every rank runs AdamW over the
+    whole 50-MB table -- world times the same arithmetic and the same 28 B/parameter of HBM traffic.  Sharded: after the
+    reduce-scatter a rank already OWNS the sum of 1/world of the table's gradient; it updates exactly that range (its moments
+    for the other ranges stay zero and are never read) and the ranks all-gather the PARAMETERS.  Bytes on the links are the same
+    (a reduce-scatter and an all-gather of the same size); AdamW work and traffic per rank drop to 1/world, and the gradient's
+    all-gather -- which nothing but the replicated update needed -- is gone.  Replicas stay bit-identical by construction:
+    every rank holds the owner's bytes.
+
+        su = ShardedUpdate()
+        own = su.reduce_scatter(flat_grad)            # async, IN PLACE: flat_grad[own[0]:own[1]] becomes the sum over ranks
+        ...                                           # (more buckets / backward kernels)
+        su.wait()                                     # the caller's stream now sees the sums
+        <update param[own] from flat_grad[own]>       # optim.FusedAdamW.step(owned={param: [own]})
+        su.all_gather(flat_param, own)                # async; su.wait() before the parameters are read again
+
+    `reduce_scatter` returns None (and does nothing) when the tensor cannot be cut evenly: reduce it through GradientBuckets
+    and update it replicated.  Backends: nccl (= RCCL; the in-place forms: recv buffer = send buffer + rank * count), gloo
+    (CPU tests; device tensors are staged through host memory, synchronously), Loopback (one GPU, identical virtual replicas:
+    the owner's range is scaled by `world`; `virtual_ranks()` lets the caller play every owner in turn)."""
+
+    def __init__(self):
+        self.works = []
+        self.bytes = []
+
+    @staticmethod
+    def virtual_ranks():
+        """the ranks whose owned ranges THIS process must update: its own -- or all of them under the Loopback double"""
+        return list(range(_loopback.world)) if _loopback is not None else [rank()]
+
+    def reduce_scatter(self, flat, unit=1):
+        assert flat.dim() == 1 and flat.is_contiguous()
+        if not collectives_active():
+            return (0, flat.numel())
+        own = shard_bounds(flat.numel(), unit)
+        if own is None:
+            return None
+        self.bytes.append(flat.numel() * flat.element_size())
+        lo, hi = own
+        if _loopback is not None:
+            self.works.append(_loopback.all_reduce(flat))          # every virtual owner's range holds its 'sum'
+            return own
+        w, r = world_size(), dist.get_rank()
+        n = hi - lo
+        if dist.get_backend() == "nccl":
+            self.works.append(dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, async_op=True))
+            return own
+        h = flat.detach().cpu() if flat.is_cuda else flat
+        for o in range(w):
+            dist.reduce(h[o * n:(o + 1) * n], dst=o, op=dist.ReduceOp.SUM)
+        if flat.is_cuda:
+            flat[lo:hi].copy_(h[lo:hi])
+        return own
+
+    def all_gather(self, flat, own):
+        """every rank's [own) range of `flat` (same bounds rule on every rank) -> all of `flat`, in place"""
+        if not collectives_active() or _loopback is not None:
+            return
+        lo, hi = own
+        if dist.get_backend() == "nccl":
+            self.works.append(dist.all_gather_into_tensor(flat, flat[lo:hi], async_op=True))
+            return
+        h = flat.detach().cpu() if flat.is_cuda else flat
+        parts = [torch.empty(hi - lo, dtype=h.dtype) for _ in range(world_size())]
+        dist.all_gather(parts, h[lo:hi].clone())
+        with torch.no_grad():
+            flat.copy_(torch.cat(parts))
+
+    def wait(self):
+        for wk in self.works:
+            wk.wait()
+        self.works = []
+
+
 def allreduce_module_grads(modules, buckets=None):
     """Convenience for autograd-driven training loops: reduce `.grad` of every parameter of `modules`, lattices as
     their own buckets, everything else in one small bucket."""

@@ -400,11 +400,17 @@ class Trainer:
         self.nr_rays = self.hp.nr_rays
         self.iter = 0
         self.capture_grads = None     # set to {} to have step() record the gradients it hands to the optimiser
+        self.shard_optimizer = parallel.sharded_optimizer_default()   # data parallel: lattices updated by their owners only
         self._colour_window_t = 1.0   # the t the colour / background lattices' windows (`_win`, ones) currently hold
         self._late_seen = False       # set by the first iteration at / after iter_start_reduce_curv (acts from the next one on)
         self.last = {}
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
         self._seed = seed + 1
+
+    def _param_key(self):
+        """changes whenever the parameters may have: the optimiser counts its steps (`generation`: the fused kernels write the
+        parameters without bumping torch's version counters), torch-level writes bump `_version` (SdfNet.sdf_only adds those)"""
+        return (self.iter, self.opt.generation)
 
     def accumulate_grads(self):
         """context manager around the step's `loss.backward()`: opens the persistent gradient buffers (the lattices'
@@ -438,14 +444,14 @@ class Trainer:
                                                                        self.sphere.m_center_tensor, jitter, False)
         if fg.samples_pos.shape[0] == 0:
             return fg, bg
-        fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it, key=self.iter))
+        fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it, key=self._param_key()))
         for rnd, mult in ((0, 1.0), (1, 2.0)):
             # sdf2alpha -> clip -> 1 - alpha + 1e-7 -> cumprod -> alpha * T -> per-ray sum -> normalise -> cdf
             # (sdf_utils.py:403-417), one launch, bit-identical to the nine of the operator chain
             cdf = VolumeRendering.sdf_importance_cdf(fg, fg.samples_sdf, 512.0, True, mult)
             imp = VolumeRendering.importance_sample(o, d, fg, cdf, hp.nr_samples_imp_sampling, jitter)
             if rnd == 0:
-                imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it, key=self.iter))
+                imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it, key=self._param_key()))
             else:
                 fg.remove_sdf()
             fg = VolumeRendering.combine_uniform_samples_with_imp(o, d, tx, fg, imp).compact_to_valid_samples()
@@ -498,7 +504,7 @@ class Trainer:
                 parallel.seed_generators(977 + git, self.dev)
                 centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
                 inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
-                self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it, key=self.iter), inv_s.view(1), 1e-4)
+                self.grid.update_with_sdf_random_sample(idx, self.sdf.sdf_only(centres, it, key=self._param_key()), inv_s.view(1), 1e-4)
             if n_fg:  # the count is already on the host
                 self.nr_rays = max(64, min(8192, int(self.nr_rays * hp.target_nr_of_samples / n_fg)))
 
@@ -581,17 +587,44 @@ class Trainer:
         if self.capture_grads is not None:      # tests: the gradients of this step as the optimiser is about to see them
             self.capture_grads = {"dense": [g.detach().clone() for g in grads], "lattices": [tr.grad.clone() for tr in self.touched],
                                   "loss": loss.detach().clone()}
+        # a lattice gradient that a backward OUTSIDE accumulate_grads() handed to autograd (p.grad) joins the buffer BEFORE the
+        # reduction: folded in later (FusedAdamW.step does that for single-process use) it would never be summed over the ranks
+        for m, tr in zip((self.sdf, self.rgb, self.bg), self.touched):
+            p = m.encoding.lattice_values
+            if p.grad is not None:
+                tr.grad.add_(p.grad)
+                p.grad = None
+        owned = None
         if parallel.world_size() > 1:
             buckets = parallel.GradientBuckets()
             small = [g for g in grads if g.numel() < (1 << 20)]
-            big = [g for g in grads if g.numel() >= (1 << 20)] + [tr.grad for tr in self.touched]
+            big = [g for g in grads if g.numel() >= (1 << 20)]
             buckets.reduce(small)
-            for g in big:           # one bucket per lattice (50 MB): the ring is per-link bound, fewer larger messages
+            for g in big:
                 buckets.reduce([g])
+            # the lattices (50 MB each): reduce-scatter IN PLACE, the owner updates its 1/world of the table, the ranks all-gather
+            # the PARAMETERS (parallel.ShardedUpdate); PSDF_DP_OPTIMIZER=replicated (or a table that cannot be cut evenly):
+            # reduce-scatter + all-gather of the gradient, every rank updates everything
+            su = parallel.ShardedUpdate()
+            owned, mine = {}, {}
+            for m, tr in zip((self.sdf, self.rgb, self.bg), self.touched):
+                p = m.encoding.lattice_values
+                own = su.reduce_scatter(tr.grad.view(-1), unit=tr.block_elems) if self.shard_optimizer else None
+                if own is None:
+                    buckets.reduce([tr.grad])     # one bucket per lattice: the ring is per-link bound, fewer larger messages
+                else:
+                    mine[p] = own
+                    owned[p] = [parallel.shard_bounds(p.numel(), tr.block_elems, rank_=r) for r in su.virtual_ranks()]
             for tr in self.touched:  # a block touched on ANY rank carries a gradient after the sum: OR of the byte maps
                 parallel.all_reduce_max_(tr.touched)
             buckets.finish()
-        self.opt.step(grad_scale=1.0 / parallel.world_size())
+            su.wait()
+        self.opt.step(grad_scale=1.0 / parallel.world_size(), owned=owned)
+        if owned:
+            for p, own in mine.items():
+                su.all_gather(p.data.view(-1), own)
+            su.wait()
+            self.last_dp = {"optimizer": "sharded", "sharded_bytes": list(su.bytes), "bucket_bytes": list(buckets.bytes)}
         for gb in self.grad_buffers:
             gb.zero()
         self.iter += 1

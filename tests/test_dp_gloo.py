@@ -84,6 +84,54 @@ def test_ray_sharded_gradients_equal_full_batch(mode, sparse):
         assert ret["bytes_0"] == ret["bytes_1"]
 
 
+def _sharded_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from permuto_sdf_amd import parallel
+    parallel.init(backend="gloo")
+    po, lat, sh, pts, w1, sl, win = _problem()
+    s, e = parallel.shard_rays(pts.shape[0], rank, world)
+    g_lat, _ = _grads(po, lat, sh, pts[s:e], w1, sl, win)
+    param = lat.clone()
+    su = parallel.ShardedUpdate()
+    flat_g = g_lat.contiguous().view(-1)
+    own = su.reduce_scatter(flat_g, unit=4)                 # in place: MY range of flat_g is now the sum over the ranks
+    su.wait()
+    ret["sharded_%d" % rank] = own is not None
+    if own is None:       # 4 * 1024 * 2 elements do not cut into 3 aligned parts: what every caller does then -- replicated
+        b = parallel.GradientBuckets()
+        b.reduce([flat_g])
+        b.finish()
+        with torch.no_grad():
+            param.view(-1).sub_(0.1 * flat_g)
+    else:
+        assert own == parallel.shard_bounds(flat_g.numel(), 4) and own[1] - own[0] == flat_g.numel() // world
+        lo, hi = own
+        with torch.no_grad():
+            param.view(-1)[lo:hi] -= 0.1 * flat_g[lo:hi]       # the owner's update (plain SGD stands in for the AdamW kernel)
+        su.all_gather(param.view(-1), own)                      # the owners' bytes to everybody
+        su.wait()
+    ret["param_%d" % rank] = param.numpy()
+    assert su.reduce_scatter(torch.zeros(world * 4 + 2), unit=4) is None      # cannot be cut evenly: the caller keeps it replicated
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_protocol_equals_the_full_batch_update(world):
+    """parallel.ShardedUpdate: in-place reduce-scatter of the lattice gradient, the owner updates its 1/world of the table,
+    all-gather of the PARAMETERS -- every rank ends with the single-process update of the whole batch, bit-identical replicas"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    po, lat, sh, pts, w1, sl, win = _problem()
+    g_lat, _ = _grads(po, lat, sh, pts, w1, sl, win)
+    want = (lat - 0.1 * g_lat).numpy()
+    assert all(ret["sharded_%d" % r] == (world == 2) for r in range(world))
+    for r in range(world):
+        assert np.abs(ret["param_%d" % r] - want).max() <= 1e-5 * np.abs(want).max()
+        assert np.array_equal(ret["param_%d" % r], ret["param_0"])          # replicas: the same bytes
+
+
 def test_single_process_is_a_noop():
     from permuto_sdf_amd import parallel
     assert parallel.world_size() == 1

@@ -184,11 +184,12 @@ def test_overlap_schedule_is_race_free_under_an_asynchronous_backend(dev):
     rs, rgb, aux = bench.make_batch(dev, 11, nr_rays=4096)
     normals, gt = aux[4], aux[5]
 
-    def run(mode, lb):
+    def run(mode, lb, optimizer="replicated"):
         prev = parallel.set_loopback(lb)
         try:
             import os
             os.environ["PSDF_DP_REDUCE"] = mode
+            os.environ["PSDF_DP_OPTIMIZER"] = optimizer
             hp = SdfHotPath(nr_levels=16, hidden=64, out_channels=1, device=dev, seed=0)
             pred, saved = hp.forward(rs, rgb, normals)
             from permuto_sdf_amd.neus import l1_loss_raw
@@ -199,19 +200,22 @@ def test_overlap_schedule_is_race_free_under_an_asynchronous_backend(dev):
         finally:
             parallel.set_loopback(prev)
             os.environ.pop("PSDF_DP_REDUCE", None)
+            os.environ.pop("PSDF_DP_OPTIMIZER", None)
 
     g1, p1 = run("all_reduce", None)
-    for mode in ("all_reduce", "reduce_scatter"):
+    for mode, optimizer in (("all_reduce", "replicated"), ("reduce_scatter", "replicated"), ("reduce_scatter", "sharded")):
         lb = parallel.Loopback(world=2)
-        g2, p2 = run(mode, lb)
+        g2, p2 = run(mode, lb, optimizer)
         kinds = [k for k, _ in lb.launched]
-        assert len(kinds) >= (3 if mode == "all_reduce" else 6), kinds      # MLP bucket + two lattice level ranges
+        # MLP bucket + two lattice level ranges (sharded: the lattice ranges are reduce-scattered in place -- one Loopback
+        # 'sum' each -- the two virtual owners' halves of every range are updated one after the other, nothing is gathered)
+        assert len(kinds) >= (3 if mode == "all_reduce" else (4 if optimizer == "sharded" else 6)), kinds
         for a, b in zip(g1, g2):
             # split_levels (two launches over level ranges) changes the summation order of nothing within a level
             assert float((b - 2.0 * a).abs().max()) <= 2e-5 * float(a.abs().max()) * 2.0 + 1e-12, mode
         # grad_scale = 1 / world: the update of two identical ranks equals the single-rank update
         for a, b in zip(p1, p2):
-            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, mode
+            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-9, (mode, optimizer)
 
 
 def test_cfg3_size_importance_sampling_and_merge(dev):

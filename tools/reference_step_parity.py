@@ -176,89 +176,138 @@ def main():
             for gb in tr.grad_buffers:
                 gb.zero()
 
+        def run_ours(tr, git, shared_fg=None):
+            """one step of `tr` from the snapshot -> (named gradients, loss, tr.last); shared_fg: a foreground sample container to
+            use INSTEAD of the trainer's own (the reference's), so that only the step itself differs, not the sample positions"""
+            restore(tr)
+            tr.iter = git
+            tr.capture_grads = {}
+            orig = tr._samples
+            if shared_fg is not None:
+                def patched(o_, d_, it_, jitter=True):
+                    fg_own, bg_own = orig(o_, d_, it_, jitter)
+                    return shared_fg, bg_own
+                tr._samples = patched
+            try:
+                tr.step(reel)
+            finally:
+                if shared_fg is not None:
+                    del tr._samples
+            torch.cuda.synchronize()
+            g, l = our_named_grads(tr)
+            tr.capture_grads = None
+            return g, l, dict(tr.last)
+
+        def run_reference(mode, it, git, seed, permute_seed=None):
+            """the reference's own step from the snapshot.  permute_seed: re-number the hidden units of the reference's SDF MLP
+            (rows of a Linear and the matching columns of the next one: the SAME function, a different fp32 summation order) --
+            the distance between two such runs is the reference's own rounding noise at this state."""
+            for p_, (s_, i_) in zip(pcgs, pcg_state):
+                p_.state, p_.inc = s_, i_
+            aabb = T.create_bb_for_dataset("dtu")
+            hp = T.hyperparams
+            model_sdf = T.SDF(in_channels=3, boundary_primitive=aabb, geom_feat_size_out=hp.sdf_geom_feat_size,
+                              nr_iters_for_c2f=hp.sdf_nr_iters_for_c2f).to("cuda")
+            model_rgb = T.RGB(in_channels=3, boundary_primitive=aabb, geom_feat_size_in=hp.sdf_geom_feat_size,
+                              nr_iters_for_c2f=hp.rgb_nr_iters_for_c2f).to("cuda")
+            model_bg = T.NerfHash(4, boundary_primitive=aabb, nr_iters_for_c2f=hp.background_nr_iters_for_c2f).to("cuda")
+            model_colorcal = T.Colorcal(reel.rgb_reel.shape[0], 0)
+            assert type(model_sdf.mlp_sdf) is torch.nn.Sequential, "the reference's evaluators must stay unfused here"
+            model_sdf.load_state_dict(checkpoint.to_reference_keys("sdf", state["sdf"]))
+            model_rgb.load_state_dict(checkpoint.to_reference_keys("rgb", state["rgb"]))
+            model_bg.load_state_dict(checkpoint.to_reference_keys("bg", state["bg"]))
+            model_colorcal.load_state_dict(state["colorcal"])
+            perms = None
+            if permute_seed is not None:
+                lins = [m for m in model_sdf.mlp_sdf if isinstance(m, torch.nn.Linear)]
+                gp = torch.Generator(device="cpu").manual_seed(permute_seed)
+                perms = [torch.randperm(l.out_features, generator=gp, device="cpu").to(dev) for l in lins[:-1]]
+                with torch.no_grad():
+                    for i, pm in enumerate(perms):
+                        lins[i].weight.copy_(lins[i].weight[pm].clone())
+                        lins[i].bias.copy_(lins[i].bias[pm].clone())
+                        lins[i + 1].weight.copy_(lins[i + 1].weight[:, pm].clone())
+            occupancy_grid = T.OccupancyGrid(256, 1.0, [0, 0, 0])
+            occupancy_grid.set_grid_values(grid_v.clone())
+            occupancy_grid.set_grid_occupancy(grid_o.clone())
+            for m in (model_sdf, model_rgb, model_bg):
+                m.train(True)
+            parallel.seed_generators(seed, dev)
+            models = {"sdf": model_sdf, "rgb": model_rgb, "bg": model_bg, "colorcal": model_colorcal}
+            terms, fg = {}, None
+            if mode == "sphere":
+                loss, loss_sdf, loss_eik = T.loss_sphere_init("dtu", 30000, aabb, model_sdf, git)    # :323
+                terms = {"loss_sdf": float(loss_sdf), "loss_eikonal": float(loss_eik)}
+            else:
+                args = argparse.Namespace(with_mask=with_mask, dataset="dtu")
+                ns = dict(vars(T))
+                loss0, loss_rgb, loss_eikonal, loss_curvature, loss_lipshitz = T.init_losses()
+                ns.update(args=args, hyperparams=hp, ray_origins=o, ray_dirs=d, img_indices=img_idx, gt_selected=gt, gt_mask=mask,
+                          does_ray_intersect_box=hit, model_sdf=model_sdf, model_rgb=model_rgb, model_bg=model_bg,
+                          model_colorcal=model_colorcal, occupancy_grid=occupancy_grid, iter_nr_for_anneal=it,
+                          cos_anneal_ratio=T.map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0),
+                          forced_variance=T.map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish),
+                          loss=loss0, loss_rgb=loss_rgb, loss_eikonal=loss_eikonal, loss_curvature=loss_curvature,
+                          loss_lipshitz=loss_lipshitz)
+                old_eik = hp.eikonal_weight
+                exec(code, ns)
+                assert hp.eikonal_weight == old_eik
+                loss = ns["loss"]
+                for k in ("loss_rgb", "loss_eikonal", "loss_curvature", "loss_offsurface_high_sdf", "loss_mask"):
+                    if k in ns and torch.is_tensor(ns[k]):
+                        terms[k] = float(ns[k].mean())
+                fg = ns["fg_ray_samples_packed"]
+                terms["nr_fg_samples"] = int(fg.samples_pos.shape[0])
+            loss.backward()
+            torch.cuda.synchronize()
+            if perms is not None:     # gradients back in the original numbering of the hidden units
+                lins = [m for m in model_sdf.mlp_sdf if isinstance(m, torch.nn.Linear)]
+                for i, pm in enumerate(perms):
+                    inv = torch.empty_like(pm)
+                    inv[pm] = torch.arange(pm.numel(), device=dev)
+                    lins[i].weight.grad = lins[i].weight.grad[inv].clone()
+                    lins[i].bias.grad = lins[i].bias.grad[inv].clone()
+                    lins[i + 1].weight.grad = lins[i + 1].weight.grad[:, inv].clone()
+            return ref_named_grads(models), float(loss), terms, fg
+
+        def compare(g, gref):
+            rows = {}
+            for k in sorted(gref):
+                if k not in g:
+                    rows[k] = {"missing": True}
+                    continue
+                if float(gref[k].abs().max()) == 0.0 and float(g[k].abs().max()) == 0.0:
+                    continue          # no gradient on either side (forced variance, colour nets in the sphere phase ...)
+                rows[k] = rel(g[k], gref[k])
+                if k.endswith("encoding.lattice_values"):      # per level: fine levels turn position noise into gradient noise
+                    rows[k]["per_level_max_rel"] = [
+                        float((g[k][l].double() - gref[k][l].double()).abs().max() / gref[k][l].double().abs().max().clamp_min(1e-30))
+                        if float(gref[k][l].abs().max()) > 0 else 0.0 for l in range(gref[k].shape[0])]
+            return {"grads": rows, "not_in_reference": sorted(set(g) - set(gref)),
+                    "worst_dense": max((v["max_rel"] for k, v in rows.items() if "lattice" not in k and "max_rel" in v), default=0.0),
+                    "worst_lattice": max((v["max_rel"] for k, v in rows.items() if "lattice" in k and "max_rel" in v), default=0.0),
+                    "worst_lattice_l2": max((v["l2_rel"] for k, v in rows.items() if "lattice" in k and "l2_rel" in v), default=0.0)}
+
         for mode in modes:
             it = {"early": 2001, "late": 52001, "mask": 2001, "sphere": None}[mode]
             git = (n0 + it) if it is not None else 101        # neither is a multiple of 8: no grid refresh inside the step
             assert git % 8 != 0
             seed = parallel.step_seed(trm._seed, 0, git)
-            ours = {}
+            with default_tensor(True):
+                gref, loss_ref, terms, fg_ref = run_reference(mode, it, git, seed)
+                gref2, loss_ref2, _, _ = run_reference(mode, it, git, seed, permute_seed=7)
+            case = {"iter_nr_for_anneal": it, "global_iter": git, "nr_rays": int(o.shape[0]), "reference_loss": loss_ref,
+                    "reference_terms": terms,
+                    # the reference against ITSELF with the hidden units of its SDF MLP re-numbered: its own rounding noise
+                    "reference_self_noise": dict(compare(gref2, gref), loss_rel=abs(loss_ref2 - loss_ref) / abs(loss_ref))}
+            del gref2
             with default_tensor(False):
                 for name, tr in (("manual", trm), ("autograd", tra)):
-                    restore(tr)
-                    tr.iter = git
-                    tr.capture_grads = {}
-                    tr.step(reel)
-                    torch.cuda.synchronize()
-                    ours[name] = our_named_grads(tr)
-                    ours[name] += (dict(tr.last),)
-                    tr.capture_grads = None
-            # ---- the reference
-            with default_tensor(True):
-                for p, (s, i) in zip(pcgs, pcg_state):
-                    p.state, p.inc = s, i
-                aabb = T.create_bb_for_dataset("dtu")
-                hp = T.hyperparams
-                model_sdf = T.SDF(in_channels=3, boundary_primitive=aabb, geom_feat_size_out=hp.sdf_geom_feat_size,
-                                  nr_iters_for_c2f=hp.sdf_nr_iters_for_c2f).to("cuda")
-                model_rgb = T.RGB(in_channels=3, boundary_primitive=aabb, geom_feat_size_in=hp.sdf_geom_feat_size,
-                                  nr_iters_for_c2f=hp.rgb_nr_iters_for_c2f).to("cuda")
-                model_bg = T.NerfHash(4, boundary_primitive=aabb, nr_iters_for_c2f=hp.background_nr_iters_for_c2f).to("cuda")
-                model_colorcal = T.Colorcal(reel.rgb_reel.shape[0], 0)
-                assert type(model_sdf.mlp_sdf) is torch.nn.Sequential, "the reference's evaluators must stay unfused here"
-                model_sdf.load_state_dict(checkpoint.to_reference_keys("sdf", state["sdf"]))
-                model_rgb.load_state_dict(checkpoint.to_reference_keys("rgb", state["rgb"]))
-                model_bg.load_state_dict(checkpoint.to_reference_keys("bg", state["bg"]))
-                model_colorcal.load_state_dict(state["colorcal"])
-                occupancy_grid = T.OccupancyGrid(256, 1.0, [0, 0, 0])
-                occupancy_grid.set_grid_values(grid_v.clone())
-                occupancy_grid.set_grid_occupancy(grid_o.clone())
-                for m in (model_sdf, model_rgb, model_bg):
-                    m.train(True)
-                parallel.seed_generators(seed, dev)
-                models = {"sdf": model_sdf, "rgb": model_rgb, "bg": model_bg, "colorcal": model_colorcal}
-                terms = {}
-                if mode == "sphere":
-                    loss, loss_sdf, loss_eik = T.loss_sphere_init("dtu", 30000, aabb, model_sdf, git)    # :323
-                    terms = {"loss_sdf": float(loss_sdf), "loss_eikonal": float(loss_eik)}
-                else:
-                    args = argparse.Namespace(with_mask=with_mask, dataset="dtu")
-                    ns = dict(vars(T))
-                    loss0, loss_rgb, loss_eikonal, loss_curvature, loss_lipshitz = T.init_losses()
-                    ns.update(args=args, hyperparams=hp, ray_origins=o, ray_dirs=d, img_indices=img_idx, gt_selected=gt, gt_mask=mask,
-                              does_ray_intersect_box=hit, model_sdf=model_sdf, model_rgb=model_rgb, model_bg=model_bg,
-                              model_colorcal=model_colorcal, occupancy_grid=occupancy_grid, iter_nr_for_anneal=it,
-                              cos_anneal_ratio=T.map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0),
-                              forced_variance=T.map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish),
-                              loss=loss0, loss_rgb=loss_rgb, loss_eikonal=loss_eikonal, loss_curvature=loss_curvature,
-                              loss_lipshitz=loss_lipshitz)
-                    old_eik = hp.eikonal_weight
-                    exec(code, ns)
-                    assert hp.eikonal_weight == old_eik
-                    loss = ns["loss"]
-                    for k in ("loss_rgb", "loss_eikonal", "loss_curvature", "loss_offsurface_high_sdf", "loss_mask"):
-                        if k in ns and torch.is_tensor(ns[k]):
-                            terms[k] = float(ns[k].mean())
-                    terms["nr_fg_samples"] = int(ns["fg_ray_samples_packed"].samples_pos.shape[0])
-                loss.backward()
-                torch.cuda.synchronize()
-                gref = ref_named_grads(models)
-            case = {"iter_nr_for_anneal": it, "global_iter": git, "nr_rays": int(o.shape[0]), "reference_loss": float(loss),
-                    "reference_terms": terms}
-            for name, (g, l, last) in ours.items():
-                rows = {}
-                for k in sorted(gref):
-                    if k not in g:
-                        rows[k] = {"missing": True}
-                        continue
-                    if float(gref[k].abs().max()) == 0.0 and float(g[k].abs().max()) == 0.0:
-                        continue          # no gradient on either side (forced variance, colour nets in the sphere phase ...)
-                    rows[k] = rel(g[k], gref[k])
-                extra = sorted(set(g) - set(gref))
-                case[name] = {"loss": l, "loss_rel": abs(l - float(loss)) / abs(float(loss)), "nr_fg_samples": last.get("nr_fg_samples"),
-                              "grads": rows, "not_in_reference": extra,
-                              "worst_dense": max((v["max_rel"] for k, v in rows.items() if "lattice" not in k and "max_rel" in v), default=0.0),
-                              "worst_lattice": max((v["max_rel"] for k, v in rows.items() if "lattice" in k and "max_rel" in v), default=0.0),
-                              "worst_lattice_l2": max((v["l2_rel"] for k, v in rows.items() if "lattice" in k and "l2_rel" in v), default=0.0)}
+                    for variant in (("", None),) + ((("_same_samples", fg_ref),) if fg_ref is not None else ()):
+                        g, l, last = run_ours(tr, git, shared_fg=variant[1])
+                        case[name + variant[0]] = dict(compare(g, gref), loss=l, loss_rel=abs(l - loss_ref) / abs(loss_ref),
+                                                       nr_fg_samples=last.get("nr_fg_samples"))
+                        del g
             out["cases"][mode] = case
             del gref
     s = json.dumps(out, indent=1)
