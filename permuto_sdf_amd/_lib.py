@@ -109,6 +109,7 @@ def zeroed_int(device):
     pool = _int_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():
         pool = _int_pools[key] = [torch.zeros(1024, dtype=torch.int32, device=device), 0]
+        torch.cuda.current_stream(device).synchronize()   # (see zeroed_scalar)
     i = pool[1]
     pool[1] = i + 1
     return pool[0][i:i + 1]
@@ -125,6 +126,9 @@ def zeroed_scalar(device):
     pool = _scalar_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():
         pool = _scalar_pools[key] = [torch.zeros(1024, dtype=torch.float32, device=device), 0]
+        # the fill runs on whatever stream is current NOW; later slices may be handed to work on another stream (the trainers
+        # run two): wait for the fill once per 1024 accumulators rather than order every consumer after it
+        torch.cuda.current_stream(device).synchronize()
     i = pool[1]
     pool[1] = i + 1
     return pool[0][i:i + 1]

@@ -26,11 +26,26 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                       int pad_points, const unsigned char* __restrict__ skip, float* __restrict__ sliced,
-                      unsigned char* __restrict__ touched, int touch_shift, int blocks_per_level) {
-  const int64_t n = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
+                      unsigned char* __restrict__ touched, int touch_shift, int blocks_per_level, int xcd_lpx = 0,
+                      int xcd_nb = 0, int xcd_lt = 0) {
+  // Two launch shapes.  Default: grid (point tiles, levels), tiles fastest -- the chip sweeps one level's table at a time and
+  // every XCD's L2 holds (its own copy of) that one table.  XCD-pinned (xcd_lpx > 0; measurement switch PSDF_ENC_FWD_XCD=1, round
+  // 4): a 1-D grid whose workgroup id i lands on XCD i % 8 (round-robin dispatch); XCD k takes `xcd_lpx` levels of the
+  // coarse/fine-interleaved order 0, Lt-1, 1, Lt-2, ... for ALL points, so a table is fetched into ONE L2 instead of eight.
+  int64_t tile = blockIdx.x;
+  int level = blockIdx.y;
+  if (xcd_lpx > 0) {
+    const int64_t id = blockIdx.x;
+    const int xcd = (int)(id & 7);
+    const int64_t slot = id >> 3;
+    const int li = xcd * xcd_lpx + (int)(slot / xcd_nb);
+    if (li >= xcd_lt) return;
+    level = (li & 1) ? xcd_lt - 1 - (li >> 1) : (li >> 1);
+    tile = slot % xcd_nb;
+  }
+  const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
   if (n >= N) return;
   if (skip && skip[n]) return;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
-  const int level = blockIdx.y;
   float pos[P];
   load_pos<P>(positions, n, pos);
   if (level >= L) {  // pseudo-levels carrying the scaled input point (zero padded)
@@ -179,7 +194,7 @@ struct ScatterCache {
   static constexpr int SC_SLOTS = TOTAL / F;  // F=2, TOTAL 8192: 16 KiB tags + 32 KiB sums
   uint32_t* tags;
   float* sums;
-  int* stats;  // [0] = hits, [1] = tries, [2] = enabled
+  int* stats;  // [0] = hits, [1] = tries, [2] = enabled, [3] = contributions of the first tile, [4] = of them run owners
   __device__ __forceinline__ void init(float* lds) {
     tags = reinterpret_cast<uint32_t*>(lds);
     sums = lds + SC_SLOTS;
@@ -190,6 +205,8 @@ struct ScatterCache {
       stats[0] = 0;
       stats[1] = 0;
       stats[2] = 1;
+      stats[3] = 0;
+      stats[4] = 0;
     }
     __syncthreads();
   }
@@ -220,23 +237,35 @@ struct ScatterCache {
       }
     }
   }
-  static constexpr size_t bytes() { return (size_t)(SC_SLOTS + SC_SLOTS * F + 4) * 4; }
+  static constexpr size_t bytes() { return (size_t)(SC_SLOTS + SC_SLOTS * F + 8) * 4; }
 };
 
 // ----------------------------------------------------------------------------------------- backward
 // grad_lattice[l][row][f] += bary_r * w_l * g[l][f][n]            (LDS-privatised, then fp32 L2 atomics)
 // grad_pos[n][i]          += dL/dpos_i  (chain through barycentric -> elevated -> position)
 // Launch: grid (B, Lt), workgroup b of level l walks point tiles b, b+B, ...
+#if !defined(PSDF_ENC_COMBINE_VOTE)
+#define PSDF_ENC_COMBINE_VOTE 1   // 0: every tile runs the DPP run combine (the round-3 kernel; A/B builds)
+#endif
 template <typename SC>
-__device__ __forceinline__ bool cache_vote(SC& sc, int hits, int tries) {
-  // called by every thread of the workgroup after its first tile; returns the workgroup-uniform decision
+__device__ __forceinline__ bool cache_vote(SC& sc, int hits, int tries, int contribs, int owners, bool& use_combine) {
+  // called by every thread of the workgroup after its first tile; returns the workgroup-uniform decisions
   hits = (int)psdf::wave_sum((float)hits);
   tries = (int)psdf::wave_sum((float)tries);
+  contribs = (int)psdf::wave_sum((float)contribs);
+  owners = (int)psdf::wave_sum((float)owners);
   if (psdf::lane_id() == 0) {
     atomicAdd(&sc.stats[0], hits);
     atomicAdd(&sc.stats[1], tries);
+    atomicAdd(&sc.stats[3], contribs);
+    atomicAdd(&sc.stats[4], owners);
   }
   __syncthreads();
+  // The run combine (segmented DPP scan per vertex: ~160 of the ~590 VALU instructions per point and level) pays where
+  // neighbouring samples share lattice rows.  On the finest levels they do not (a simplex is smaller than the sample spacing):
+  // when fewer than 1 in 16 contributions of the first tile were merged into a neighbour's, the rest of the walk skips it --
+  // every lane then owns its contribution, exactly what the combine would have found almost everywhere.
+  use_combine = !PSDF_ENC_COMBINE_VOTE || (sc.stats[3] - sc.stats[4]) * 16 >= sc.stats[3];
   return sc.stats[0] * 8 >= sc.stats[1];  // keep the cache when >= 1/8 of the first tile hit an existing entry
 }
 
@@ -451,9 +480,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
   int* q_cnt = reinterpret_cast<int*>(lds + SCache::bytes() / 4);  // [Q_MAX_PARTS]
   int* q_base = q_cnt + Q_MAX_PARTS;                                          // [Q_MAX_PARTS]
   int* q_off = q_base + Q_MAX_PARTS;                                          // [Q_MAX_PARTS + 1]
-  bool use_cache = LATTICE;
+  bool use_cache = LATTICE, use_combine = true;
   int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
-  int hits = 0, tries = 0, iter = 0;
+  int hits = 0, tries = 0, iter = 0, contribs = 0, owners = 0;
   const float w = window[level];
   const int64_t tbase = (int64_t)level * capacity * F;
   float sfl[P], shl[P];
@@ -588,7 +617,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
       for (int c = 0; c < NC; c++) {
         // (also when the cache has been voted off: skipping the combine there was measured, round 3 -- encode backward pair
         // 0.78 -> 0.92 ms, the runs of the mid levels are what keeps their queue traffic down)
-        const bool own = combine_runs16<F>(crow[c], pending[c], cval[c]);
+        // use_combine is workgroup-uniform (voted after the first tile): no lane is left out of the DPP scan
+        const bool own = use_combine ? combine_runs16<F>(crow[c], pending[c], cval[c]) : pending[c];
+        if (iter == 0) {
+          contribs += pending[c];
+          owners += own;
+        }
         bool absorbed = false;
         if (own && use_cache) {
           const int rc = sc.add(crow[c], cval[c], hot);
@@ -627,7 +661,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
       }
     }
     if (LATTICE && iter == 0) {
-      use_cache = cache_vote(sc, hits, tries);  // re-use rate of the first tile
+      use_cache = cache_vote(sc, hits, tries, contribs, owners, use_combine);  // re-use rate / merged share of the first tile
       if (QUEUE && !use_cache) cache_drain_to_queue<F>(sc, Q, level, q_cnt, q_base, grad_lattice + tbase);
     }
   }
@@ -649,8 +683,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 // levels and sums their contributions in registers before it touches grad_positions: a quarter of the atomics of the
 // general kernel (which also carries the scatter-cache / queue machinery of the lattice gradient) while the 4 tables
 // of a group (8 MiB) still mostly live in the L2s.
+// PARTIAL (round 4): the level groups do not meet in grad_positions with float atomics (3 per point and group: at 2 M points
+// x 5 groups 30 M atomics against a ceiling of ~21 G/s -- the atomics, not the gathers, made this kernel 3x as slow as the
+// forward); each group stores its sum to its own [N, P] slab of a scratch buffer (plain coalesced stores) and
+// encode_bwd_pos_reduce_kernel adds the slabs into grad_positions: 2 x 12 B per point and group of extra traffic.
 constexpr int POS_LPB = 4;
-template <int P, int F>
+template <int P, int F, bool PARTIAL = false>
 __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                           const float* __restrict__ lattice, const float* __restrict__ scale_factor,
@@ -728,8 +766,25 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       gp[i] = gp[i] + acc * sfl[i];
     }
   }
+  if (PARTIAL) {   // grad_positions = the scratch slabs [groups][N][P]
 #pragma unroll
-  for (int i = 0; i < P; i++) atomicAdd(grad_positions + n * P + i, gp[i]);
+    for (int i = 0; i < P; i++) grad_positions[((int64_t)blockIdx.y * N + n) * P + i] = gp[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < P; i++) atomicAdd(grad_positions + n * P + i, gp[i]);
+  }
+}
+
+// grad_positions[n][i] += sum over the level groups of partial[g][n][i] (in group order: deterministic); one thread per float
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    encode_bwd_pos_reduce_kernel(int64_t NP, int P, int groups, const float* __restrict__ partial,
+                                 const unsigned char* __restrict__ skip, float* __restrict__ grad_positions) {
+  const int64_t e = (int64_t)blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (e >= NP) return;
+  if (skip && skip[e / P]) return;     // masked sample: its slabs were not written, its gradient stays as it is
+  float s = partial[e];
+  for (int g = 1; g < groups; g++) s = s + partial[(int64_t)g * NP + e];
+  grad_positions[e] = grad_positions[e] + s;
 }
 
 // One workgroup per (partition, level): fold the queue into an LDS image of the partition's table slice (64-bit
@@ -838,9 +893,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
   ScatterCache<F> sc;
   if (LATTICE) sc.init(lds);
-  bool use_cache = LATTICE;
+  bool use_cache = LATTICE, use_combine = true;
   int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
-  int hits = 0, tries = 0, iter = 0;
+  int hits = 0, tries = 0, iter = 0, contribs = 0, owners = 0;
   const int64_t tbase = (int64_t)level * capacity * F;
   float sfl[P], shl[P];
 #pragma unroll
@@ -916,7 +971,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 #pragma unroll
       for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = gg[f];
     }
-    if (LATTICE && iter == 0) use_cache = cache_vote(sc, hits, tries);  // re-use rate of the first tile
+    if (LATTICE && iter == 0) {
+      bool unused_combine = true;
+      use_cache = cache_vote(sc, hits, tries, 0, 0, unused_combine);  // re-use rate of the first tile
+    }
   }
   if (LATTICE) sc.flush(grad_lattice + tbase);
 }
@@ -937,6 +995,29 @@ EncConv& enc_conv_state() {
 }  // namespace psdf
 
 // ================================================================================== C ABI
+// Position gradient only: the level-group kernel + the slab reduction when stream-ordered scratch is available (not while a
+// graph is being captured: there the float-atomic form runs), PSDF_ENC_POS_ATOMICS=1 forces the atomic form (A/B).
+template <int P_, int F_>
+static void launch_bwd_pos(int64_t N, int nr_levels, int Lt, int capacity, const float* positions, const float* lattice,
+                           const float* scale_factor, const float* shifts, const float* window, float points_scaling, int pad,
+                           const float* grad_sliced, const unsigned char* skip, float* grad_positions, hipStream_t st) {
+  static const bool force_atomics = getenv("PSDF_ENC_POS_ATOMICS") && atoi(getenv("PSDF_ENC_POS_ATOMICS")) != 0;
+  const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
+  const int groups = (Lt + POS_LPB - 1) / POS_LPB;
+  float* slabs = (groups > 1 && !force_atomics) ? (float*)psdf::stream_scratch((size_t)groups * N * P_ * sizeof(float), st) : nullptr;
+  if (slabs) {
+    hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_, true>), dim3(nb, groups), dim3(PSDF_BLOCK), 0, st, N, nr_levels, Lt,
+                       (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,
+                       points_scaling, pad, grad_sliced, skip, slabs);
+    hipLaunchKernelGGL(encode_bwd_pos_reduce_kernel, dim3(psdf_blocks(N * P_, PSDF_BLOCK)), dim3(PSDF_BLOCK), 0, st, N * P_, P_,
+                       groups, slabs, skip, grad_positions);
+  } else {
+    hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_, false>), dim3(nb, groups), dim3(PSDF_BLOCK), 0, st, N, nr_levels, Lt,
+                       (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,
+                       points_scaling, pad, grad_sliced, skip, grad_positions);
+  }
+}
+
 extern "C" {
 
 // The conventions in force, by index: 0 hash multiplier, 1 rank tie rule (both RUNTIME values: the defaults of
@@ -972,10 +1053,17 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);
+  static const bool xcd_mode = getenv("PSDF_ENC_FWD_XCD") && atoi(getenv("PSDF_ENC_FWD_XCD")) != 0;
+  int xcd_lpx = 0;
+  const int xcd_nb = (int)grid.x;
+  if (xcd_mode && N >= (1 << 18)) {
+    xcd_lpx = (Lt + 7) / 8;
+    grid = dim3((unsigned)(8 * xcd_lpx) * grid.x, 1);
+  }
 #define FWD(P_, F_)                                                                                            \
   hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, psdf::enc_conv_state(), \
                      positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced,  \
-                     touched, touch_shift, (capacity + (1 << touch_shift) - 1) >> touch_shift)
+                     touched, touch_shift, (capacity + (1 << touch_shift) - 1) >> touch_shift, xcd_lpx, xcd_nb, Lt)
   if (pos_dim == 3 && nr_feat == 2)
     FWD(3, 2);
   else if (pos_dim == 4 && nr_feat == 2)
@@ -1149,10 +1237,9 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     else if (grad_lattice)                                                                                       \
       BWD(P_, F_, true, false, false);                                                                           \
     else                                                                                                         \
-      hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, \
-                         st, N, nr_levels, Lt, (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, \
-                         points_scaling, pad_points(concat_points), grad_sliced, (const unsigned char*)nullptr,  \
-                         grad_positions);                                                                          \
+      launch_bwd_pos<P_, F_>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window,        \
+                             points_scaling, pad_points(concat_points), grad_sliced, (const unsigned char*)nullptr, \
+                             grad_positions, st);                                                                 \
     if (use_queue) {                                                                                             \
       const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                          \
       hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                              \
@@ -1220,11 +1307,9 @@ int psdf_encode_backward_positions_masked(int pos_dim, int nr_feat, int64_t N, i
     return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
-  const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
 #define POS(P_, F_)                                                                                                  \
-  hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_>), dim3(nb, (Lt + POS_LPB - 1) / POS_LPB), dim3(PSDF_BLOCK), 0, st, N,   \
-                     nr_levels, Lt, (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, points_scaling, \
-                     pad_points(concat_points), grad_sliced, skip, grad_positions)
+  launch_bwd_pos<P_, F_>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window, points_scaling, \
+                         pad_points(concat_points), grad_sliced, skip, grad_positions, st)
   if (pos_dim == 3 && nr_feat == 2)
     POS(3, 2);
   else if (pos_dim == 4 && nr_feat == 2)

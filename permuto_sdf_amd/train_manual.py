@@ -18,6 +18,9 @@ the feature gradient) -> `psdf_mlp_double_backward` (gradient w.r.t. features an
 `tests/test_gpu_train_step.py::test_manual_backward_equals_autograd` holds every gradient of this file against the autograd
 trainer's on the same batch.
 """
+import contextlib
+import os
+
 import torch
 
 from . import _lib as L
@@ -74,6 +77,14 @@ class ManualTrainer(Trainer):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         assert self.touched, "ManualTrainer accumulates the lattice gradients in the touched-rows buffers"
+        self.overlap_streams = os.environ.get("PSDF_TRAIN_STREAMS", "1") != "0"
+        self._side = None
+        self._events = [torch.cuda.Event() for _ in range(4)] if self.dev.type == "cuda" else []
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def _hand_written_step_applies(self):
         """The hand-written step is built on the fused compositing kernels (at most 256 samples per ray: foreground
@@ -110,20 +121,90 @@ class ManualTrainer(Trainer):
         _enc_dbl_scatter(enc, pts, win, g_n, dfeat, dX2)
         return _enc_bwd(enc, pts, win, dX2, want_pos=True, want_lattice=False) if want_pos else None
 
+    # ------------------------------------------------------------------ the background branch (NerfHash, models.py:431-526)
+    def _bg_forward(self, bg, calib):
+        """4-D lattice -> density + feature net -> [gelu(features), SH4(dir)] -> colour head -> (calibrated) sigmoid.  Everything
+        the compositing and the backward need, as a dict."""
+        bgn = self.bg
+        M = bg.samples_pos_4d.shape[0]
+        p4, dirs_b = bg.samples_pos_4d, bg.samples_dirs
+        feat4 = _enc_fwd(bgn.encoding, p4, bgn._win)
+        l1b = list(bgn.mlp_feat_and_density.layers)
+        w1b, b1b = [l.weight for l in l1b], [l.bias for l in l1b]
+        d1 = bgn.mlp_feat_and_density.dims
+        fd = mlp_forward_raw(d1, feat4, pack_params(d1, w1b, b1b))                        # [65, M]
+        gel = torch.nn.functional.gelu(fd[1:65])
+        sh4 = PermutoSDF.spherical_harmonics(dirs_b, 4)
+        x2 = torch.cat([gel, sh4.t()], 0)                                                 # [80, M]
+        l2b = list(bgn.mlp_rgb.layers)
+        w2b, b2b = [l.weight for l in l2b], [l.bias for l in l2b]
+        d2 = bgn.mlp_rgb.dims
+        rgbb_fm = mlp_forward_raw(d2, x2, pack_params(d2, w2b, b2b))                      # [3, M]
+        B = dict(p4=p4, feat4=feat4, fd=fd, x2=x2, l1b=l1b, w1b=w1b, b1b=b1b, d1=d1, l2b=l2b, w2b=w2b, b2b=b2b, d2=d2)
+        if calib is not None:
+            cw, cb = calib
+            B["rgbb_raw"] = rgbb_fm.t().contiguous()                                      # [M, 3]
+            B["ridx"] = RaySamplesPacked.compute_per_sample_ray_idx(bg.ray_start_end_idx, M).long()
+            B["rgbb"] = torch.sigmoid(B["rgbb_raw"] * cw.index_select(0, B["ridx"]) + cb.index_select(0, B["ridx"]))
+        else:
+            B["rgbb"] = sigmoid_rows_raw(rgbb_fm)
+        B["raw_den"] = fd[0]                                                              # [M], a row of the feature-major output
+        return B
+
+    def _bg_backward(self, B, g_raw, g_rgbb, calib, R):
+        """-> (g_cw, g_cb) of the colour calibration (or None, None); the networks' gradients are set / accumulated"""
+        bgn = self.bg
+        g_cw = g_cb = None
+        rgbb = B["rgbb"]
+        if calib is not None:
+            cw, _ = calib
+            g_pre_b = g_rgbb * rgbb * (1.0 - rgbb)                                        # sigmoid
+            g_cb = torch.zeros(R, 3, device=self.dev).index_add_(0, B["ridx"], g_pre_b)
+            g_cw = torch.zeros(R, 3, device=self.dev).index_add_(0, B["ridx"], g_pre_b * B["rgbb_raw"])
+            g_pre_b_fm = (g_pre_b * cw.index_select(0, B["ridx"])).t().contiguous()
+        else:
+            g_pre_b_fm = sigmoid_rows_backward_raw(g_rgbb, rgbb)                          # [3, M], one launch
+        dX2b, dW2b, db2b = mlp_backward_raw(B["d2"], B["x2"], B["w2b"], B["b2b"], g_pre_b_fm, need_dx=True)
+        _set_grads(B["l2b"], dW2b, db2b)
+        g_fd = torch.cat([g_raw.view(1, -1), torch.ops.aten.gelu_backward(dX2b[:64], B["fd"][1:65])], 0)      # [65, M]
+        dX4, dW1b, db1b = mlp_backward_raw(B["d1"], B["feat4"], B["w1b"], B["b1b"], g_fd, need_dx=True)
+        _set_grads(B["l1b"], dW1b, db1b)
+        _enc_bwd(bgn.encoding, B["p4"], bgn._win, dX4)
+        return g_cw, g_cb
+
     # ------------------------------------------------------------------ one iteration of the main phase
     def _main_phase(self, reel, it, git, eikonal_weight):
+        """Two streams (round 4; PSDF_TRAIN_STREAMS=0: one): the background branch is independent of the SDF / colour branch
+        between the samplers and the composition, and again between the composition's backward and the optimiser -- and every
+        kernel of a 49 152-sample step leaves most of the chip idle.  So the background forward runs on a side stream beside the
+        foreground forward, joins for `nerf_composite` (+ losses), and the background backward runs beside the foreground
+        backward.  Cross-stream tensors live until this function returns, after both streams have joined: the caching
+        allocator's per-stream pools never hand a block to new work that an unfinished kernel of the other stream still reads."""
         if not self._hand_written_step_applies():
             return Trainer._main_phase(self, reel, it, git, eikonal_weight)
         hp, dev = self.hp, self.dev
         cos_r = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
         forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream() if self.overlap_streams else None
+
+        def fork(ev):
+            if side is not None:
+                ev.record(main)
+                side.wait_event(ev)
+
+        def join(ev):
+            if side is not None:
+                ev.record(side)
+                main.wait_event(ev)
+        side_ctx = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         with torch.no_grad():
             o, d, gt, hit, img_idx, _ = self._draw_rays(reel)
             fg, bg = self._samples(o, d, it, True)
             R = o.shape[0]
             n_fg = fg.samples_pos.shape[0]
             cc = self.colorcal
-            sdfn, rgbn, bgn = self.sdf, self.rgb, self.bg
+            sdfn, rgbn = self.sdf, self.rgb
             gb = self.grad_buffers[0]
             lin = list(sdfn.mlp_sdf.layers)
             ws, bs = [l.weight for l in lin], [l.bias for l in lin]
@@ -134,7 +215,17 @@ class ManualTrainer(Trainer):
             inv_s = torch.exp(torch.tensor(float(forced_variance) * 10.0, device=dev)).clip(1e-6, 1e6).view(1)
             rgbn.last_inv_s = inv_s.view(())
             loss = L.zeroed_scalar(dev)     # ONE accumulator: every loss kernel of the step adds its (already weighted) term to it
+            calib = None
+            if cc is not None:              # per-ray calibration of both branches (models.py:384-385,523-524)
+                cam = img_idx.long()
+                fixed = (cam == cc.idx_with_fixed_calib)[:, None]
+                cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
+                cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
+                calib = (cw, cb)
             # ================================================================= forward
+            fork(self._events[0])
+            with side_ctx():
+                B = self._bg_forward(bg, calib)
             if n_fg:
                 pts, dirs = fg.samples_pos, fg.samples_dirs
                 feat = _enc_fwd(sdfn.encoding, pts, win)
@@ -153,10 +244,6 @@ class ManualTrainer(Trainer):
                 if cc is not None:
                     rgb_raw = rgb_fm.t().contiguous()                                                            # [N, 3]
                     ridx_fg = RaySamplesPacked.compute_per_sample_ray_idx(fg.ray_start_end_idx, n_fg).long()
-                    cam = img_idx.long()
-                    fixed = (cam == cc.idx_with_fixed_calib)[:, None]
-                    cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
-                    cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
                     rgb = torch.sigmoid(rgb_raw * cw.index_select(0, ridx_fg) + cb.index_select(0, ridx_fg))
                 else:
                     rgb = sigmoid_rows_raw(rgb_fm)
@@ -166,37 +253,18 @@ class ManualTrainer(Trainer):
             else:
                 pred_fg = torch.zeros(R, 3, device=dev)
                 bgT = torch.ones(R, 1, device=dev)
-            # background NeRF
-            M = bg.samples_pos_4d.shape[0]
-            p4, dirs_b = bg.samples_pos_4d, bg.samples_dirs
-            feat4 = _enc_fwd(bgn.encoding, p4, bgn._win)
-            l1b = list(bgn.mlp_feat_and_density.layers)
-            w1b, b1b = [l.weight for l in l1b], [l.bias for l in l1b]
-            d1 = bgn.mlp_feat_and_density.dims
-            fd = mlp_forward_raw(d1, feat4, pack_params(d1, w1b, b1b))                        # [65, M]
-            gel = torch.nn.functional.gelu(fd[1:65])
-            sh4 = PermutoSDF.spherical_harmonics(dirs_b, 4)
-            x2 = torch.cat([gel, sh4.t()], 0)                                                 # [80, M]
-            l2b = list(bgn.mlp_rgb.layers)
-            w2b, b2b = [l.weight for l in l2b], [l.bias for l in l2b]
-            d2 = bgn.mlp_rgb.dims
-            rgbb_fm = mlp_forward_raw(d2, x2, pack_params(d2, w2b, b2b))                      # [3, M]
-            if cc is not None:
-                rgbb_raw = rgbb_fm.t().contiguous()                                           # [M, 3]
-                ridx_bg = RaySamplesPacked.compute_per_sample_ray_idx(bg.ray_start_end_idx, M).long()
-                if not n_fg:
-                    cam = img_idx.long()
-                    fixed = (cam == cc.idx_with_fixed_calib)[:, None]
-                    cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
-                    cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
-                rgbb = torch.sigmoid(rgbb_raw * cw.index_select(0, ridx_bg) + cb.index_select(0, ridx_bg))
-            else:
-                rgbb = sigmoid_rows_raw(rgbb_fm)
-            raw_den = fd[0]                                                                   # [M], a row of the feature-major output
+            join(self._events[1])
+            raw_den, rgbb = B["raw_den"], B["rgbb"]
             # softplus -> opacity -> transmittance -> weights -> background radiance -> pred = pred_fg + bgT * pred_bg: one launch
             _, pred = nerf_composite_forward_raw(bg, raw_den, rgbb, pred_fg, bgT)
             # ---- losses (forward values; their gradients are produced by the same launches)
             _, g_pred = l1_loss_raw(pred, gt, hit, loss=loss)
+            # pred = pred_fg + bgT * pred_bg and the whole background compositing backward, one launch; then the background
+            # networks' backward leaves for the side stream while this one goes on with the SDF losses
+            g_raw, g_rgbb, g_bgT = nerf_composite_backward_raw(bg, hp.nr_samples_bg, g_pred, raw_den, rgbb, bgT)
+            fork(self._events[2])
+            with side_ctx():
+                g_cw_bg, g_cb_bg = self._bg_backward(B, g_raw, g_rgbb, calib, R)
             g_n = None
             curv = None
             if n_fg:
@@ -221,31 +289,15 @@ class ManualTrainer(Trainer):
                    L.ptr(loss), L.ptr(g_so), L.stream())
             self._refresh_and_adapt(it, git, n_fg)
 
-            # ================================================================= backward
-            # pred = pred_fg + bgT * pred_bg and the whole background compositing, one launch
-            g_raw, g_rgbb, g_bgT = nerf_composite_backward_raw(bg, hp.nr_samples_bg, g_pred, raw_den, rgbb, bgT)
+            # ================================================================= backward (foreground; the background's is under way)
             g_cw = g_cb = None
-            if cc is not None:
-                g_pre_b = g_rgbb * rgbb * (1.0 - rgbb)                                        # sigmoid
-                g_cb = torch.zeros(R, 3, device=dev).index_add_(0, ridx_bg, g_pre_b)
-                g_cw = torch.zeros(R, 3, device=dev).index_add_(0, ridx_bg, g_pre_b * rgbb_raw)
-                g_pre_b_fm = (g_pre_b * cw.index_select(0, ridx_bg)).t().contiguous()
-            else:
-                g_pre_b_fm = sigmoid_rows_backward_raw(g_rgbb, rgbb)                          # [3, M], one launch
-            dX2b, dW2b, db2b = mlp_backward_raw(d2, x2, w2b, b2b, g_pre_b_fm, need_dx=True)
-            _set_grads(l2b, dW2b, db2b)
-            g_fd = torch.cat([g_raw.view(1, -1), torch.ops.aten.gelu_backward(dX2b[:64], fd[1:65])], 0)      # [65, M]
-            dX4, dW1b, db1b = mlp_backward_raw(d1, feat4, w1b, b1b, g_fd, need_dx=True)
-            _set_grads(l1b, dW1b, db1b)
-            _enc_bwd(bgn.encoding, p4, bgn._win, dX4)
-            # ---- foreground
             if n_fg:
                 g_sdf, g_nc, g_rgb, _ = neus_composite_backward_raw(fg, per_ray, g_pred.contiguous(), g_bgT.contiguous(), sdf_col, n,
                                                                     rgb, inv_s, cos_r, need_grad=True, need_rgb=True, need_inv_s=False)
                 if cc is not None:
                     g_pre = g_rgb * rgb * (1.0 - rgb)
-                    g_cb.index_add_(0, ridx_fg, g_pre)
-                    g_cw.index_add_(0, ridx_fg, g_pre * rgb_raw)
+                    g_cb = torch.zeros(R, 3, device=dev).index_add_(0, ridx_fg, g_pre)
+                    g_cw = torch.zeros(R, 3, device=dev).index_add_(0, ridx_fg, g_pre * rgb_raw)
                     g_pre_fm = (g_pre * cw.index_select(0, ridx_fg)).t().contiguous()
                 else:
                     g_pre_fm = sigmoid_rows_backward_raw(g_rgb, rgb)
@@ -272,7 +324,10 @@ class ManualTrainer(Trainer):
             g_yo[0] = g_so
             dXo, _, _ = mlp_backward_raw(dims_s, feat_o, ws, bs, g_yo, need_dx=True, into=(gb.dWs, gb.dbs))
             _enc_bwd(sdfn.encoding, off, win, dXo)
+            join(self._events[3])
             if cc is not None:
+                g_cw = g_cw_bg if g_cw is None else g_cw_bg + g_cw         # background first, as the single-stream order added them
+                g_cb = g_cb_bg if g_cb is None else g_cb_bg + g_cb
                 fixed3 = fixed.expand(-1, 3)
                 gwd = torch.zeros_like(cc.weight_delta).index_add_(0, cam, torch.where(fixed3, torch.zeros_like(g_cw), g_cw))
                 gbi = torch.zeros_like(cc.bias).index_add_(0, cam, torch.where(fixed3, torch.zeros_like(g_cb), g_cb))
