@@ -106,7 +106,19 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     int s, e;
     ri.get(ray, s, e);
     if (!ri.valid(s, e)) continue;          // their per-sample gradients: see the host wrapper (zero-filled for such containers)
-    const int n = e - s;                    // <= 64 K (checked by the launcher through max_per_ray)
+    const int n = e - s;                    // <= 64 K is the CALLER'S promise (max_per_ray)
+    if (n > 64 * K) {
+      // a ray longer than declared: the chunked scans below would silently drop its tail.  Fail loudly instead: every
+      // gradient of this ray becomes NaN (the C ABI has no other error channel out of a kernel).
+      const float bad = __int_as_float(0x7fc00000);
+      for (int i = lane; i < n; i += 64) {
+        const int64_t m = (int64_t)s + i;
+        g_sdf[m] = bad;
+        if (g_rgb) g_rgb[3 * m] = g_rgb[3 * m + 1] = g_rgb[3 * m + 2] = bad;
+        if (g_gradients) st3(g_gradients + 3 * m, mk3(bad, bad, bad));
+      }
+      continue;
+    }
     const float gx = g_pred[3 * ray], gy = g_pred[3 * ray + 1], gz = g_pred[3 * ray + 2];
     float a_[K], T_[K], gw_[K], v_[K];
     float carry = 1.f;
@@ -264,6 +276,16 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       continue;
     }
     const int n = e - s;
+    if (n > 64 * K) {   // longer than the caller declared: fail loudly (see neus_composite_bwd_kernel)
+      const float bad = __int_as_float(0x7fc00000);
+      for (int i = lane; i < n; i += 64) {
+        const int64_t m = (int64_t)s + i;
+        g_raw[m] = bad;
+        g_rgb[3 * m] = g_rgb[3 * m + 1] = g_rgb[3 * m + 2] = bad;
+      }
+      if (g_fg_bg && lane == 0) g_fg_bg[ray] = bad;
+      continue;
+    }
     const float gx = t * ux, gy = t * uy, gz = t * uz;                                       // dL/d pred_bg
     float a_[K], T_[K], gw_[K], v_[K], e_[K];
     float carry = 1.f, pr = 0.f, pg = 0.f, pb = 0.f;

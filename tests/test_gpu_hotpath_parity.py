@@ -216,8 +216,17 @@ def test_cfg2_full_batch_dense_gradient_against_float64(dev, dy_kind):
             idx = po.vertex_indices(rem0, rank, T_)
             bw = bary[:, :4].double()
             gl = x.grad[:, l * F_:(l + 1) * F_]
-            for r in range(4):
-                g64[l].index_add_(0, idx[:, r], gl * bw[:, r:r + 1])
+            # float64 scatter WITHOUT atomics (a coarse level sends the whole chunk to a handful of rows: float64 atomics on one
+            # address serialise for seconds): sort by row, running sum, differences at the row boundaries
+            rows_all = idx.t().reshape(-1)                                             # [4 n]: vertex 0 of every sample, then 1, ...
+            vals_all = torch.cat([gl * bw[:, r:r + 1] for r in range(4)], 0)           # [4 n, F]
+            order = torch.argsort(rows_all)
+            rs_, cs_ = rows_all[order], vals_all[order].cumsum(0)
+            uniq, counts = torch.unique_consecutive(rs_, return_counts=True)
+            ends = counts.cumsum(0) - 1
+            seg = cs_[ends]
+            seg[1:] = seg[1:] - cs_[ends[:-1]]
+            g64[l][uniq] += seg
             if c0 == 0:     # the rows / weights used for the float64 scatter are the kernel's: they reproduce its features
                 f_chk = sum(enc.lattice_values[l].detach().double().index_select(0, idx[:, r]) * bw[:, r:r + 1] for r in range(4))
                 e_rows = max(e_rows, float((f_chk - feat[l * F_:(l + 1) * F_, sl].t().double()).abs().max()))

@@ -350,3 +350,41 @@ def test_nerf_composite_equals_the_operator_chain(dev, layout):
     pb3, none = nerf_composite_forward_raw(rs, raw, rgb)
     assert none is None
     close(pb, pb3)
+
+
+def test_fused_backward_poisons_rays_longer_than_declared(dev):
+    """`max_per_ray` is the caller's promise.  A ray that holds more samples than declared used to lose its tail
+    silently (gradients of the dropped samples never written); now every gradient of such a ray is NaN -- loud -- and the rays
+    that keep the promise are untouched."""
+    from permuto_sdf import RaySamplesPacked
+    from permuto_sdf_amd.neus import (nerf_composite_backward_raw, nerf_composite_forward_raw, neus_composite_backward_raw,
+                                      neus_composite_forward_raw)
+    g = torch.Generator().manual_seed(9)
+    counts = torch.tensor([40, 100, 64, 7])              # declared: at most 64 per ray -> ray 1 breaks the promise
+    ends = torch.cumsum(counts, 0)
+    starts = ends - counts
+    R, N = 4, int(ends[-1])
+    sdf, dirs, grad, dt = _inputs(N, 5, scale=0.01)
+    rgb = torch.rand(N, 3, generator=g).to(dev)
+    rs = RaySamplesPacked(R, N, device=dev)
+    rs.ray_start_end_idx = torch.stack([starts, ends], 1).to(torch.int32).to(dev)
+    rs.samples_dirs, rs.samples_dt = dirs.to(dev), dt.to(dev)
+    rs.cur_nr_samples.fill_(N)
+    inv_s = torch.tensor([300.0], device=dev)
+    sdf_d, grad_d = sdf.to(dev), grad.to(dev)
+    g_pred, g_bg = torch.randn(R, 3, generator=g).to(dev), torch.randn(R, 1, generator=g).to(dev)
+    ok = neus_composite_backward_raw(rs, 128, g_pred, g_bg, sdf_d, grad_d, rgb, inv_s, 0.6, need_inv_s=False)      # honest bound
+    bad = neus_composite_backward_raw(rs, 64, g_pred, g_bg, sdf_d, grad_d, rgb, inv_s, 0.6, need_inv_s=False)
+    lo, hi = int(starts[1]), int(ends[1])
+    for a, b in zip(ok[:3], bad[:3]):
+        assert torch.isfinite(a).all()
+        assert torch.isnan(b[lo:hi]).all()
+        keep = torch.ones(N, dtype=torch.bool, device=dev)
+        keep[lo:hi] = False
+        assert torch.equal(a[keep], b[keep])
+    raw = torch.randn(N, generator=g).to(dev)
+    fg_pred, fg_bg = torch.rand(R, 3, generator=g).to(dev), torch.rand(R, 1, generator=g).to(dev)
+    ok = nerf_composite_backward_raw(rs, 128, g_pred, raw, rgb, fg_bg)
+    bad = nerf_composite_backward_raw(rs, 64, g_pred, raw, rgb, fg_bg)
+    assert torch.isfinite(ok[0]).all() and torch.isnan(bad[0][lo:hi]).all() and torch.isnan(bad[2][1]).all()
+    assert torch.equal(ok[0][:lo], bad[0][:lo]) and torch.equal(ok[2][[0, 2, 3]], bad[2][[0, 2, 3]])

@@ -12,6 +12,12 @@
 Compared: the loss, every dense parameter gradient, the three lattice gradients -- as the optimiser is about to see them.
 Also the sphere-initialisation step (train_permuto_sdf.py:322-330: the reference's own `loss_sphere_init`).
 
+Every comparison is made twice: with each trainer's OWN foreground samples (the whole step, sampling included) and with the
+reference's foreground samples handed to the trainer (`*_same_samples`: only the step itself differs).  And the reference is run
+against ITSELF with the hidden units of its SDF MLP re-numbered (the same function, another fp32 summation order):
+`reference_self_noise` is the size of the reference's own rounding noise at that state -- the importance samples follow the SDF
+values, the finest lattice levels have cells of 1e-4, so last-bit differences of the SDF move samples across cells.
+
 What is shared: the networks' state (written in the reference's checkpoint layout and loaded by the reference's classes),
 the occupancy grid, the rays (`PermutoSDF.random_rays_from_reel` drawn once), torch's generators (seeded alike before each
 run: the curvature term's `randn_like` and `rand_points_inside` draw the same numbers) and the three PCG32 jitter generators
@@ -183,20 +189,21 @@ def main():
             tr.iter = git
             tr.capture_grads = {}
             orig = tr._samples
-            if shared_fg is not None:
-                def patched(o_, d_, it_, jitter=True):
-                    fg_own, bg_own = orig(o_, d_, it_, jitter)
-                    return shared_fg, bg_own
-                tr._samples = patched
+            seen = {}
+
+            def patched(o_, d_, it_, jitter=True):
+                fg_own, bg_own = orig(o_, d_, it_, jitter)
+                seen["fg"] = fg_own
+                return (shared_fg if shared_fg is not None else fg_own), bg_own
+            tr._samples = patched
             try:
                 tr.step(reel)
             finally:
-                if shared_fg is not None:
-                    del tr._samples
+                del tr._samples
             torch.cuda.synchronize()
             g, l = our_named_grads(tr)
             tr.capture_grads = None
-            return g, l, dict(tr.last)
+            return g, l, dict(tr.last), seen.get("fg")
 
         def run_reference(mode, it, git, seed, permute_seed=None):
             """the reference's own step from the snapshot.  permute_seed: re-number the hidden units of the reference's SDF MLP
@@ -304,9 +311,20 @@ def main():
             with default_tensor(False):
                 for name, tr in (("manual", trm), ("autograd", tra)):
                     for variant in (("", None),) + ((("_same_samples", fg_ref),) if fg_ref is not None else ()):
-                        g, l, last = run_ours(tr, git, shared_fg=variant[1])
+                        g, l, last, fg_own = run_ours(tr, git, shared_fg=variant[1])
                         case[name + variant[0]] = dict(compare(g, gref), loss=l, loss_rel=abs(l - loss_ref) / abs(loss_ref),
                                                        nr_fg_samples=last.get("nr_fg_samples"))
+                        if variant[1] is None and fg_ref is not None and fg_own is not None:
+                            # how far this trainer's OWN foreground samples are from the reference's (same rays, same jitter
+                            # streams; the importance samples follow each side's own SDF evaluations)
+                            a_, b_ = fg_own.samples_z.reshape(-1), fg_ref.samples_z.reshape(-1)
+                            st = {"same_count": bool(a_.numel() == b_.numel()),
+                                  "same_ranges": bool(torch.equal(fg_own.ray_start_end_idx, fg_ref.ray_start_end_idx))}
+                            if st["same_count"]:
+                                dz = (a_ - b_).abs()
+                                st.update(identical=int((dz == 0).sum()), of=int(dz.numel()), max_abs_dz=float(dz.max()),
+                                          above_1e_6=int((dz > 1e-6).sum()), above_1e_4=int((dz > 1e-4).sum()))
+                            case[name + variant[0]]["own_samples_vs_reference"] = st
                         del g
             out["cases"][mode] = case
             del gref
