@@ -26,23 +26,13 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
                       const float* __restrict__ shifts, const float* __restrict__ window, float points_scaling,
                       int pad_points, const unsigned char* __restrict__ skip, float* __restrict__ sliced,
-                      unsigned char* __restrict__ touched, int touch_shift, int blocks_per_level, int xcd_lpx = 0,
-                      int xcd_nb = 0, int xcd_lt = 0) {
-  // Two launch shapes.  Default: grid (point tiles, levels), tiles fastest -- the chip sweeps one level's table at a time and
-  // every XCD's L2 holds (its own copy of) that one table.  XCD-pinned (xcd_lpx > 0; measurement switch PSDF_ENC_FWD_XCD=1, round
-  // 4): a 1-D grid whose workgroup id i lands on XCD i % 8 (round-robin dispatch); XCD k takes `xcd_lpx` levels of the
-  // coarse/fine-interleaved order 0, Lt-1, 1, Lt-2, ... for ALL points, so a table is fetched into ONE L2 instead of eight.
-  int64_t tile = blockIdx.x;
-  int level = blockIdx.y;
-  if (xcd_lpx > 0) {
-    const int64_t id = blockIdx.x;
-    const int xcd = (int)(id & 7);
-    const int64_t slot = id >> 3;
-    const int li = xcd * xcd_lpx + (int)(slot / xcd_nb);
-    if (li >= xcd_lt) return;
-    level = (li & 1) ? xcd_lt - 1 - (li >> 1) : (li >> 1);
-    tile = slot % xcd_nb;
-  }
+                      unsigned char* __restrict__ touched, int touch_shift, int blocks_per_level) {
+  // (Round 4 measured an XCD-pinned shape -- a 1-D grid whose workgroup id i lands on XCD i % 8, each XCD taking two or three
+  // levels for ALL points so that a table is fetched into one L2 instead of eight: 0.358 -> 0.631 ms at 2 M points, 16 levels
+  // (profiles/r04_enc_ab.jsonl).  Eight XCDs streaming eight different tables each touch every position and write every
+  // output row with 1/8 of the chip; the level-at-a-time sweep below keeps all 256 CUs on one 2-MiB table.)
+  const int64_t tile = blockIdx.x;
+  const int level = blockIdx.y;
   const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
   if (n >= N) return;
   if (skip && skip[n]) return;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
@@ -194,7 +184,7 @@ struct ScatterCache {
   static constexpr int SC_SLOTS = TOTAL / F;  // F=2, TOTAL 8192: 16 KiB tags + 32 KiB sums
   uint32_t* tags;
   float* sums;
-  int* stats;  // [0] = hits, [1] = tries, [2] = enabled, [3] = contributions of the first tile, [4] = of them run owners
+  int* stats;  // [0] = hits, [1] = tries, [2] = enabled
   __device__ __forceinline__ void init(float* lds) {
     tags = reinterpret_cast<uint32_t*>(lds);
     sums = lds + SC_SLOTS;
@@ -205,8 +195,6 @@ struct ScatterCache {
       stats[0] = 0;
       stats[1] = 0;
       stats[2] = 1;
-      stats[3] = 0;
-      stats[4] = 0;
     }
     __syncthreads();
   }
@@ -237,35 +225,23 @@ struct ScatterCache {
       }
     }
   }
-  static constexpr size_t bytes() { return (size_t)(SC_SLOTS + SC_SLOTS * F + 8) * 4; }
+  static constexpr size_t bytes() { return (size_t)(SC_SLOTS + SC_SLOTS * F + 4) * 4; }
 };
 
 // ----------------------------------------------------------------------------------------- backward
 // grad_lattice[l][row][f] += bary_r * w_l * g[l][f][n]            (LDS-privatised, then fp32 L2 atomics)
 // grad_pos[n][i]          += dL/dpos_i  (chain through barycentric -> elevated -> position)
 // Launch: grid (B, Lt), workgroup b of level l walks point tiles b, b+B, ...
-#if !defined(PSDF_ENC_COMBINE_VOTE)
-#define PSDF_ENC_COMBINE_VOTE 1   // 0: every tile runs the DPP run combine (the round-3 kernel; A/B builds)
-#endif
 template <typename SC>
-__device__ __forceinline__ bool cache_vote(SC& sc, int hits, int tries, int contribs, int owners, bool& use_combine) {
-  // called by every thread of the workgroup after its first tile; returns the workgroup-uniform decisions
+__device__ __forceinline__ bool cache_vote(SC& sc, int hits, int tries) {
+  // called by every thread of the workgroup after its first tile; returns the workgroup-uniform decision
   hits = (int)psdf::wave_sum((float)hits);
   tries = (int)psdf::wave_sum((float)tries);
-  contribs = (int)psdf::wave_sum((float)contribs);
-  owners = (int)psdf::wave_sum((float)owners);
   if (psdf::lane_id() == 0) {
     atomicAdd(&sc.stats[0], hits);
     atomicAdd(&sc.stats[1], tries);
-    atomicAdd(&sc.stats[3], contribs);
-    atomicAdd(&sc.stats[4], owners);
   }
   __syncthreads();
-  // The run combine (segmented DPP scan per vertex: ~160 of the ~590 VALU instructions per point and level) pays where
-  // neighbouring samples share lattice rows.  On the finest levels they do not (a simplex is smaller than the sample spacing):
-  // when fewer than 1 in 16 contributions of the first tile were merged into a neighbour's, the rest of the walk skips it --
-  // every lane then owns its contribution, exactly what the combine would have found almost everywhere.
-  use_combine = !PSDF_ENC_COMBINE_VOTE || (sc.stats[3] - sc.stats[4]) * 16 >= sc.stats[3];
   return sc.stats[0] * 8 >= sc.stats[1];  // keep the cache when >= 1/8 of the first tile hit an existing entry
 }
 
@@ -480,9 +456,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
   int* q_cnt = reinterpret_cast<int*>(lds + SCache::bytes() / 4);  // [Q_MAX_PARTS]
   int* q_base = q_cnt + Q_MAX_PARTS;                                          // [Q_MAX_PARTS]
   int* q_off = q_base + Q_MAX_PARTS;                                          // [Q_MAX_PARTS + 1]
-  bool use_cache = LATTICE, use_combine = true;
+  bool use_cache = LATTICE;
   int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
-  int hits = 0, tries = 0, iter = 0, contribs = 0, owners = 0;
+  int hits = 0, tries = 0, iter = 0;
   const float w = window[level];
   const int64_t tbase = (int64_t)level * capacity * F;
   float sfl[P], shl[P];
@@ -617,12 +593,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
       for (int c = 0; c < NC; c++) {
         // (also when the cache has been voted off: skipping the combine there was measured, round 3 -- encode backward pair
         // 0.78 -> 0.92 ms, the runs of the mid levels are what keeps their queue traffic down)
-        // use_combine is workgroup-uniform (voted after the first tile): no lane is left out of the DPP scan
-        const bool own = use_combine ? combine_runs16<F>(crow[c], pending[c], cval[c]) : pending[c];
-        if (iter == 0) {
-          contribs += pending[c];
-          owners += own;
-        }
+        // (also where neighbouring samples do not share rows -- the finest levels: a per-workgroup vote that skips the combine
+        // when the first tile merged < 1/16 of its contributions was measured in round 4 and made the pair SLOWER, 0.798 ->
+        // 0.835 ms on the bench step, profiles/r04_bench_combine_vote_ab.txt: the scan is cheaper than the vote's bookkeeping)
+        const bool own = combine_runs16<F>(crow[c], pending[c], cval[c]);
         bool absorbed = false;
         if (own && use_cache) {
           const int rc = sc.add(crow[c], cval[c], hot);
@@ -661,7 +635,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
       }
     }
     if (LATTICE && iter == 0) {
-      use_cache = cache_vote(sc, hits, tries, contribs, owners, use_combine);  // re-use rate / merged share of the first tile
+      use_cache = cache_vote(sc, hits, tries);  // re-use rate of the first tile
       if (QUEUE && !use_cache) cache_drain_to_queue<F>(sc, Q, level, q_cnt, q_base, grad_lattice + tbase);
     }
   }
@@ -683,10 +657,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 // levels and sums their contributions in registers before it touches grad_positions: a quarter of the atomics of the
 // general kernel (which also carries the scatter-cache / queue machinery of the lattice gradient) while the 4 tables
 // of a group (8 MiB) still mostly live in the L2s.
-// PARTIAL (round 4): the level groups do not meet in grad_positions with float atomics (3 per point and group: at 2 M points
-// x 5 groups 30 M atomics against a ceiling of ~21 G/s -- the atomics, not the gathers, made this kernel 3x as slow as the
-// forward); each group stores its sum to its own [N, P] slab of a scratch buffer (plain coalesced stores) and
-// encode_bwd_pos_reduce_kernel adds the slabs into grad_positions: 2 x 12 B per point and group of extra traffic.
+// PARTIAL (round 4): the level groups do not meet in grad_positions with float atomics; each group stores its sum to its own
+// [N, P] slab of a scratch buffer (plain coalesced stores) and encode_bwd_pos_reduce_kernel adds the slabs in group order.
+// What it buys is DETERMINISM, not time: the position gradient (the normals of every training step, whose last bits the
+// curvature term amplifies) no longer depends on the order in which atomics land.  Measured (profiles/r04_enc_ab.jsonl, 2 M
+// points, 16 levels): 0.634 ms against 0.644 ms with atomics -- the 30 M atomics were NOT what makes this kernel 1.8x the
+// forward (0.358 ms); 49 152 points x 24 levels: 30.8 against 28.8 us (one more launch).
 constexpr int POS_LPB = 4;
 template <int P, int F, bool PARTIAL = false>
 __global__ void __launch_bounds__(PSDF_BLOCK)
@@ -893,9 +869,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
   ScatterCache<F> sc;
   if (LATTICE) sc.init(lds);
-  bool use_cache = LATTICE, use_combine = true;
+  bool use_cache = LATTICE;
   int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
-  int hits = 0, tries = 0, iter = 0, contribs = 0, owners = 0;
+  int hits = 0, tries = 0, iter = 0;
   const int64_t tbase = (int64_t)level * capacity * F;
   float sfl[P], shl[P];
 #pragma unroll
@@ -971,10 +947,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 #pragma unroll
       for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = gg[f];
     }
-    if (LATTICE && iter == 0) {
-      bool unused_combine = true;
-      use_cache = cache_vote(sc, hits, tries, 0, 0, unused_combine);  // re-use rate of the first tile
-    }
+    if (LATTICE && iter == 0) use_cache = cache_vote(sc, hits, tries);  // re-use rate of the first tile
   }
   if (LATTICE) sc.flush(grad_lattice + tbase);
 }
@@ -1053,17 +1026,10 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);
-  static const bool xcd_mode = getenv("PSDF_ENC_FWD_XCD") && atoi(getenv("PSDF_ENC_FWD_XCD")) != 0;
-  int xcd_lpx = 0;
-  const int xcd_nb = (int)grid.x;
-  if (xcd_mode && N >= (1 << 18)) {
-    xcd_lpx = (Lt + 7) / 8;
-    grid = dim3((unsigned)(8 * xcd_lpx) * grid.x, 1);
-  }
 #define FWD(P_, F_)                                                                                            \
   hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, psdf::enc_conv_state(), \
                      positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced,  \
-                     touched, touch_shift, (capacity + (1 << touch_shift) - 1) >> touch_shift, xcd_lpx, xcd_nb, Lt)
+                     touched, touch_shift, (capacity + (1 << touch_shift) - 1) >> touch_shift)
   if (pos_dim == 3 && nr_feat == 2)
     FWD(3, 2);
   else if (pos_dim == 4 && nr_feat == 2)

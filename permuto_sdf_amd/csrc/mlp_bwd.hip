@@ -1143,7 +1143,11 @@ int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, c
   return PSDF_OK;
 }
 
-template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+// WITH_DW = false: only the data-gradient instantiation exists for this shape.  The 64-wide nets with MANY outputs take their
+// parameter gradients from the workgroup-cooperative kernel (mlp_wide.hip); their single-wave dW instantiations spilled 128 - 253
+// registers and were reachable only while a stream was being captured -- they are not built any more (round 4): such a call
+// returns PSDF_ERR_UNSUPPORTED (tests/test_dispatch_tables.py lists every instantiation that still spills, with its route).
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool WITH_DW = true>
 int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
   constexpr int NW = (T1 <= 2 && T2 <= 2 && T3 <= 2) ? 8 : BW;   // 32-wide nets: two waves per SIMD
   const int64_t ntiles = (N + 15) / 16;
@@ -1164,6 +1168,9 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
     PSDF_LAUNCH_CHECK();
     return PSDF_OK;
   }
+  if constexpr (!WITH_DW) {
+    return PSDF_ERR_UNSUPPORTED;
+  } else {
   const size_t shmem = ((size_t)img + NW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
   if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
 #define GO(DX)                                                                                                     \
@@ -1183,6 +1190,7 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
   grad_scratch_reduce(p, ap, (int)blocks, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
+  }
 }
 
 }  // namespace
@@ -1256,8 +1264,7 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   // 64-wide nets with MANY outputs (the background density / feature net 52 -> 64 x 3 -> 65, and 64 x 3 -> 33): their dW does
   // not fit one wave's registers (the single-wave instantiations below spill 213-227 registers) -- the workgroup-cooperative
   // kernel of mlp_wide.hip splits the dW rows over 8 waves.  -2 (no stream-ordered scratch: capture) falls through.
-  const char* many = getenv("PSDF_MLP_BWD_WIDE_MANY");     // "0": keep the single-wave kernel (A/B measurements)
-  if (dW && n_layers == 4 && to >= 2 && t1 == 4 && t2 == 4 && t3 == 4 && !(many && many[0] == '0')) {
+  if (dW && n_layers == 4 && to >= 2 && t1 == 4 && t2 == 4 && t3 == 4) {
     const int r = psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
     if (r != PSDF_ERR_UNSUPPORTED) {
       psdf::g_last_path[psdf::PATH_MLP_BWD] = 3;
@@ -1265,9 +1272,11 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
     }
   }
   psdf::g_last_path[psdf::PATH_MLP_BWD] = 1;
-#define CASE(I, A, B, C, O, D)                                                   \
+#define CASE_(I, A, B, C, O, D, W)                                               \
   if (ti0 == I && t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
-    return launch_bwd<I, A, B, C, O, D>(p, N, X, dY, dX, a, st);
+    return launch_bwd<I, A, B, C, O, D, W>(p, N, X, dY, dX, a, st);
+#define CASE(I, A, B, C, O, D) CASE_(I, A, B, C, O, D, true)
+#define CASE_DX_ONLY(I, A, B, C, O, D) CASE_(I, A, B, C, O, D, false)
   CASE(3, 4, 4, 4, 1, true)   // 33..48 -> 64x3 -> 1..4   (BASELINE SDF net on a 16-level encoding)
   CASE(4, 4, 4, 4, 1, true)   // 49..64 -> 64x3 -> 1..4   (24-level encoding)
   CASE(2, 4, 4, 4, 1, true)   // 17..32 -> 64x3 -> 1..4   (small encodings)
@@ -1276,11 +1285,13 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   CASE(2, 2, 2, 2, 1, true)   // 17..32 -> 32x3 -> 1..4
   CASE(4, 2, 2, 2, 3, false)  // 52 -> 32x3 -> 33         (reference SDF net, models.py:153-161)
   CASE(3, 2, 2, 2, 3, false)  // 36 -> 32x3 -> 33         (same net on a 16-level encoding)
-  CASE(4, 4, 4, 4, 5, false)  // 52 -> 64x3 -> 65         (background density net, models.py:451-459)
-  CASE(4, 4, 4, 4, 3, false)  // 52 -> 64x3 -> 33
-  CASE(3, 4, 4, 4, 3, false)  // 36 -> 64x3 -> 33
+  CASE_DX_ONLY(4, 4, 4, 4, 5, false)  // 52 -> 64x3 -> 65  (background density net, models.py:451-459): dX here, dW in mlp_wide.hip
+  CASE_DX_ONLY(4, 4, 4, 4, 3, false)  // 52 -> 64x3 -> 33
+  CASE_DX_ONLY(3, 4, 4, 4, 3, false)  // 36 -> 64x3 -> 33
   CASE(5, 4, 4, 0, 1, true)   // 80 -> 64x2 -> 3          (background colour head, models.py:463-469)
 #undef CASE
+#undef CASE_DX_ONLY
+#undef CASE_
   // nets too wide for one wave's registers (the 128-wide colour network): workgroup-cooperative kernel, mlp_wide.hip
   psdf::g_last_path[psdf::PATH_MLP_BWD] = 3;
   if (dW) return psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);

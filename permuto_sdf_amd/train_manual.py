@@ -77,7 +77,8 @@ class ManualTrainer(Trainer):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         assert self.touched, "ManualTrainer accumulates the lattice gradients in the touched-rows buffers"
-        self.overlap_streams = os.environ.get("PSDF_TRAIN_STREAMS", "1") != "0"
+        # second stream for the background branch: OFF by default -- measured slower (see _main_phase); PSDF_TRAIN_STREAMS=1 turns it on
+        self.overlap_streams = os.environ.get("PSDF_TRAIN_STREAMS", "0") == "1"
         self._side = None
         self._events = [torch.cuda.Event() for _ in range(4)] if self.dev.type == "cuda" else []
 
@@ -174,12 +175,15 @@ class ManualTrainer(Trainer):
 
     # ------------------------------------------------------------------ one iteration of the main phase
     def _main_phase(self, reel, it, git, eikonal_weight):
-        """Two streams (round 4; PSDF_TRAIN_STREAMS=0: one): the background branch is independent of the SDF / colour branch
-        between the samplers and the composition, and again between the composition's backward and the optimiser -- and every
-        kernel of a 49 152-sample step leaves most of the chip idle.  So the background forward runs on a side stream beside the
-        foreground forward, joins for `nerf_composite` (+ losses), and the background backward runs beside the foreground
-        backward.  Cross-stream tensors live until this function returns, after both streams have joined: the caching
-        allocator's per-stream pools never hand a block to new work that an unfinished kernel of the other stream still reads."""
+        """One stream by default.  PSDF_TRAIN_STREAMS=1 (round 4, measured and NOT kept as the default): the background branch is
+        independent of the SDF / colour branch between the samplers and the composition, and again between the composition's
+        backward and the optimiser, so its forward can run on a side stream beside the foreground forward, join for
+        `nerf_composite` (+ losses), and its backward beside the foreground backward.  On MI355X that LOST 9 %: 427 -> 389 it/s
+        at iteration 0, 400 -> 370 with every level open (profiles/r04_train_streams_ab.jsonl) -- the step is balanced between
+        host and device (~2.2 ms of launches against ~2.25 ms of kernels), and the stream switches and event records cost the
+        host more than the overlapped ~0.2 ms of small kernels give back.  (Cross-stream tensors live until this function
+        returns, after both streams have joined: the caching allocator's per-stream pools never hand a block to new work that
+        an unfinished kernel of the other stream still reads.)"""
         if not self._hand_written_step_applies():
             return Trainer._main_phase(self, reel, it, git, eikonal_weight)
         hp, dev = self.hp, self.dev

@@ -11,7 +11,9 @@ def _cases(src, func):
     body = src[src.index("int %s(" % func):]
     body = body[:body.index("return PSDF_ERR_UNSUPPORTED;\n}")]
     out = set()
-    for m in re.finditer(r"^\s*CASE\((\d+), (\d+), (\d+), (\d+), (\d+), (true|false)\)", body, re.M):
+    # CASE_DX_ONLY: shapes whose parameter gradients come from mlp_wide.hip (psdf_mlp_backward routes them there first); the
+    # single-wave kernel serves their data gradient only
+    for m in re.finditer(r"^\s*CASE(?:_DX_ONLY)?\((\d+), (\d+), (\d+), (\d+), (\d+), (true|false)\)", body, re.M):
         out.add(tuple(int(x) for x in m.groups()[:5]) + (m.group(6) == "true",))
     return out
 

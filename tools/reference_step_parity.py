@@ -303,10 +303,21 @@ def main():
             with default_tensor(True):
                 gref, loss_ref, terms, fg_ref = run_reference(mode, it, git, seed)
                 gref2, loss_ref2, _, _ = run_reference(mode, it, git, seed, permute_seed=7)
+                repeats = []                                                         # the same run again, three times
+                for _ in range(3):
+                    g3, l3, _, _ = run_reference(mode, it, git, seed)
+                    repeats.append(dict(compare(g3, gref), loss_rel=abs(l3 - loss_ref) / abs(loss_ref)))
+                    del g3
             case = {"iter_nr_for_anneal": it, "global_iter": git, "nr_rays": int(o.shape[0]), "reference_loss": loss_ref,
                     "reference_terms": terms,
                     # the reference against ITSELF with the hidden units of its SDF MLP re-numbered: its own rounding noise
-                    "reference_self_noise": dict(compare(gref2, gref), loss_rel=abs(loss_ref2 - loss_ref) / abs(loss_ref))}
+                    "reference_self_noise": dict(compare(gref2, gref), loss_rel=abs(loss_ref2 - loss_ref) / abs(loss_ref)),
+                    # ... and REPEATED unchanged (same samples by construction): what float atomics alone do to its gradients
+                    "reference_repeat_noise": {k: max(r[k] for r in repeats)
+                                               for k in ("worst_dense", "worst_lattice", "worst_lattice_l2", "loss_rel")}}
+            case["reference_repeat_noise"]["dense_by_tensor"] = {
+                k: max(r["grads"][k]["max_rel"] for r in repeats if k in r["grads"] and "max_rel" in r["grads"][k])
+                for k in repeats[0]["grads"] if "lattice" not in k and "max_rel" in repeats[0]["grads"][k]}
             del gref2
             with default_tensor(False):
                 for name, tr in (("manual", trm), ("autograd", tra)):
