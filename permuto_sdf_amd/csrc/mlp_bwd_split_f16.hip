@@ -37,7 +37,15 @@ constexpr int RECL = NT * 2 * NP * 64;
 constexpr int OFF_W0 = 0, OFF_W1 = RECL, OFF_W2 = 2 * RECL, OFF_T2 = 3 * RECL, OFF_T1 = 4 * RECL, OFF_T0 = 5 * RECL;
 constexpr int off_f32(int nt0) { return 5 * RECL + nt0 * 2 * NP * 64; }
 constexpr int TAIL_FLOATS = 3 * HID + HID + 1;  // biases of the three hidden layers, final weights, final bias
+#if defined(PSDF_F16_PROTO_OCC)
+// MEASUREMENT BUILD ONLY (round 4, tools/r04_mlp_occupancy_proto.sh; never the shipped library): what would TWO waves per SIMD
+// buy?  The workgroup-cooperative design of DESIGN.md "Next" keeps 1/4 of the dW accumulators per wave (44 registers instead of
+// 176) so that eight waves share one CU.  This build emulates its per-wave resources without its LDS exchange: every dW product
+// of a layer lands in one of FOUR accumulators (wrong sums, same MFMA and VALU instruction mix), eight waves per workgroup.
+constexpr int NWAVES = 8;
+#else
 constexpr int NWAVES = 4;
+#endif
 constexpr size_t img_aligned(int nt0) { return ((size_t)off_f32(nt0) * 16 + TAIL_FLOATS * 4 + 15) / 16 * 16; }
 // gradient image (floats): dW1 [64][64 (K0 used)], dW2 [64][64], dW3 [64][64], db1, db2, db3 [64], dW4 [64], db4
 constexpr int G_W1 = 0, G_W2 = 4096, G_W3 = 8192, G_B1 = 12288, G_B2 = 12352, G_B3 = 12416, G_W4 = 12480, G_B4 = 12544,
@@ -309,9 +317,14 @@ __device__ __forceinline__ void chain(const f32x4 (&in)[NT], f32x4 (&out)[NTILE]
 }
 // backward of one layer: dH chain (hands the pieces of dZ to the transposes), then dW[to][ti] += dZ(to) x H(ti)
 // backward of one layer: dH chain (hands the pieces of dZ to the transposes), then dW[to][ti] += dZ(to) x H(ti)
+#if defined(PSDF_F16_PROTO_OCC)
+#define PSDF_DW_COLS 1
+#else
+#define PSDF_DW_COLS NTI
+#endif
 template <int NTO, int NTI>
 __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO], const u32x4* __restrict__ wT, int lane,
-                                          const f16x8 (&id)[2], const f32x4 (&hT)[NTI], f32x4 (&dW)[NT][NTI], float (&db)[NT],
+                                          const f16x8 (&id)[2], const f32x4 (&hT)[NTI], f32x4 (&dW)[NT][PSDF_DW_COLS], float (&db)[NT],
                                           const f32x4& rT) {
   AT A[NT];
   chain<NTO>(dz, dh, wT, lane, [&](int s, const BP& b) {
@@ -322,8 +335,13 @@ __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO
   for (int ti = 0; ti < NTI; ti++) {
     BT B;
     split4(hT[ti] * rT, B);      // H of sample 4 g + r carries that sample's dY magnitude (see the header)
+#if defined(PSDF_F16_PROTO_OCC)
+#pragma unroll
+    for (int to = 0; to < NT; to++) dW[(to + ti) & 3][0] = dw_mac(dW[(to + ti) & 3][0], A[to], B);
+#else
 #pragma unroll
     for (int to = 0; to < NT; to++) dW[to][ti] = dw_mac(dW[to][ti], A[to], B);
+#endif
   }
 }
 
@@ -372,6 +390,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   const float* tail = reinterpret_cast<const float*>(lds + OFF_F32);
   const int lane_k = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f16x8 id[2] = {ident_op(0, lane_k), ident_op(1, lane_k)};
+#if defined(PSDF_F16_PROTO_OCC)
+  f32x4 dW1[NT][1], dW2[NT][1], dW3[NT][1];
+#pragma unroll
+  for (int to = 0; to < NT; to++) dW1[to][0] = dW2[to][0] = dW3[to][0] = zero4();
+#else
   f32x4 dW1[NT][NT0], dW2[NT][NT], dW3[NT][NT];
 #pragma unroll
   for (int to = 0; to < NT; to++) {
@@ -380,6 +403,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 #pragma unroll
     for (int ti = 0; ti < NT0; ti++) dW1[to][ti] = zero4();
   }
+#endif
   float db1[NT] = {0.f, 0.f, 0.f, 0.f}, db2[NT] = {0.f, 0.f, 0.f, 0.f}, db3[NT] = {0.f, 0.f, 0.f, 0.f},
         dw4[NT] = {0.f, 0.f, 0.f, 0.f}, db4 = 0.f;
   const int64_t ntiles = (N + 15) / 16;
@@ -567,6 +591,11 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = (16 * to + 4 * g + r) * 64;  // [out][in]
+#if defined(PSDF_F16_PROTO_OCC)
+          G[G_W2 + row + c] += dW2[to][0][r];
+          G[G_W3 + row + c] += dW3[to][0][r];
+          G[G_W1 + row + c] += dW1[to][0][r];
+#else
 #pragma unroll
           for (int ti = 0; ti < NT; ti++) {
             G[G_W2 + row + 16 * ti + c] += dW2[to][ti][r];
@@ -574,6 +603,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
           }
 #pragma unroll
           for (int ti = 0; ti < NT0; ti++) G[G_W1 + row + 16 * ti + c] += dW1[to][ti][r];
+#endif
         }
 #pragma unroll
       for (int t = 0; t < NT; t++) {  // lane (f = c, g) holds the partial of its four samples: add the four groups
