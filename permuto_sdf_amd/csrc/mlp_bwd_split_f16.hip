@@ -360,6 +360,16 @@ __device__ __forceinline__ int dy_scale(uint32_t bits, float& sc, float& isc) {
 // give (0, 0): the sample contributes nothing.  Inf / NaN pass through as they are (and poison what they touch, as in any
 // fp32 evaluation).  (Values below 2^-122 lose their factor to the exponent clamp: treated as zero.)
 constexpr int CHAIN_EXP = 4;
+// The H-side operand of the parameter-gradient products is H[n] * 2^(e(n) - e_max) split into two fp16 pieces, and fp16 ends at
+// 2^-24: with activations of 1e-2 (the encoding features that feed layer 1 are that small) the LOW piece of even the largest-dY
+// sample is already subnormal, and samples a few decades below the largest dY lose their contribution's precision altogether --
+// measured with all 2 097 152 samples carrying gradient, dY spread over six decades plus one outlier: dW errors of 1.2e-3 ..
+// 1.7e-3 of the largest entry (tests/test_gpu_hotpath_parity.py::test_cfg2_full_batch_dense_gradient_against_float64; reproduced
+// by a numpy emulation of this arithmetic).  fp16 has as much room ABOVE as it lacks below: the operand is pre-scaled by 2^8
+// (exact) and the factor is taken out again by the summing launch.  Cost: none.  Limit: |activation| * 2^8 must stay below
+// 65504, i.e. inputs and hidden activations up to 255 (beyond: the piece saturates at the largest fp16 number -- a silently
+// clipped contribution, not an inf; such nets belong to PSDF_MLP_BWD_SPLIT=bf16 like those whose forward exceeds 65504).
+constexpr int H_PRESCALE_EXP = 8;
 __device__ __forceinline__ void dy_parts(float dy, float& mant, float& pow2) {
   const uint32_t b = __float_as_uint(dy);
   const int ex = (int)(b >> 23) & 255;
@@ -505,7 +515,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       for (int r = 0; r < 4; r++) {
         const bool in = n0 + 4 * g + r < N;
         const int ex = (int)(__float_as_uint(dyT[r]) >> 23) & 255;
-        int er = ex + kscale - CHAIN_EXP;                   // dZ of the chain = true dZ * 2^(CHAIN_EXP - e(n))
+        int er = ex + kscale - CHAIN_EXP + H_PRESCALE_EXP;  // dZ of the chain = true dZ * 2^(CHAIN_EXP - e(n)); + the H pre-scale
         er = er < 1 ? 0 : (er > 254 ? 254 : er);            // below 2^-126 after scaling: the contribution is dropped
         rT[r] = (in && ex > CHAIN_EXP && ex != 255) ? __uint_as_float((uint32_t)er << 23) : ((in && ex == 255) ? 1.f : 0.f);
         dyT[r] = in ? dyT[r] * sc : 0.f;
@@ -642,6 +652,7 @@ __global__ void mlp_split_reduce_kernel(const float* __restrict__ partial, const
   float sc, isc;
   dy_scale(absmax[0], sc, isc);
   s *= isc;                        // the images are gradients of dY * 2^k: exact power-of-two scaling
+  if (e < G_W4) s *= __uint_as_float((uint32_t)(127 - H_PRESCALE_EXP) << 23);   // dW1..3, db1..3 carry the H pre-scale; dW4, db4 do not
   if (e < G_W2) {
     const int o = e >> 6, k = e & 63;
     if (k < K0) atomicAdd(&dW0[o * K0 + k], s);
