@@ -663,7 +663,10 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 // curvature term amplifies) no longer depends on the order in which atomics land.  Measured (profiles/r04_enc_ab.jsonl, 2 M
 // points, 16 levels): 0.634 ms against 0.644 ms with atomics -- the 30 M atomics were NOT what makes this kernel 1.8x the
 // forward (0.358 ms); 49 152 points x 24 levels: 30.8 against 28.8 us (one more launch).
-constexpr int POS_LPB = 4;
+#if !defined(PSDF_ENC_POS_LPB)
+#define PSDF_ENC_POS_LPB 4     // levels per thread (A/B builds: 2, 8)
+#endif
+constexpr int POS_LPB = PSDF_ENC_POS_LPB;
 template <int P, int F, bool PARTIAL = false>
 __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
@@ -1150,6 +1153,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   static const int wg_cap_env = getenv("PSDF_ENC_BWD_WG_PER_LEVEL") ? atoi(getenv("PSDF_ENC_BWD_WG_PER_LEVEL")) : 0;
   const unsigned wg_cap = wg_cap_env > 0 ? (unsigned)wg_cap_env : 512u;
   dim3 grid(nb < wg_cap ? nb : wg_cap, Lt);
+  static const bool pos_fused = getenv("PSDF_ENC_POS_FUSED") && atoi(getenv("PSDF_ENC_POS_FUSED")) != 0;   // A/B: the round-3 form
   Queues Q{};
   int64_t need = 0;
   const bool use_queue = grad_lattice && workspace && queue_plan(pos_dim, nr_feat, N, nr_levels, capacity, Q, need) &&
@@ -1181,7 +1185,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
       int per_cu = 0;                                                                                            \
       const size_t shm = ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                  \
       const hipError_t eo =                                                                                      \
-          grad_positions ? hipOccupancyMaxActiveBlocksPerMultiprocessor(                                        \
+          (grad_positions && pos_fused) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(                                        \
                                &per_cu, encode_bwd_kernel<P_, F_, true, true, true>, PSDF_BLOCK, shm)            \
                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(                                        \
                                &per_cu, encode_bwd_kernel<P_, F_, true, false, true>, PSDF_BLOCK, shm);          \
@@ -1194,7 +1198,16 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
         (void)hipGetLastError();                                                                                 \
       }                                                                                                          \
     }                                                                                                            \
-    if (use_queue && grad_positions)                                                                             \
+    if (use_queue && grad_positions && !pos_fused) {                                                             \
+      /* large batch, both gradients: the binning kernel for the lattice (its own levels only) and the level-group */ \
+      /* kernel for the positions -- the fused form adds the position gradient with float atomics from inside the */ \
+      /* binning kernel: +0.98 ms at 2 M points x 16 levels against 0.63 ms for the separate kernel (round 4) */   \
+      grid.y = nr_levels;                                                                                        \
+      BWD(P_, F_, true, false, true);                                                                            \
+      launch_bwd_pos<P_, F_>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window,        \
+                             points_scaling, pad_points(concat_points), grad_sliced, (const unsigned char*)nullptr, \
+                             grad_positions, st);                                                                 \
+    } else if (use_queue && grad_positions)                                                                      \
       BWD(P_, F_, true, true, true);                                                                             \
     else if (use_queue)                                                                                          \
       BWD(P_, F_, true, false, true);                                                                            \

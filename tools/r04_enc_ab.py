@@ -31,8 +31,11 @@ def timeit(fn, n=20):
 def main():
     dev = torch.device("cuda:0")
     rs, _, _ = bench.make_batch(dev, 7)
-    out = {"env": {k: os.environ.get(k) for k in ("PSDF_ENC_FWD_XCD", "PSDF_ENC_POS_ATOMICS", "PSDF_LIB_PATH") if os.environ.get(k)}}
+    out = {"env": {k: os.environ.get(k) for k in ("PSDF_ENC_POS_FUSED", "PSDF_ENC_POS_ATOMICS", "PSDF_LIB_PATH", "PSDF_AB_ONLY") if os.environ.get(k)}}
+    only = os.environ.get("PSDF_AB_ONLY")      # one configuration (counter runs: a mean over launches of ONE size)
     for L_, pts, tag in ((16, rs.samples_pos, "2M_L16"), (24, rs.samples_pos, "2M_L24"), (24, rs.samples_pos[:49152].contiguous(), "49k_L24")):
+        if only and tag != only:
+            continue
         torch.manual_seed(0)
         enc = PermutoEncoding(3, 2 ** 18, L_, 2, np.geomspace(1.0, 1e-4, L_), concat_points=True, concat_points_scaling=1e-3,
                               init_scale=1e-2).to(dev)
@@ -44,7 +47,8 @@ def main():
         g_lat = torch.zeros_like(enc.lattice_values)
         out[tag] = {"fwd_ms": timeit(lambda: encode_forward_raw(*a)),
                     "bwd_pos_ms": timeit(lambda: encode_backward_raw(*a, g, None, g_pos)),
-                    "bwd_lattice_ms": timeit(lambda: encode_backward_raw(*a, g, g_lat, None))}
+                    "bwd_lattice_ms": timeit(lambda: encode_backward_raw(*a, g, g_lat, None)),
+                    "bwd_lattice_and_pos_ms": timeit(lambda: encode_backward_raw(*a, g, g_lat, g_pos))}
     print(json.dumps(out))
 
 

@@ -23,8 +23,8 @@ if [ -z "$SHORT" ]; then
 bash tools/pmc_hbm_traffic.sh r04 > $O/pmc_hbm.log 2>&1
 bash tools/pmc_sq.sh mlp_bwd_split_f16_kernel mlpbwdf16 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_sq_mlp_bwd_f16.log 2>&1
 bash tools/pmc_sq.sh "encode_bwd_kernel" encbwd -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_sq_encode_bwd.log 2>&1
-bash tools/pmc_sq.sh "encode_bwd_pos_kernel" encbwdpos -- python $R/tools/r04_enc_ab.py > $O/pmc_sq_encode_bwd_pos.log 2>&1
-PMC_SETS="TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" bash tools/pmc_sq.sh "encode_bwd_pos_kernel" encbwdpos_mem -- python $R/tools/r04_enc_ab.py > $O/pmc_mem_encode_bwd_pos.log 2>&1
+PSDF_AB_ONLY=2M_L16 bash tools/pmc_sq.sh "encode_bwd_pos_kernel" encbwdpos -- python $R/tools/r04_enc_ab.py > $O/pmc_sq_encode_bwd_pos.log 2>&1
+PSDF_AB_ONLY=2M_L16 PMC_SETS="TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum;TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" bash tools/pmc_sq.sh "encode_bwd_pos_kernel" encbwdpos_mem -- python $R/tools/r04_enc_ab.py > $O/pmc_mem_encode_bwd_pos.log 2>&1
 python tools/cfg2_matrix.py > $O/cfg2_matrix.jsonl 2> $O/cfg2_matrix.err
 rm -rf $R/gpurun_out/pmc_hbm_r04/FETCH_SIZE $R/gpurun_out/pmc_hbm_r04/WRITE_SIZE $R/gpurun_out/pmc_sq_mlpbwdf16/pass* $R/gpurun_out/pmc_sq_encbwd/pass* $R/gpurun_out/pmc_sq_encbwdpos/pass* $R/gpurun_out/pmc_sq_encbwdpos_mem/pass*
 cat $R/gpurun_out/pmc_sq_encbwdpos/summary.txt $R/gpurun_out/pmc_sq_encbwdpos_mem/summary.txt
