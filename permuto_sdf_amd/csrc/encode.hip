@@ -663,11 +663,12 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 // curvature term amplifies) no longer depends on the order in which atomics land.  Measured (profiles/r04_enc_ab.jsonl, 2 M
 // points, 16 levels): 0.634 ms against 0.644 ms with atomics -- the 30 M atomics were NOT what makes this kernel 1.8x the
 // forward (0.358 ms); 49 152 points x 24 levels: 30.8 against 28.8 us (one more launch).
-#if !defined(PSDF_ENC_POS_LPB)
-#define PSDF_ENC_POS_LPB 4     // levels per thread (A/B builds: 2, 8)
-#endif
-constexpr int POS_LPB = PSDF_ENC_POS_LPB;
-template <int P, int F, bool PARTIAL = false>
+// LPB = levels per thread: 2 for large batches, 8 for small ones (round 4, profiles/r04_enc_ab_pos_lpb.jsonl).  At 2 M points the
+// kernel waits for gathers (70 % of its wave cycles) and the tables of 4 levels (8 MiB) do not fit an XCD's 4-MiB L2 (hit rate
+// 48 %, profiles/r04_pmc_encode_bwd_pos.txt): 16 levels 0.623 ms with 4 levels per thread, **0.503 ms with 2** (two tables = one
+// L2), 0.524 with 1 (nine more slabs to write and read), 0.749 with 8.  At a training step's 49 152 points x 24 levels nothing
+// thrashes and fewer, longer threads win: 28.8 us with 8, 31.0 with 4, 32.9 with 2.
+template <int P, int F, bool PARTIAL, int POS_LPB>
 __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_bwd_pos_kernel(int64_t N, int L, int Lt, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                           const float* __restrict__ lattice, const float* __restrict__ scale_factor,
@@ -973,25 +974,40 @@ EncConv& enc_conv_state() {
 // ================================================================================== C ABI
 // Position gradient only: the level-group kernel + the slab reduction when stream-ordered scratch is available (not while a
 // graph is being captured: there the float-atomic form runs), PSDF_ENC_POS_ATOMICS=1 forces the atomic form (A/B).
-template <int P_, int F_>
-static void launch_bwd_pos(int64_t N, int nr_levels, int Lt, int capacity, const float* positions, const float* lattice,
-                           const float* scale_factor, const float* shifts, const float* window, float points_scaling, int pad,
-                           const float* grad_sliced, const unsigned char* skip, float* grad_positions, hipStream_t st) {
+template <int P_, int F_, int POS_LPB>
+static void launch_bwd_pos_lpb(int64_t N, int nr_levels, int Lt, int capacity, const float* positions, const float* lattice,
+                               const float* scale_factor, const float* shifts, const float* window, float points_scaling, int pad,
+                               const float* grad_sliced, const unsigned char* skip, float* grad_positions, hipStream_t st) {
   static const bool force_atomics = getenv("PSDF_ENC_POS_ATOMICS") && atoi(getenv("PSDF_ENC_POS_ATOMICS")) != 0;
   const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
   const int groups = (Lt + POS_LPB - 1) / POS_LPB;
   float* slabs = (groups > 1 && !force_atomics) ? (float*)psdf::stream_scratch((size_t)groups * N * P_ * sizeof(float), st) : nullptr;
   if (slabs) {
-    hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_, true>), dim3(nb, groups), dim3(PSDF_BLOCK), 0, st, N, nr_levels, Lt,
+    hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_, true, POS_LPB>), dim3(nb, groups), dim3(PSDF_BLOCK), 0, st, N, nr_levels, Lt,
                        (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,
                        points_scaling, pad, grad_sliced, skip, slabs);
     hipLaunchKernelGGL(encode_bwd_pos_reduce_kernel, dim3(psdf_blocks(N * P_, PSDF_BLOCK)), dim3(PSDF_BLOCK), 0, st, N * P_, P_,
                        groups, slabs, skip, grad_positions);
   } else {
-    hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_, false>), dim3(nb, groups), dim3(PSDF_BLOCK), 0, st, N, nr_levels, Lt,
+    hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_, false, POS_LPB>), dim3(nb, groups), dim3(PSDF_BLOCK), 0, st, N, nr_levels, Lt,
                        (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,
                        points_scaling, pad, grad_sliced, skip, grad_positions);
   }
+}
+
+template <int P_, int F_>
+static void launch_bwd_pos(int64_t N, int nr_levels, int Lt, int capacity, const float* positions, const float* lattice,
+                           const float* scale_factor, const float* shifts, const float* window, float points_scaling, int pad,
+                           const float* grad_sliced, const unsigned char* skip, float* grad_positions, hipStream_t st) {
+  if (psdf::stream_scratch(16, st) == nullptr)     // stream capture (the sphere tracer's graph): float atomics, as measured in round 2
+    launch_bwd_pos_lpb<P_, F_, 4>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window, points_scaling,
+                                  pad, grad_sliced, skip, grad_positions, st);
+  else if (N >= ((int64_t)1 << 17))
+    launch_bwd_pos_lpb<P_, F_, 2>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window, points_scaling,
+                                  pad, grad_sliced, skip, grad_positions, st);
+  else
+    launch_bwd_pos_lpb<P_, F_, 8>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window, points_scaling,
+                                  pad, grad_sliced, skip, grad_positions, st);
 }
 
 extern "C" {
