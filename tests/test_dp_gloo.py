@@ -116,7 +116,7 @@ def _sharded_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_optimizer_protocol_equals_the_full_batch_update(world):
     """parallel.ShardedUpdate: in-place reduce-scatter of the lattice gradient, the owner updates its 1/world of the table,
     all-gather of the PARAMETERS -- every rank ends with the single-process update of the whole batch, bit-identical replicas"""
@@ -126,7 +126,7 @@ def test_sharded_optimizer_protocol_equals_the_full_batch_update(world):
     po, lat, sh, pts, w1, sl, win = _problem()
     g_lat, _ = _grads(po, lat, sh, pts, w1, sl, win)
     want = (lat - 0.1 * g_lat).numpy()
-    assert all(ret["sharded_%d" % r] == (world == 2) for r in range(world))
+    assert all(ret["sharded_%d" % r] == (world in (2, 4)) for r in range(world))      # 8 192 elements do not cut into 3 x 4k
     for r in range(world):
         assert np.abs(ret["param_%d" % r] - want).max() <= 1e-5 * np.abs(want).max()
         assert np.array_equal(ret["param_%d" % r], ret["param_0"])          # replicas: the same bytes
