@@ -323,6 +323,16 @@ def shard_bounds(n, unit=1, world=None, rank_=None):
     return r * per, (r + 1) * per
 
 
+_warned = set()
+
+
+def _warn_once(msg):
+    if msg not in _warned:
+        _warned.add(msg)
+        import warnings
+        warnings.warn(msg)
+
+
 def sharded_optimizer_default():
     """PSDF_DP_OPTIMIZER = sharded (default) | replicated"""
     return os.environ.get("PSDF_DP_OPTIMIZER", "sharded") == "sharded"
@@ -375,7 +385,13 @@ class ShardedUpdate:
         w, r = world_size(), dist.get_rank()
         n = hi - lo
         if dist.get_backend() == "nccl":
-            self.works.append(dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, async_op=True))
+            try:
+                self.works.append(dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, async_op=True))
+            except Exception as e:      # a backend build that rejects the aliased (in-place) form: same result through a shard
+                _warn_once("ShardedUpdate: in-place reduce_scatter_tensor failed (%r); staging through a shard buffer" % (e,))
+                shard = torch.empty(n, dtype=flat.dtype, device=flat.device)
+                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
+                flat[lo:hi].copy_(shard)
             return own
         h = flat.detach().cpu() if flat.is_cuda else flat
         for o in range(w):
@@ -390,7 +406,11 @@ class ShardedUpdate:
             return
         lo, hi = own
         if dist.get_backend() == "nccl":
-            self.works.append(dist.all_gather_into_tensor(flat, flat[lo:hi], async_op=True))
+            try:
+                self.works.append(dist.all_gather_into_tensor(flat, flat[lo:hi], async_op=True))
+            except Exception as e:
+                _warn_once("ShardedUpdate: in-place all_gather_into_tensor failed (%r); gathering from a copy of the shard" % (e,))
+                dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
             return
         h = flat.detach().cpu() if flat.is_cuda else flat
         parts = [torch.empty(hi - lo, dtype=h.dtype) for _ in range(world_size())]
