@@ -242,7 +242,9 @@ int psdf_encode_backward_positions_masked(int pos_dim, int nr_feat, int64_t N, i
 /* ---- mlp_bwd.hip ---- */
 /* replaces: autograd backward of the same evaluators (dX, dW_l, db_l in one launch; forward recomputed from X).
    weights[l]/biases[l]: torch-layout parameters; dW[l]/db[l] are accumulated into (caller zero-fills); dW = db = NULL:
-   data gradient only (lighter kernel: analytic normals at inference) */
+   data gradient only (lighter kernel: analytic normals at inference).  dY = NULL (data gradient only; also accepted by
+   psdf_mlp_backward_data_masked and psdf_mlp_double_backward): the unit gradient of output 0, i.e. d y_0 / d X -- the
+   `torch.autograd.grad(sdf, points, torch.ones_like(sdf))` of models.py:236-251 without a [rows, N] tensor that is 1 in one row */
 int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights, const
     float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 

@@ -151,6 +151,12 @@ __device__ __forceinline__ void unpack_index(const Plan16& p, int e, int& l, int
   }
 }
 
+// upstream gradient of output `row` at sample n; dY == NULL means "the unit gradient of output 0" (d y_0 / d . : what the SDF
+// normal needs, models.py:236-251) -- callers then neither allocate nor fill a [rows, N] tensor that is 1 in one row (round 4)
+__device__ __forceinline__ float ld_dy(const float* __restrict__ dY, int row, int64_t N, int64_t n) {
+  return dY ? dY[(int64_t)row * N + n] : (row == 0 ? 1.f : 0.f);
+}
+
 struct BwdPtrs {
   const float* W[MAXL];
   const float* b[MAXL];
@@ -183,18 +189,23 @@ __device__ __forceinline__ void flush_image(const Plan16& p, const BwdPtrs& a, c
   }
 }
 
-// 64 image entries per workgroup; wave w sums the workgroup images w, w+4, ... (coalesced), LDS combines the four.
-__global__ void __launch_bounds__(256) mlp_grad_reduce_kernel(Plan16 p, BwdPtrs a, int nimages) {
-  __shared__ float part[4][64];
+// 64 image entries per workgroup; wave w sums the workgroup images w, w + 16, ... (coalesced), LDS combines the sixteen.
+// (Four waves walking 64 images each took 16 us per call, five calls per training step: the loop is a chain of dependent
+// loads on 77 workgroups; sixteen waves shorten it four-fold -- round 4.)
+constexpr int GRW = 16;
+__global__ void __launch_bounds__(GRW * 64) mlp_grad_reduce_kernel(Plan16 p, BwdPtrs a, int nimages) {
+  __shared__ float part[GRW][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
   float s = 0.f;
   if (e < p.total)
-    for (int b = wave; b < nimages; b += 4) s += a.partial[(size_t)b * p.total + e];
+    for (int b = wave; b < nimages; b += GRW) s += a.partial[(size_t)b * p.total + e];
   part[wave][lane] = s;
   __syncthreads();
   if (wave != 0 || e >= p.total) return;
-  const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  float v = 0.f;
+#pragma unroll
+  for (int w = 0; w < GRW; w += 4) v += (part[w][lane] + part[w + 1][lane]) + (part[w + 2][lane] + part[w + 3][lane]);
   if (v == 0.f) return;
   int l, row, col;
   bool is_bias;
@@ -216,7 +227,7 @@ static float* grad_scratch_alloc(size_t floats, hipStream_t st) {
 
 static void grad_scratch_reduce(const Plan16& p, const BwdPtrs& a, int nimages, hipStream_t st) {
   if (!a.partial) return;
-  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((unsigned)((p.total + 63) / 64)), dim3(256), 0, st, p, a, nimages);
+  hipLaunchKernelGGL(mlp_grad_reduce_kernel, dim3((unsigned)((p.total + 63) / 64)), dim3(GRW * 64), 0, st, p, a, nimages);
 }
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -601,7 +612,7 @@ __global__ void __launch_bounds__(NW * 64)
 #pragma unroll
         for (int o = 0; o < 4; o++) {
           if (o < OUT) {
-            const float dy = live ? dY[(int64_t)o * N + n] : 0.f;
+            const float dy = live ? ld_dy(dY, o, N, n) : 0.f;
 #pragma unroll
             for (int t = 0; t < TL; t++)
 #pragma unroll
@@ -628,7 +639,7 @@ __global__ void __launch_bounds__(NW * 64)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int row = 16 * to + 4 * g + r;
-            dyT[to][r] = (row < OUT && live) ? dY[(int64_t)row * N + n] : 0.f;
+            dyT[to][r] = (row < OUT && live) ? ld_dy(dY, row, N, n) : 0.f;
           }
         chain_bwd4<OTS, TL>(dyT, dhl, W + IM::BO, lane);
         if constexpr (NEED_DW) {
@@ -956,7 +967,7 @@ __global__ void __launch_bounds__(BW * 64)
 #pragma unroll
       for (int o = 0; o < 4; o++) {
         if (o < OUT) {
-          dyo[o] = live ? dY[(int64_t)o * N + n] : 0.f;
+          dyo[o] = live ? ld_dy(dY, o, N, n) : 0.f;
 #pragma unroll
           for (int t = 0; t < T3; t++)
 #pragma unroll
@@ -969,7 +980,7 @@ __global__ void __launch_bounds__(BW * 64)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = 16 * to + 4 * g + r;
-          dyT[to][r] = (row < OUT && live) ? dY[(int64_t)row * N + n] : 0.f;
+          dyT[to][r] = (row < OUT && live) ? ld_dy(dY, row, N, n) : 0.f;
         }
       chain_bwd4<OTS, T3>(dyT, q3, W + IM::BO, lane);
     }
@@ -1223,7 +1234,8 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   int rc = make_plan16(n_layers, dims, p);
   if (rc != PSDF_OK) return rc;
   if (N == 0) return PSDF_OK;
-  if (N < 0 || !X || !weights || !biases || !dY || ((dW == nullptr) != (db == nullptr))) return PSDF_ERR_ARG;
+  if (N < 0 || !X || !weights || !biases || ((dW == nullptr) != (db == nullptr))) return PSDF_ERR_ARG;
+  if (!dY && dW) return PSDF_ERR_ARG;      // dY == NULL (unit gradient of output 0) is a data-gradient-only request
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
   // Large batches of the BASELINE net (<= 64 inputs, 64x3, 1 output) with parameter gradients: the split-operand kernels on
   // the 16-bit matrix pipes -- by default two fp16 pieces per operand (mlp_bwd_split_f16.hip: errors of a few 1e-6 of the largest
@@ -1320,7 +1332,7 @@ int psdf_mlp_backward_data_masked(int n_layers, const int* dims, int64_t N, cons
   int rc = make_plan16(n_layers, dims, p);
   if (rc != PSDF_OK) return rc;
   if (N == 0) return PSDF_OK;
-  if (N < 0 || !X || !weights || !biases || !dY || !dX) return PSDF_ERR_ARG;
+  if (N < 0 || !X || !weights || !biases || !dX) return PSDF_ERR_ARG;      // dY == NULL: unit gradient of output 0
   if (n_layers != 3 && n_layers != 4) return PSDF_ERR_UNSUPPORTED;
   BwdPtrs a;
   a.partial = nullptr;
@@ -1359,7 +1371,7 @@ int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const flo
   if (rc != PSDF_OK) return rc;
   if (n_layers != 4) return PSDF_ERR_UNSUPPORTED;
   if (N == 0) return PSDF_OK;
-  if (N < 0 || !X || !weights || !biases || !dY || !V || !dX2 || !dW || !db) return PSDF_ERR_ARG;
+  if (N < 0 || !X || !weights || !biases || !V || !dX2 || !dW || !db) return PSDF_ERR_ARG;   // dY == NULL: unit gradient of output 0
   BwdPtrs a;
   a.partial = nullptr;
   for (int l = 0; l < MAXL; l++) {

@@ -360,22 +360,26 @@ class Coarse2Fine(torch.nn.Module):
         self.last_t = 0.0
         self.register_buffer("level_idx", torch.arange(nr_levels, dtype=torch.float32), persistent=False)
 
-    def forward(self, t):
+    def _update(self, t):
+        """the window of `t` into the cache (no copy handed out)"""
         self.last_t = float(t)
-        # a training step asks for the window of the same t half a dozen times: five elementwise launches once, not each time
+        # a training step asks for the window of the same t half a dozen times: computed once per t, and on the HOST (five
+        # elementwise launches on 24 floats cost more on the GPU than the whole evaluation does here; one 96-byte upload)
         key = (self.last_t, self.level_idx.device)
         if getattr(self, "_cached_key", None) != key:
-            alpha = float(t) * self.nr_levels
-            x = torch.clamp(alpha - self.level_idx, 0.0, 1.0)
-            self._cached = 0.5 * (1.0 + torch.cos(math.pi * x + math.pi))
+            alpha = torch.tensor(float(t) * self.nr_levels, dtype=torch.float32, device="cpu")   # (explicit: the reference sets
+            x = torch.clamp(alpha - torch.arange(self.nr_levels, dtype=torch.float32, device="cpu"), 0.0, 1.0)   # a CUDA default type)
+            self._cached = (0.5 * (1.0 + torch.cos(math.pi * x + math.pi))).to(self.level_idx.device)
             self._cached_key = key
-        # a copy (one launch instead of five): callers own what they get -- unmodified reference Python may write into it
-        return self._cached.clone()
+        return self._cached
+
+    def forward(self, t):
+        # a copy (one launch): callers own what they get -- unmodified reference Python may write into it
+        return self._update(t).clone()
 
     def window_readonly(self, t):
         """the cached window itself, no copy: for callers that promise not to modify it (train_step.SdfNet)"""
-        self.forward(t)
-        return self._cached
+        return self._update(t)
 
     def get_last_t(self):
         return self.last_t

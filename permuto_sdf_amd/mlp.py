@@ -110,7 +110,9 @@ class GradBuffer:
 def mlp_backward_raw(dims, x_fm, weights, biases, gy_fm, need_dx=True, need_dw=True, into=None):
     """weights/biases: the torch-layout parameters (the backward kernel builds its own LDS image from them)
     -> (dx_fm [dims[0], N] or None, [dW_l], [db_l]); need_dw=False: data gradient only (lighter kernel, empty lists);
-    into = (dWs, dbs): accumulate into these instead of fresh zero-filled tensors"""
+    into = (dWs, dbs): accumulate into these instead of fresh zero-filled tensors; gy_fm = None (with need_dw=False): the unit
+    gradient of output 0, d y_0 / d x"""
+    assert gy_fm is not None or not need_dw
     N = x_fm.shape[1]
     n_layers = len(dims) - 1
     dev = x_fm.device
@@ -364,7 +366,10 @@ def double_backward_supported(dims):
 
 def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None, module=None):
     """-> (dX [C,N], [dW_l], [db_l]) of <dx(x, params; gy), v>; fused kernel where one is built, torch (GPU) otherwise;
-    into = (dWs, dbs): accumulate the parameter gradients there"""
+    into = (dWs, dbs): accumulate the parameter gradients there; gy_fm = None: the unit gradient of output 0"""
+    if gy_fm is None and not double_backward_supported(dims):      # the torch route needs the tensor: unit gradient of output 0
+        gy_fm = torch.zeros((dims[-1], x_fm.shape[1]), dtype=torch.float32, device=x_fm.device)
+        gy_fm[0].fill_(1.0)
     if not double_backward_supported(dims):
         dX, dWs, dbs = _torch_gpu_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, module)
         if into is not None:

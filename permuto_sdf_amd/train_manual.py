@@ -80,6 +80,7 @@ class ManualTrainer(Trainer):
         # second stream for the background branch: OFF by default -- measured slower (see _main_phase); PSDF_TRAIN_STREAMS=1 turns it on
         self.overlap_streams = os.environ.get("PSDF_TRAIN_STREAMS", "0") == "1"
         self._side = None
+        self._g_yo = None
         self._events = [torch.cuda.Event() for _ in range(4)] if self.dev.type == "cuda" else []
 
     def _side_stream(self):
@@ -96,17 +97,11 @@ class ManualTrainer(Trainer):
         return (not self.with_mask and hp.nr_samples_bg <= 256
                 and hp.max_nr_samples_per_ray + 2 * hp.nr_samples_imp_sampling <= 256)
 
-    def _unit_row(self, rows, N):
-        """[rows, N] feature-major upstream gradient that selects output 0 (d sdf / d .)"""
-        t = torch.zeros((rows, N), dtype=torch.float32, device=self.dev)
-        t[0].fill_(1.0)
-        return t
-
     # ------------------------------------------------------------------ the SDF network, one evaluation
     def _sdf_gradient(self, feat, pts, win, ws, bs):
         """n = d sdf / d p and the feature gradient it came through"""
         dims = self.sdf.mlp_sdf.dims
-        e0 = self._unit_row(dims[-1], pts.shape[0])
+        e0 = None       # "the unit gradient of output 0": the kernels take NULL for it (no [33, N] tensor that is 1 in one row)
         dfeat, _, _ = mlp_backward_raw(dims, feat, ws, bs, e0, need_dx=True, need_dw=False)
         n = _enc_bwd(self.sdf.encoding, pts, win, dfeat, want_pos=True, want_lattice=False)
         return n, dfeat, e0
@@ -215,8 +210,9 @@ class ManualTrainer(Trainer):
             dims_s = sdfn.mlp_sdf.dims
             win = sdfn.window(it).contiguous()
             packed_s = pack_params(dims_s, ws, bs)
-            # exp(10 v) clipped, as RgbNet.neus_render computes it -- but rounded like torch's float32 exp on the device
-            inv_s = torch.exp(torch.tensor(float(forced_variance) * 10.0, device=dev)).clip(1e-6, 1e6).view(1)
+            # exp(10 v) clipped, as RgbNet.neus_render computes it: evaluated in float32 on the host and uploaded (one 4-byte copy
+            # instead of a copy + exp + clamp on the device; the schedule is a host scalar anyway)
+            inv_s = torch.exp(torch.tensor(float(forced_variance) * 10.0, dtype=torch.float32, device="cpu")).clip(1e-6, 1e6).view(1).to(dev)
             rgbn.last_inv_s = inv_s.view(())
             loss = L.zeroed_scalar(dev)     # ONE accumulator: every loss kernel of the step adds its (already weighted) term to it
             calib = None
@@ -288,7 +284,11 @@ class ManualTrainer(Trainer):
             off = self.sphere.rand_points_inside(1024)
             feat_o = _enc_fwd(sdfn.encoding, off, win)
             y_o = mlp_forward_raw(dims_s, feat_o, packed_s)
-            g_so = torch.empty(1024, dtype=torch.float32, device=dev)
+            # the off-surface term's gradient w.r.t. the net's 33 outputs is zero except in row 0 (the SDF): a persistent
+            # [33, 1024] buffer whose rows 1.. stay zero, row 0 rewritten by the loss kernel every step (no fill, no copy)
+            if self._g_yo is None:
+                self._g_yo = torch.zeros((dims_s[-1], 1024), dtype=torch.float32, device=dev)
+            g_so = self._g_yo[0]
             L.call("psdf_offsurface_loss", L.c_l(1024), L.ptr(y_o[0]), L.c_f(1e2), L.c_f(hp.offsurface_weight / 1024.0),
                    L.ptr(loss), L.ptr(g_so), L.stream())
             self._refresh_and_adapt(it, git, n_fg)
@@ -324,9 +324,7 @@ class ManualTrainer(Trainer):
                 dX1, _, _ = mlp_backward_raw(dims_s, feat, ws, bs, g_y, need_dx=True, into=(gb.dWs, gb.dbs))
                 self._sdf_gradient_backward(g_n, feat, dfeat, e0, pts, win, ws, bs, gb, extra_dfeat=dX1)
             # ---- off-surface points
-            g_yo = torch.zeros_like(y_o)
-            g_yo[0] = g_so
-            dXo, _, _ = mlp_backward_raw(dims_s, feat_o, ws, bs, g_yo, need_dx=True, into=(gb.dWs, gb.dbs))
+            dXo, _, _ = mlp_backward_raw(dims_s, feat_o, ws, bs, self._g_yo, need_dx=True, into=(gb.dWs, gb.dbs))
             _enc_bwd(sdfn.encoding, off, win, dXo)
             join(self._events[3])
             if cc is not None:
