@@ -511,3 +511,28 @@ def test_split_f16_forward_against_float64(dev, K0, N):
         d2 = [K0, 32, 32, 32, 33]
         l2 = [torch.nn.Linear(d2[i], d2[i + 1]).to(dev) for i in range(4)]
         pack_params(d2, [l.weight for l in l2], [l.bias for l in l2], f16=True)
+
+
+@pytest.mark.parametrize("dims", [[52, 32, 32, 32, 33], [36, 64, 64, 64, 1]])
+def test_null_upstream_gradient_is_the_unit_gradient_of_output_zero(dev, dims):
+    """dY = NULL (round 4): `d y_0 / d x` and its double backward without a [rows, N] tensor that is 1 in row 0 -- bit-identical to
+    passing that tensor (data gradient, double backward: dX2 and every parameter gradient)"""
+    from permuto_sdf_amd.mlp import FusedMLP, mlp_backward_raw, mlp_double_backward
+    torch.manual_seed(3)
+    net = FusedMLP(dims).to(dev)
+    N = 5003
+    x = torch.randn(dims[0], N, device=dev)
+    ws, bs = [l.weight for l in net.layers], [l.bias for l in net.layers]
+    e0 = torch.zeros(dims[-1], N, device=dev)
+    e0[0] = 1.0
+    a, _, _ = mlp_backward_raw(dims, x, ws, bs, e0, need_dx=True, need_dw=False)
+    b, _, _ = mlp_backward_raw(dims, x, ws, bs, None, need_dx=True, need_dw=False)
+    assert torch.equal(a, b)
+    v = torch.randn(dims[0], N, device=dev)
+    d1 = mlp_double_backward(dims, x, ws, bs, e0, v)
+    d2 = mlp_double_backward(dims, x, ws, bs, None, v)
+    assert torch.equal(d1[0], d2[0])
+    for p, q in zip(d1[1] + d1[2], d2[1] + d2[2]):
+        assert torch.equal(p, q)
+    with pytest.raises(AssertionError):
+        mlp_backward_raw(dims, x, ws, bs, None, need_dx=True, need_dw=True)
