@@ -205,10 +205,12 @@ def main():
             tr.capture_grads = None
             return g, l, dict(tr.last), seen.get("fg")
 
-        def run_reference(mode, it, git, seed, permute_seed=None):
+        def run_reference(mode, it, git, seed, permute_seed=None, forced_fg=None):
             """the reference's own step from the snapshot.  permute_seed: re-number the hidden units of the reference's SDF MLP
             (rows of a Linear and the matching columns of the next one: the SAME function, a different fp32 summation order) --
-            the distance between two such runs is the reference's own rounding noise at this state."""
+            the distance between two such runs is the reference's own rounding noise at this state.  forced_fg: the foreground
+            samples of an earlier run, returned by `importance_sampling_sdf_model` in place of its own result (the perturbed SDF
+            would otherwise move the importance samples: with it the noise of the STEP is measured apart from the samplers')."""
             for p_, (s_, i_) in zip(pcgs, pcg_state):
                 p_.state, p_.inc = s_, i_
             aabb = T.create_bb_for_dataset("dtu")
@@ -257,7 +259,13 @@ def main():
                           loss=loss0, loss_rgb=loss_rgb, loss_eikonal=loss_eikonal, loss_curvature=loss_curvature,
                           loss_lipshitz=loss_lipshitz)
                 old_eik = hp.eikonal_weight
-                exec(code, ns)
+                orig_imp = T.importance_sampling_sdf_model
+                if forced_fg is not None:        # (run_net looks the name up in the reference module's own globals)
+                    T.importance_sampling_sdf_model = lambda *a_, **k_: forced_fg
+                try:
+                    exec(code, ns)
+                finally:
+                    T.importance_sampling_sdf_model = orig_imp
                 assert hp.eikonal_weight == old_eik
                 loss = ns["loss"]
                 for k in ("loss_rgb", "loss_eikonal", "loss_curvature", "loss_offsurface_high_sdf", "loss_mask"):
@@ -303,6 +311,9 @@ def main():
             with default_tensor(True):
                 gref, loss_ref, terms, fg_ref = run_reference(mode, it, git, seed)
                 gref2, loss_ref2, _, _ = run_reference(mode, it, git, seed, permute_seed=7)
+                gref4 = None
+                if fg_ref is not None:     # hidden units re-numbered AND the first run's samples: rounding noise of the step alone
+                    gref4, loss_ref4, _, _ = run_reference(mode, it, git, seed, permute_seed=11, forced_fg=fg_ref)
                 repeats = []                                                         # the same run again, three times
                 for _ in range(3):
                     g3, l3, _, _ = run_reference(mode, it, git, seed)
@@ -315,6 +326,9 @@ def main():
                     # ... and REPEATED unchanged (same samples by construction): what float atomics alone do to its gradients
                     "reference_repeat_noise": {k: max(r[k] for r in repeats)
                                                for k in ("worst_dense", "worst_lattice", "worst_lattice_l2", "loss_rel")}}
+            if gref4 is not None:
+                case["reference_self_noise_same_samples"] = dict(compare(gref4, gref), loss_rel=abs(loss_ref4 - loss_ref) / abs(loss_ref))
+                del gref4
             case["reference_repeat_noise"]["dense_by_tensor"] = {
                 k: max(r["grads"][k]["max_rel"] for r in repeats if k in r["grads"] and "max_rel" in r["grads"][k])
                 for k in repeats[0]["grads"] if "lattice" not in k and "max_rel" in repeats[0]["grads"][k]}
