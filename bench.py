@@ -178,70 +178,7 @@ def main():
     _lp = _L.lib().psdf_last_path
     _lp.restype = ctypes.c_int
     path_bwd, path_fwd = int(_lp(ctypes.c_int(1))), int(_lp(ctypes.c_int(2)))
-    # ---- extra row (not the headline): the north_star's stated shape, 24 levels -> 52-64-64-64-1, same batch, same step
     extra = {}
-    if world == 1 and not args.no_extra:
-        try:
-            hp24 = SdfHotPath(nr_levels=24, hidden=64, out_channels=1, device=dev, seed=0)
-            for _ in range(3):
-                hp24.step(rs, rgb, normals, gt)
-            torch.cuda.synchronize()
-            K24 = max(5, K // 2)
-            t24 = time.perf_counter()
-            for _ in range(K24):
-                hp24.step(rs, rgb, normals, gt)
-            torch.cuda.synchronize()
-            dt24 = (time.perf_counter() - t24) / K24
-            extra["L24_52-64-64-64-1"] = {"ms_per_step": dt24 * 1e3, "samples_per_s": N / dt24, "steps": K24,
-                                         "note": "same batch and step with a 24-level encoding (the reference's level count, "
-                                                 "models.py:144)"}
-            del hp24
-        except Exception as e:  # the extra row must never take the headline down
-            extra["L24_52-64-64-64-1"] = {"error": repr(e)}
-    # ---- the other half of BASELINE.json's metric, "train iters/sec" (cfg 4), and the cfg 3 / cfg 5 figures.  Every one of
-    # them is guarded: nothing here can take the headline down.  cfg 4 runs in this process (and this process group: under
-    # N > 1 every rank steps its own rays, gradients all-reduced over RCCL); cfg 3 / cfg 5 are one-GPU inference figures and
-    # run as child processes under a hard timeout, N = 1 only.
-    if not args.no_extra:
-        try:
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("psdf_train_bench", os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                                                                                         "tools", "train_bench.py"))
-            tb = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(tb)
-            rows = {}
-            for start in (0, 20000):
-                r = tb.measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=start)
-                rows["start_iter_%d" % start] = {k: r[k] for k in ("value", "unit", "ms_per_step", "fg_samples_per_step_per_gpu",
-                                                                    "rays_last_step", "steps", "warmup", "repeats_it_per_s", "backward")}
-            extra["train_iters_per_s"] = {
-                "metric": "train iters/sec (cfg 4: train_permuto_sdf.py's full SDF + colour + background step -- occupancy sampling, "
-                          "2 rounds of importance sampling, eikonal + curvature + off-surface losses, AdamW, grid refresh every 8th "
-                          "step -- on a synthetic 49-image reel; the reference's hyper-parameters, ~49 152 foreground samples per GPU "
-                          "per step)",
-                "n_gpus": world, "scaling": "weak", "data": "synthetic", "dtype": "f32",
-                "value": rows["start_iter_0"]["value"], "value_all_levels_open": rows["start_iter_20000"]["value"],
-                "note": "value: iteration counter 0 (coarse-to-fine window of the SDF lattice mostly closed); "
-                        "value_all_levels_open: counter 20 000 (every level carries gradient); median of three timed blocks of 60 "
-                        "steps, max over ranks", **rows}
-        except Exception as e:
-            extra["train_iters_per_s"] = {"error": repr(e)}
-    if world == 1 and not args.no_extra:
-        import subprocess
-        here = os.path.dirname(os.path.abspath(__file__))
-        for key, tool, env_extra in (("cfg3_render", "cfg3_render.py", {}),
-                                     ("cfg5_sphere_trace", "sphere_trace_bench.py", {"PSDF_TRACE_WEIGHTS": "sphere_init"})):
-            try:
-                r = subprocess.run([sys.executable, os.path.join(here, "tools", tool)], capture_output=True, text=True, timeout=240,
-                                   env=dict(os.environ, **env_extra))
-                extra[key] = json.loads(r.stdout.strip().splitlines()[-1])
-            except Exception as e:
-                extra[key] = {"error": repr(e)}
-        try:
-            extra["cfg3_ms_per_image"] = extra["cfg3_render"]["one_pool"]["ms_per_image"]
-            extra["cfg5_fps"] = extra["cfg5_sphere_trace"]["fps_graph"]
-        except Exception:
-            pass
     cdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else "cpu"
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     per_rank = None
@@ -366,15 +303,6 @@ def main():
             "fwd_only_samples_per_s": N / (ms["fwd"] * 1e-3),
             "extra": extra,
         }
-        # BASELINE.json's metric has two halves: "ray-samples/sec (encode+MLP+composite) AND train iters/sec"; the second one
-        # (and the cfg 3 / cfg 5 figures) at the top level as well, so that a reader of the line does not have to dig
-        tis = extra.get("train_iters_per_s", {})
-        if "value" in tis:
-            out["train_iters_per_s"] = tis["value"]
-            out["train_iters_per_s_all_levels_open"] = tis["value_all_levels_open"]
-        for k in ("cfg3_ms_per_image", "cfg5_fps"):
-            if k in extra:
-                out[k] = extra[k]
         if world > 1:
             from permuto_sdf_amd.parallel import _mode_default
             out["dp"] = {"per_rank": per_rank, "reduce": _mode_default() + (" (reduce-scatter + all-gather per bucket)" if _mode_default() == "reduce_scatter" else ""),
@@ -390,7 +318,7 @@ def main():
             # The vectorised torch-CPU restatement gets SLOWER beyond ~8 threads on the 256-core host (measured:
             # 8 thr 0.7 s, 32 thr 1.1 s, 64 thr 2.2 s per 32k samples), so the baseline uses 8 threads and says so.
             # It runs in a child process under a hard timeout: the baseline must never take the GPU number down.
-            import subprocess
+            import subprocess  # noqa: F811
             cores = min(8, os.cpu_count() or 1)
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(cores)],
@@ -399,7 +327,96 @@ def main():
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": cores, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+    # ---- everything below is EXTRA: the headline (`out`, rank 0) is complete.  A watchdog prints it and ends the process if the
+    # extras -- which under N > 1 contain collectives -- do not come back: they must never cost the driver its line.
+    import threading
+    out_ref = {"out": out if rank == 0 else None}
+
+    def _watchdog():
+        if rank == 0:
+            o = dict(out_ref["out"])
+            o["extra"] = dict(o.get("extra", {}), watchdog="the extra measurements did not finish within their time budget")
+            print(json.dumps(o), flush=True)
+        os._exit(0)
+    dog = threading.Timer(float(os.environ.get("PSDF_BENCH_EXTRA_BUDGET_S", "420")), _watchdog)
+    dog.daemon = True
+    dog.start()
+    # ---- extra row (not the headline): the north_star's stated shape, 24 levels -> 52-64-64-64-1, same batch, same step
+    if world == 1 and not args.no_extra:
+        try:
+            hp24 = SdfHotPath(nr_levels=24, hidden=64, out_channels=1, device=dev, seed=0)
+            for _ in range(3):
+                hp24.step(rs, rgb, normals, gt)
+            torch.cuda.synchronize()
+            K24 = max(5, K // 2)
+            t24 = time.perf_counter()
+            for _ in range(K24):
+                hp24.step(rs, rgb, normals, gt)
+            torch.cuda.synchronize()
+            dt24 = (time.perf_counter() - t24) / K24
+            extra["L24_52-64-64-64-1"] = {"ms_per_step": dt24 * 1e3, "samples_per_s": N / dt24, "steps": K24,
+                                         "note": "same batch and step with a 24-level encoding (the reference's level count, "
+                                                 "models.py:144)"}
+            del hp24
+        except Exception as e:  # the extra row must never take the headline down
+            extra["L24_52-64-64-64-1"] = {"error": repr(e)}
+    # ---- the other half of BASELINE.json's metric, "train iters/sec" (cfg 4), and the cfg 3 / cfg 5 figures.  Every one of
+    # them is guarded: nothing here can take the headline down.  cfg 4 runs in this process (and this process group: under
+    # N > 1 every rank steps its own rays, gradients all-reduced over RCCL); cfg 3 / cfg 5 are one-GPU inference figures and
+    # run as child processes under a hard timeout, N = 1 only.
+    if not args.no_extra:
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("psdf_train_bench", os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                                         "tools", "train_bench.py"))
+            tb = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(tb)
+            rows = {}
+            for start in (0, 20000):
+                r = tb.measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=start)
+                rows["start_iter_%d" % start] = {k: r[k] for k in ("value", "unit", "ms_per_step", "fg_samples_per_step_per_gpu",
+                                                                    "rays_last_step", "steps", "warmup", "repeats_it_per_s", "backward")}
+            extra["train_iters_per_s"] = {
+                "metric": "train iters/sec (cfg 4: train_permuto_sdf.py's full SDF + colour + background step -- occupancy sampling, "
+                          "2 rounds of importance sampling, eikonal + curvature + off-surface losses, AdamW, grid refresh every 8th "
+                          "step -- on a synthetic 49-image reel; the reference's hyper-parameters, ~49 152 foreground samples per GPU "
+                          "per step)",
+                "n_gpus": world, "scaling": "weak", "data": "synthetic", "dtype": "f32",
+                "value": rows["start_iter_0"]["value"], "value_all_levels_open": rows["start_iter_20000"]["value"],
+                "note": "value: iteration counter 0 (coarse-to-fine window of the SDF lattice mostly closed); "
+                        "value_all_levels_open: counter 20 000 (every level carries gradient); median of three timed blocks of 60 "
+                        "steps, max over ranks", **rows}
+        except Exception as e:
+            extra["train_iters_per_s"] = {"error": repr(e)}
+    if world == 1 and not args.no_extra:
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        for key, tool, env_extra in (("cfg3_render", "cfg3_render.py", {}),
+                                     ("cfg5_sphere_trace", "sphere_trace_bench.py", {"PSDF_TRACE_WEIGHTS": "sphere_init"})):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(here, "tools", tool)], capture_output=True, text=True, timeout=240,
+                                   env=dict(os.environ, **env_extra))
+                extra[key] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                extra[key] = {"error": repr(e)}
+        try:
+            extra["cfg3_ms_per_image"] = extra["cfg3_render"]["one_pool"]["ms_per_image"]
+            extra["cfg5_fps"] = extra["cfg5_sphere_trace"]["fps_graph"]
+        except Exception:
+            pass
+    if rank == 0:
+        # BASELINE.json's metric has two halves: "ray-samples/sec (encode+MLP+composite) AND train iters/sec"; the second one
+        # (and the cfg 3 / cfg 5 figures) at the top level as well, so that a reader of the line does not have to dig
+        tis = extra.get("train_iters_per_s", {})
+        if "value" in tis:
+            out["train_iters_per_s"] = tis["value"]
+            out["train_iters_per_s_all_levels_open"] = tis["value_all_levels_open"]
+        for k in ("cfg3_ms_per_image", "cfg5_fps"):
+            if k in extra:
+                out[k] = extra[k]
+        dog.cancel()
         print(json.dumps(out), flush=True)
+    dog.cancel()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
