@@ -121,7 +121,10 @@ class RaySamplesPacked:
         se = self.ray_start_end_idx
         return int((se[:, 1] - se[:, 0]).sum().item())
 
-    def compact_to_valid_samples(self):
+    def compact_to_valid_samples(self, known_nr_samples=None):
+        """known_nr_samples (not part of the reference's API): the exact sample count when the caller already has it on the
+        host -- the container of a producer that packs densely is then narrowed WITHOUT the host sync that reading
+        `cur_nr_samples` costs (train_step.Trainer._samples derives the counts after the importance rounds from the march's)"""
         R = self.m_nr_rays
         out = RaySamplesPacked(R, 0, device=self.samples_pos.device, _alloc=False)
         out.has_sdf = self.has_sdf
@@ -129,7 +132,7 @@ class RaySamplesPacked:
         out.fixed_nr_of_samples_per_ray = self.fixed_nr_of_samples_per_ray
         if self._exact:
             # producer already packed the samples densely in ray order: the compaction is a narrow view
-            cur = int(self.cur_nr_samples.item())      # the one host sync of this call
+            cur = int(self.cur_nr_samples.item()) if known_nr_samples is None else int(known_nr_samples)   # the one host sync
             n = min(cur, self.max_nr_samples)
             out.max_nr_samples = n
             for name in ("samples_pos", "samples_pos_4d", "samples_dirs", "samples_z", "samples_dt", "samples_sdf"):
@@ -403,6 +406,7 @@ class OccupancyGrid:
         if jitter_samples:
             rng.advance()
         rs._exact = True
+        object.__setattr__(rs, "_ray_counts", scratch[:R])     # per-ray sample counts (0 or >= 3), still on the device
         return rs
 
     def compute_first_sample_start_of_occupied_regions(self, ray_origins, ray_dirs, ray_t_entry, ray_t_exit):

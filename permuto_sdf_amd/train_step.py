@@ -438,8 +438,17 @@ class Trainer:
     def _samples(self, o, d, it, jitter=True):
         hp = self.hp
         _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
-        fg = self.grid.compute_samples_in_occupied_regions(o, d, te, tx, hp.min_dist_between_samples,
-                                                           hp.max_nr_samples_per_ray, jitter).compact_to_valid_samples()
+        pool = self.grid.compute_samples_in_occupied_regions(o, d, te, tx, hp.min_dist_between_samples,
+                                                             hp.max_nr_samples_per_ray, jitter)
+        # ONE host sync for the whole sampling phase (the reference has three: a `.item()` per compaction, src/RaySamplesPacked.cu:
+        # 44-54): the march's per-ray counts come to the host once; a ray holds 0 or >= 3 samples (OccupancyGridGPU.cuh:685-689),
+        # and every importance round adds exactly nr_samples_imp_sampling to each non-empty ray and nothing to the others
+        # (combine_count_kernel: n <= 1 ? 0 : n + nr_imp), so the later counts are host arithmetic
+        counts = pool._ray_counts.cpu()
+        n_known, nonempty = int(counts.sum()), int((counts > 0).sum())
+        if n_known > pool.max_nr_samples:      # pool overflow (silent in the reference): the generic path sorts it out
+            n_known = nonempty = None
+        fg = pool.compact_to_valid_samples(known_nr_samples=n_known)
         bg = None if self.with_mask else RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius,
                                                                        self.sphere.m_center_tensor, jitter, False)
         if fg.samples_pos.shape[0] == 0:
@@ -454,7 +463,9 @@ class Trainer:
                 imp.set_sdf(self.sdf.sdf_only(imp.samples_pos, it, key=self._param_key()))
             else:
                 fg.remove_sdf()
-            fg = VolumeRendering.combine_uniform_samples_with_imp(o, d, tx, fg, imp).compact_to_valid_samples()
+            if n_known is not None:
+                n_known += nonempty * hp.nr_samples_imp_sampling
+            fg = VolumeRendering.combine_uniform_samples_with_imp(o, d, tx, fg, imp).compact_to_valid_samples(known_nr_samples=n_known)
         return fg, bg
 
     # ---- run_net: train_permuto_sdf.py:111-169

@@ -180,3 +180,30 @@ def test_step_without_foreground_samples(dev, manual):
     assert float(lat[2].abs().max()) > 0          # background lattice
     assert float(lat[1].abs().max()) == 0.0       # colour lattice: nothing rendered
     assert float(lat[0].abs().max()) > 0          # SDF lattice: off-surface points
+
+
+@pytest.mark.parametrize("jitter", [False, True])
+def test_sampling_phase_derives_the_later_counts_on_the_host(dev, jitter):
+    """Round 4: `Trainer._samples` reads the march's per-ray counts ONCE and derives the sample counts after both importance rounds
+    on the host (a non-empty ray gains exactly 16 samples per round, an empty one none).  The containers it builds that way must
+    be the ones the syncing path builds: the device-side counter, the last ray's range end and the tensor shapes agree -- with
+    a grid that leaves many rays empty and rays that miss the sphere."""
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel, Trainer
+    hp = HyperParams()
+    hp.nr_rays, hp.target_nr_of_samples = 700, 700 * 96
+    tr = Trainer(dev, hp)
+    c = tr.grid.compute_grid_points(False)
+    tr.grid.set_grid_occupancy(((c.norm(dim=1) - 0.25).abs() < 0.03) & (c[:, 0] > -0.1))      # a shell with a part cut away
+    reel = SyntheticReel(dev, nr_images=3, height=60, width=80, dist=0.9)                     # close cameras: some rays miss
+    o, d, gt, hit, img_idx, _ = tr._draw_rays(reel)
+    fg, bg = tr._samples(o, d, 0, jitter)
+    n = fg.samples_pos.shape[0]
+    se = fg.ray_start_end_idx
+    lengths = (se[:, 1] - se[:, 0])
+    assert n > 0 and n == int(fg.cur_nr_samples.item()) == int(lengths.sum()) == int(se[:, 1].max())
+    assert int((lengths == 0).sum()) > 0 and int(lengths[lengths > 0].min()) >= 3 + 32     # empty rays exist; the others gained 2 x 16
+    for name in ("samples_pos", "samples_dirs", "samples_z", "samples_dt"):
+        assert getattr(fg, name).shape[0] == n
+    # and it is what the syncing path produces
+    fg2 = fg.compact_to_valid_samples()
+    assert fg2.samples_pos.shape[0] == n and torch.equal(fg2.samples_z, fg.samples_z)
