@@ -199,10 +199,21 @@ class ManualTrainer(Trainer):
         side_ctx = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         with torch.no_grad():
             o, d, gt, hit, img_idx, _ = self._draw_rays(reel)
-            fg, bg = self._samples(o, d, it, True)
             R = o.shape[0]
-            n_fg = fg.samples_pos.shape[0]
             cc = self.colorcal
+            calib = None
+            if cc is not None:              # per-ray calibration of both branches (models.py:384-385,523-524)
+                cam = img_idx.long()
+                fixed = (cam == cc.idx_with_fixed_calib)[:, None]
+                cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
+                cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
+                calib = (cw, cb)
+            # one stream: the background network's forward is enqueued while the host waits for the march's sample counts (it
+            # needs the background samples only), so the step's one host sync leaves no bubble on the GPU
+            early_bg = {}
+            fg, bg = self._samples(o, d, it, True, between=None if side is not None else
+                                   (lambda bg_: early_bg.__setitem__("B", self._bg_forward(bg_, calib))))
+            n_fg = fg.samples_pos.shape[0]
             sdfn, rgbn = self.sdf, self.rgb
             gb = self.grad_buffers[0]
             lin = list(sdfn.mlp_sdf.layers)
@@ -215,17 +226,13 @@ class ManualTrainer(Trainer):
             inv_s = torch.exp(torch.tensor(float(forced_variance) * 10.0, dtype=torch.float32, device="cpu")).clip(1e-6, 1e6).view(1).to(dev)
             rgbn.last_inv_s = inv_s.view(())
             loss = L.zeroed_scalar(dev)     # ONE accumulator: every loss kernel of the step adds its (already weighted) term to it
-            calib = None
-            if cc is not None:              # per-ray calibration of both branches (models.py:384-385,523-524)
-                cam = img_idx.long()
-                fixed = (cam == cc.idx_with_fixed_calib)[:, None]
-                cw = torch.where(fixed, torch.ones_like(cc.weight_delta[:1]), 1.0 + cc.weight_delta.index_select(0, cam))
-                cb = torch.where(fixed, torch.zeros_like(cc.bias[:1]), cc.bias.index_select(0, cam))
-                calib = (cw, cb)
             # ================================================================= forward
-            fork(self._events[0])
-            with side_ctx():
-                B = self._bg_forward(bg, calib)
+            if "B" in early_bg:
+                B = early_bg["B"]
+            else:
+                fork(self._events[0])
+                with side_ctx():
+                    B = self._bg_forward(bg, calib)
             if n_fg:
                 pts, dirs = fg.samples_pos, fg.samples_dirs
                 feat = _enc_fwd(sdfn.encoding, pts, win)

@@ -401,6 +401,7 @@ class Trainer:
         self.iter = 0
         self.capture_grads = None     # set to {} to have step() record the gradients it hands to the optimiser
         self.shard_optimizer = parallel.sharded_optimizer_default()   # data parallel: lattices updated by their owners only
+        self._pinned_counts = None    # host landing zone of the march's per-ray counts (one asynchronous copy per step)
         self._colour_window_t = 1.0   # the t the colour / background lattices' windows (`_win`, ones) currently hold
         self._late_seen = False       # set by the first iteration at / after iter_start_reduce_curv (acts from the next one on)
         self.last = {}
@@ -435,22 +436,36 @@ class Trainer:
 
     # ---- sampling (no grad): nerf_utils.py:502-525 + sdf_utils.py:383-423
     @torch.no_grad()
-    def _samples(self, o, d, it, jitter=True):
+    def _samples(self, o, d, it, jitter=True, between=None):
+        """-> (foreground container with both importance rounds merged in, background container or None).
+        between(bg): optional work to ENQUEUE while the host waits for the march's counts -- anything that needs the background
+        samples only (train_manual.ManualTrainer: the background network's forward).  The counts travel to pinned memory by an
+        asynchronous copy enqueued right behind the march, and the host waits for THAT copy's event, not for the stream: the
+        kernels `between` enqueued keep the GPU busy across what would otherwise be the step's one pipeline bubble."""
         hp = self.hp
         _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
         pool = self.grid.compute_samples_in_occupied_regions(o, d, te, tx, hp.min_dist_between_samples,
                                                              hp.max_nr_samples_per_ray, jitter)
+        R = o.shape[0]
+        if self._pinned_counts is None or self._pinned_counts.numel() < R:
+            self._pinned_counts = torch.empty(max(R, 8192), dtype=torch.int32).pin_memory()
+            self._counts_event = torch.cuda.Event()
+        self._pinned_counts[:R].copy_(pool._ray_counts, non_blocking=True)
+        self._counts_event.record()
         # ONE host sync for the whole sampling phase (the reference has three: a `.item()` per compaction, src/RaySamplesPacked.cu:
         # 44-54): the march's per-ray counts come to the host once; a ray holds 0 or >= 3 samples (OccupancyGridGPU.cuh:685-689),
         # and every importance round adds exactly nr_samples_imp_sampling to each non-empty ray and nothing to the others
         # (combine_count_kernel: n <= 1 ? 0 : n + nr_imp), so the later counts are host arithmetic
-        counts = pool._ray_counts.cpu()
+        bg = None if self.with_mask else RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius,
+                                                                       self.sphere.m_center_tensor, jitter, False)
+        if between is not None:
+            between(bg)
+        self._counts_event.synchronize()
+        counts = self._pinned_counts[:R]
         n_known, nonempty = int(counts.sum()), int((counts > 0).sum())
         if n_known > pool.max_nr_samples:      # pool overflow (silent in the reference): the generic path sorts it out
             n_known = nonempty = None
         fg = pool.compact_to_valid_samples(known_nr_samples=n_known)
-        bg = None if self.with_mask else RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius,
-                                                                       self.sphere.m_center_tensor, jitter, False)
         if fg.samples_pos.shape[0] == 0:
             return fg, bg
         fg.set_sdf(self.sdf.sdf_only(fg.samples_pos, it, key=self._param_key()))
