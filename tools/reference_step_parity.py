@@ -191,8 +191,8 @@ def main():
             orig = tr._samples
             seen = {}
 
-            def patched(o_, d_, it_, jitter=True):
-                fg_own, bg_own = orig(o_, d_, it_, jitter)
+            def patched(o_, d_, it_, jitter=True, **kw):
+                fg_own, bg_own = orig(o_, d_, it_, jitter, **kw)
                 seen["fg"] = fg_own
                 return (shared_fg if shared_fg is not None else fg_own), bg_own
             tr._samples = patched
