@@ -373,7 +373,14 @@ def main():
             spec.loader.exec_module(tb)
             rows = {}
             for start in (0, 20000):
-                r = tb.measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=start)
+                if world == 1:      # a fresh process, like the cfg 3 / cfg 5 figures: isolated from this one's state and failures
+                    import subprocess
+                    cp = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
+                                                                      "train_bench.py"), "--manual", "--start-iter", str(start)],
+                                        capture_output=True, text=True, timeout=180)
+                    r = json.loads(cp.stdout.strip().splitlines()[-1])
+                else:
+                    r = tb.measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=start)
                 rows["start_iter_%d" % start] = {k: r[k] for k in ("value", "unit", "ms_per_step", "fg_samples_per_step_per_gpu",
                                                                     "rays_last_step", "steps", "warmup", "repeats_it_per_s", "backward")}
             extra["train_iters_per_s"] = {
