@@ -81,12 +81,54 @@ class ManualTrainer(Trainer):
         self.overlap_streams = os.environ.get("PSDF_TRAIN_STREAMS", "0") == "1"
         self._side = None
         self._g_yo = None
+        # the NEXT step's rays, sphere intersection, occupancy march and background samples are issued on a side stream as soon
+        # as this step's grid refresh is enqueued, and run beside this step's backward (PSDF_TRAIN_PREFETCH=0: off)
+        self.prefetch_sampling = os.environ.get("PSDF_TRAIN_PREFETCH", "1") != "0"
+        self._prefetched = None
+        self._prefetch_side = None
         self._events = [torch.cuda.Event() for _ in range(4)] if self.dev.type == "cuda" else []
 
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
+
+    # ------------------------------------------------------------------ next step's sampling, first half, ahead of time
+    def _prefetch_valid(self, git):
+        pf = self._prefetched
+        return (pf is not None and pf["git"] == git and pf["nr_rays"] == self.nr_rays and self._hand_written_step_applies()
+                and "_draw_rays" not in self.__dict__ and "_samples" not in self.__dict__)
+
+    def _launch_prefetch(self, reel, next_git):
+        """The march is the largest kernel of the step (0.21 ms) and runs on 12 waves: nothing it needs -- the grid, the image
+        reel, the ray count -- changes after `_refresh_and_adapt`, and nothing else of the step draws from torch's generators
+        after that point.  So the generators are seeded for the next iteration HERE, its rays are drawn, intersected and marched
+        and its background samples placed on a side stream while this step's backward and optimiser run; the next step skips
+        its own seeding and starts from the generator state this leaves -- the very state it would have had after drawing its
+        rays itself.  The side stream first waits for the main stream (the refreshed grid), the next step's main stream waits
+        for the side stream's event.  Tensors allocated here live in the side stream's pool and are next reused by the NEXT
+        prefetch, whose work again starts behind a fresh event of the main stream: no kernel of either stream can still be
+        reading them.  A prefetch that does not fit the step that comes (iteration counter or ray count changed from outside,
+        samplers patched by a test) is dropped."""
+        if (not self.prefetch_sampling or self.dev.type != "cuda" or "_draw_rays" in self.__dict__
+                or "_samples" in self.__dict__):
+            self._prefetched = None
+            return
+        from . import parallel
+        main = torch.cuda.current_stream(self.dev)
+        if self._prefetch_side is None:
+            self._prefetch_side = torch.cuda.Stream(device=self.dev)
+        side = self._prefetch_side
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        parallel.seed_generators(parallel.step_seed(self._seed, parallel.rank(), next_git), self.dev)
+        with torch.cuda.stream(side), torch.no_grad():
+            rays = self._draw_rays(reel)
+            begun = self._samples_begin(rays[0], rays[1], True)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._prefetched = dict(git=next_git, nr_rays=self.nr_rays, reel=id(reel), rays=rays, begun=begun, done=done)
 
     def _hand_written_step_applies(self):
         """The hand-written step is built on the fused compositing kernels (at most 256 samples per ray: foreground
@@ -198,7 +240,14 @@ class ManualTrainer(Trainer):
                 main.wait_event(ev)
         side_ctx = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         with torch.no_grad():
-            o, d, gt, hit, img_idx, _ = self._draw_rays(reel)
+            begun = None
+            if self._prefetch_valid(git) and self._prefetched["reel"] == id(reel):
+                pf, self._prefetched = self._prefetched, None
+                main.wait_event(pf["done"])
+                (o, d, gt, hit, img_idx, _), begun = pf["rays"], pf["begun"]
+            else:
+                self._prefetched = None
+                o, d, gt, hit, img_idx, _ = self._draw_rays(reel)
             R = o.shape[0]
             cc = self.colorcal
             calib = None
@@ -211,7 +260,7 @@ class ManualTrainer(Trainer):
             # one stream: the background network's forward is enqueued while the host waits for the march's sample counts (it
             # needs the background samples only), so the step's one host sync leaves no bubble on the GPU
             early_bg = {}
-            fg, bg = self._samples(o, d, it, True, between=None if side is not None else
+            fg, bg = self._samples(o, d, it, True, begun=begun, between=None if side is not None else
                                    (lambda bg_: early_bg.__setitem__("B", self._bg_forward(bg_, calib))))
             n_fg = fg.samples_pos.shape[0]
             sdfn, rgbn = self.sdf, self.rgb
@@ -299,6 +348,7 @@ class ManualTrainer(Trainer):
             L.call("psdf_offsurface_loss", L.c_l(1024), L.ptr(y_o[0]), L.c_f(1e2), L.c_f(hp.offsurface_weight / 1024.0),
                    L.ptr(loss), L.ptr(g_so), L.stream())
             self._refresh_and_adapt(it, git, n_fg)
+            self._launch_prefetch(reel, git + 1)
 
             # ================================================================= backward (foreground; the background's is under way)
             g_cw = g_cb = None

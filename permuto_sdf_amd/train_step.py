@@ -401,12 +401,17 @@ class Trainer:
         self.iter = 0
         self.capture_grads = None     # set to {} to have step() record the gradients it hands to the optimiser
         self.shard_optimizer = parallel.sharded_optimizer_default()   # data parallel: lattices updated by their owners only
-        self._pinned_counts = None    # host landing zone of the march's per-ray counts (one asynchronous copy per step)
+        self._pinned_counts = None    # host landing zones of the march's per-ray counts (one asynchronous copy per step)
+        self._pinned_flip = 0
         self._colour_window_t = 1.0   # the t the colour / background lattices' windows (`_win`, ones) currently hold
         self._late_seen = False       # set by the first iteration at / after iter_start_reduce_curv (acts from the next one on)
         self.last = {}
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
         self._seed = seed + 1
+
+    def _prefetch_valid(self, git):
+        """True when the first half of iteration `git`'s sampling has already been issued (train_manual.ManualTrainer)"""
+        return False
 
     def _param_key(self):
         """changes whenever the parameters may have: the optimiser counts its steps (`generation`: the fused kernels write the
@@ -436,32 +441,49 @@ class Trainer:
 
     # ---- sampling (no grad): nerf_utils.py:502-525 + sdf_utils.py:383-423
     @torch.no_grad()
-    def _samples(self, o, d, it, jitter=True, between=None):
-        """-> (foreground container with both importance rounds merged in, background container or None).
-        between(bg): optional work to ENQUEUE while the host waits for the march's counts -- anything that needs the background
-        samples only (train_manual.ManualTrainer: the background network's forward).  The counts travel to pinned memory by an
-        asynchronous copy enqueued right behind the march, and the host waits for THAT copy's event, not for the stream: the
-        kernels `between` enqueued keep the GPU busy across what would otherwise be the step's one pipeline bubble."""
+    def _samples_begin(self, o, d, jitter=True):
+        """first half of the sampling phase, everything that needs neither a network nor the host: sphere intersection, the
+        occupancy march, the background sampler, and the march's per-ray counts on their way to pinned memory (an asynchronous
+        copy; `event` fires when it has landed).  Runs on whatever stream is current: train_manual.ManualTrainer issues it for
+        the NEXT step on a side stream while this step's backward runs."""
         hp = self.hp
         _, te, _, tx, _ = self.sphere.ray_intersection(o, d)
         pool = self.grid.compute_samples_in_occupied_regions(o, d, te, tx, hp.min_dist_between_samples,
                                                              hp.max_nr_samples_per_ray, jitter)
         R = o.shape[0]
-        if self._pinned_counts is None or self._pinned_counts.numel() < R:
-            self._pinned_counts = torch.empty(max(R, 8192), dtype=torch.int32).pin_memory()
-            self._counts_event = torch.cuda.Event()
-        self._pinned_counts[:R].copy_(pool._ray_counts, non_blocking=True)
-        self._counts_event.record()
+        pinned = self._pinned(R)
+        pinned[:R].copy_(pool._ray_counts, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        bg = None if self.with_mask else RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius,
+                                                                       self.sphere.m_center_tensor, jitter, False)
+        return dict(o=o, d=d, tx=tx, pool=pool, bg=bg, counts=pinned[:R], event=event, jitter=jitter)
+
+    def _pinned(self, R):
+        """host landing zones of the march's per-ray counts: two, used alternately (a prefetched step's counts are in flight
+        while the current step still reads its own)"""
+        if self._pinned_counts is None or self._pinned_counts[0].numel() < R:
+            self._pinned_counts = [torch.empty(max(R, 8192), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._pinned_flip ^= 1
+        return self._pinned_counts[self._pinned_flip]
+
+    def _samples(self, o, d, it, jitter=True, between=None, begun=None):
+        """-> (foreground container with both importance rounds merged in, background container or None).
+        between(bg): optional work to ENQUEUE while the host waits for the march's counts -- anything that needs the background
+        samples only (train_manual.ManualTrainer: the background network's forward).  The host waits for the EVENT of the counts'
+        copy, not for the stream: the kernels `between` enqueued keep the GPU busy across what would otherwise be the step's one
+        pipeline bubble.  begun: the result of an earlier `_samples_begin` for these rays (the prefetched first half)."""
+        hp = self.hp
+        b = begun if begun is not None else self._samples_begin(o, d, jitter)
+        tx, pool, bg = b["tx"], b["pool"], b["bg"]
         # ONE host sync for the whole sampling phase (the reference has three: a `.item()` per compaction, src/RaySamplesPacked.cu:
         # 44-54): the march's per-ray counts come to the host once; a ray holds 0 or >= 3 samples (OccupancyGridGPU.cuh:685-689),
         # and every importance round adds exactly nr_samples_imp_sampling to each non-empty ray and nothing to the others
         # (combine_count_kernel: n <= 1 ? 0 : n + nr_imp), so the later counts are host arithmetic
-        bg = None if self.with_mask else RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius,
-                                                                       self.sphere.m_center_tensor, jitter, False)
         if between is not None:
             between(bg)
-        self._counts_event.synchronize()
-        counts = self._pinned_counts[:R]
+        b["event"].synchronize()
+        counts = b["counts"]
         n_known, nonempty = int(counts.sum()), int((counts > 0).sum())
         if n_known > pool.max_nr_samples:      # pool overflow (silent in the reference): the generic path sorts it out
             n_known = nonempty = None
@@ -572,7 +594,8 @@ class Trainer:
         n0 = int(hp.nr_iter_sphere_fit) if self.reference_schedule else 0
         in_sphere_init = git < n0
         it = git if in_sphere_init else git - n0                      # iter_nr_for_anneal (permuto_sdf_utils.py:80-88)
-        parallel.seed_generators(parallel.step_seed(self._seed, parallel.rank(), git), self.dev)  # this rank's rays / jitter
+        if not self._prefetch_valid(git):     # (a prefetched step has been seeded, and its rays drawn, by the step before it)
+            parallel.seed_generators(parallel.step_seed(self._seed, parallel.rank(), git), self.dev)  # this rank's rays / jitter
         late = (not in_sphere_init) and it >= hp.iter_start_reduce_curv
         for group in self.opt.param_groups:
             if self.reference_schedule:

@@ -207,3 +207,36 @@ def test_sampling_phase_derives_the_later_counts_on_the_host(dev, jitter):
     # and it is what the syncing path produces
     fg2 = fg.compact_to_valid_samples()
     assert fg2.samples_pos.shape[0] == n and torch.equal(fg2.samples_z, fg.samples_z)
+
+
+def test_prefetched_sampling_draws_the_same_rays_and_samples(dev):
+    """Round 4: ManualTrainer issues the NEXT step's rays + sphere intersection + occupancy march + background samples on a side
+    stream while the current step's backward runs.  The prefetch seeds torch's generators for the next iteration and the next
+    step continues from the state that leaves; the jitter generators advance in the same order.  So a run with the prefetch must
+    draw exactly the rays and place exactly the samples of a run without it: per-step ray counts, sample counts (the adaptive
+    ray count depends on them) and the losses (to rounding: the lattice scatters use float atomics) agree over a stretch that
+    includes two occupancy refreshes."""
+    import copy
+    from permuto_sdf_amd.bridge import OccupancyGrid, RaySampler, VolumeRendering
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel
+    reel = SyntheticReel(dev, nr_images=4, height=60, width=80)
+    owners = (OccupancyGrid, RaySampler, VolumeRendering)
+    saved = [copy.deepcopy(c._rng) for c in owners]
+    runs = []
+    for prefetch in (False, True):
+        for c, r in zip(owners, saved):
+            c._rng = copy.deepcopy(r)
+        hp = HyperParams()
+        hp.nr_rays, hp.target_nr_of_samples = 256, 256 * 96
+        tr = ManualTrainer(dev, hp)
+        tr.prefetch_sampling = prefetch
+        rec = []
+        for _ in range(18):
+            loss = float(tr.step(reel))
+            rec.append((tr.last["nr_rays"], tr.last["nr_fg_samples"], loss))
+        runs.append(rec)
+        assert (tr._prefetched is not None) == prefetch
+    for (ra, na, la), (rb, nb, lb) in zip(*runs):
+        assert (ra, na) == (rb, nb), (runs[0], runs[1])
+        assert abs(la - lb) <= 2e-3 * max(1.0, abs(la)), (la, lb)
