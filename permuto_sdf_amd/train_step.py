@@ -463,7 +463,8 @@ class Trainer:
         """host landing zones of the march's per-ray counts: two, used alternately (a prefetched step's counts are in flight
         while the current step still reads its own)"""
         if self._pinned_counts is None or self._pinned_counts[0].numel() < R:
-            self._pinned_counts = [torch.empty(max(R, 8192), dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._pinned_counts = [torch.empty(max(R, 8192), dtype=torch.int32, device="cpu").pin_memory() for _ in range(2)]   # (explicit
+            # device: the reference's scripts set a CUDA default tensor type)
         self._pinned_flip ^= 1
         return self._pinned_counts[self._pinned_flip]
 
