@@ -323,6 +323,11 @@ def shard_bounds(n, unit=1, world=None, rank_=None):
     return r * per, (r + 1) * per
 
 
+def _inplace_collectives():
+    """PSDF_DP_INPLACE=1: reduce_scatter_tensor / all_gather_into_tensor with the shard ALIASING its slot of the full buffer"""
+    return os.environ.get("PSDF_DP_INPLACE") == "1"
+
+
 _warned = set()
 
 
@@ -350,19 +355,22 @@ class ShardedUpdate:
     every rank holds the owner's bytes.
 
         su = ShardedUpdate()
-        own = su.reduce_scatter(flat_grad)            # async, IN PLACE: flat_grad[own[0]:own[1]] becomes the sum over ranks
+        own = su.reduce_scatter(flat_grad)            # async: flat_grad[own[0]:own[1]] becomes the sum over ranks ...
         ...                                           # (more buckets / backward kernels)
-        su.wait()                                     # the caller's stream now sees the sums
+        su.wait()                                     # ... once this returns: the caller's stream now sees the sums
         <update param[own] from flat_grad[own]>       # optim.FusedAdamW.step(owned={param: [own]})
         su.all_gather(flat_param, own)                # async; su.wait() before the parameters are read again
 
     `reduce_scatter` returns None (and does nothing) when the tensor cannot be cut evenly: reduce it through GradientBuckets
-    and update it replicated.  Backends: nccl (= RCCL; the in-place forms: recv buffer = send buffer + rank * count), gloo
+    and update it replicated.  Backends: nccl (= RCCL: a separate shard + a copy into the owned range by default, the documented
+    in-place forms -- recv buffer = send buffer + rank * count -- with PSDF_DP_INPLACE=1), gloo
     (CPU tests; device tensors are staged through host memory, synchronously), Loopback (one GPU, identical virtual replicas:
     the owner's range is scaled by `world`; `virtual_ranks()` lets the caller play every owner in turn)."""
 
     def __init__(self):
         self.works = []
+        self.copies = []     # (owned range, shard) pairs to copy once their reduce-scatter has completed
+        self.keep = []       # sources of collectives in flight
         self.bytes = []
 
     @staticmethod
@@ -385,13 +393,16 @@ class ShardedUpdate:
         w, r = world_size(), dist.get_rank()
         n = hi - lo
         if dist.get_backend() == "nccl":
-            try:
+            if _inplace_collectives():
+                # receive buffer = send buffer + rank * count: NCCL / RCCL's documented in-place form (no staging at all)
                 self.works.append(dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, async_op=True))
-            except Exception as e:      # a backend build that rejects the aliased (in-place) form: same result through a shard
-                _warn_once("ShardedUpdate: in-place reduce_scatter_tensor failed (%r); staging through a shard buffer" % (e,))
+            else:
+                # default: the textbook form -- a separate shard (1/world of the bucket), copied into the owned range once the
+                # collective has completed (wait()).  No multi-GPU box has run this code yet: the form
+                # every RCCL build is exercised with daily is the safe default, the in-place one an option to measure
                 shard = torch.empty(n, dtype=flat.dtype, device=flat.device)
-                dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM)
-                flat[lo:hi].copy_(shard)
+                self.works.append(dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True))
+                self.copies.append((flat[lo:hi], shard))
             return own
         h = flat.detach().cpu() if flat.is_cuda else flat
         for o in range(w):
@@ -406,11 +417,9 @@ class ShardedUpdate:
             return
         lo, hi = own
         if dist.get_backend() == "nccl":
-            try:
-                self.works.append(dist.all_gather_into_tensor(flat, flat[lo:hi], async_op=True))
-            except Exception as e:
-                _warn_once("ShardedUpdate: in-place all_gather_into_tensor failed (%r); gathering from a copy of the shard" % (e,))
-                dist.all_gather_into_tensor(flat, flat[lo:hi].clone())
+            src = flat[lo:hi] if _inplace_collectives() else flat[lo:hi].clone()
+            self.works.append(dist.all_gather_into_tensor(flat, src, async_op=True))
+            self.keep.append(src)
             return
         h = flat.detach().cpu() if flat.is_cuda else flat
         parts = [torch.empty(hi - lo, dtype=h.dtype) for _ in range(world_size())]
@@ -421,7 +430,9 @@ class ShardedUpdate:
     def wait(self):
         for wk in self.works:
             wk.wait()
-        self.works = []
+        for dst, src in self.copies:      # (the caller's stream has just been ordered behind the collectives)
+            dst.copy_(src)
+        self.works, self.copies, self.keep = [], [], []
 
 
 def allreduce_module_grads(modules, buckets=None):

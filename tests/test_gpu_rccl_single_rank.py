@@ -37,11 +37,12 @@ g0, p0, _ = run(False)
 res = {}
 rank, world, local = parallel.init(backend="nccl")
 assert world == 1 and torch.distributed.get_backend() == "nccl" and parallel.collectives_active()
-for mode in ("reduce_scatter", "all_reduce", "sharded"):
-    os.environ["PSDF_DP_REDUCE"] = "reduce_scatter" if mode == "sharded" else mode
+for mode in ("reduce_scatter", "all_reduce", "sharded", "sharded_inplace"):
+    os.environ["PSDF_DP_REDUCE"] = "reduce_scatter" if mode.startswith("sharded") else mode
+    os.environ["PSDF_DP_INPLACE"] = "1" if mode == "sharded_inplace" else "0"
     # sharded: in-place reduce_scatter_tensor of the lattice ranges, owner update, in-place all_gather_into_tensor of the
     # PARAMETERS (parallel.ShardedUpdate) -- with one rank the owned range is everything, the calls are the real ones
-    os.environ["PSDF_DP_OPTIMIZER"] = "sharded" if mode == "sharded" else "replicated"
+    os.environ["PSDF_DP_OPTIMIZER"] = "sharded" if mode.startswith("sharded") else "replicated"
     g1, p1, bytes_ = run(True)
     # level-split launches change nothing within a level; a sum over one rank is the identity
     gerr = max(float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) for a, b in zip(g0, g1))
@@ -75,7 +76,7 @@ def test_real_rccl_collectives_on_one_rank(dev):
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
     res = json.loads(line[7:])
     print(res)
-    for mode in ("reduce_scatter", "all_reduce", "sharded"):
+    for mode in ("reduce_scatter", "all_reduce", "sharded", "sharded_inplace"):
         assert res[mode]["grad_rel"] <= 5e-5 and res[mode]["param_rel"] <= 1e-6, res
         assert len(res[mode]["bucket_bytes"]) == 3            # MLP bucket + two lattice level ranges
     # rows 100..163 of level 1, blocks of 64 floats = 32 rows: three touched blocks travel, not the 32 KB table
