@@ -82,6 +82,11 @@ class RaySamplesPacked:
         self.has_sdf = False
         self._exact = False  # set by producers whose output is already hole-free and ray ordered
         self._dense = False  # set by compaction: every slot of the sample tensors belongs to a ray (outputs need no zero fill)
+        # host-side knowledge that spares later compactions their sync (round 4): the per-ray counts of a march (device tensor),
+        # the number of non-empty rays once those counts have been on the host, the exact total of a merge derived from them
+        self._ray_counts = None
+        self._host_nonempty = None
+        self._known_total = None
         if _alloc:
             M, R = self.max_nr_samples, self.m_nr_rays
             f = dict(dtype=torch.float32, device=dev)
@@ -103,6 +108,8 @@ class RaySamplesPacked:
         if name in ("ray_start_end_idx", "cur_nr_samples"):
             object.__setattr__(self, "_exact", False)
             object.__setattr__(self, "_dense", False)
+            for k in ("_ray_counts", "_host_nonempty", "_known_total"):
+                object.__setattr__(self, k, None)
         object.__setattr__(self, name, value)
 
     # -- ray-index arguments shared by every per-ray kernel
@@ -132,7 +139,17 @@ class RaySamplesPacked:
         out.fixed_nr_of_samples_per_ray = self.fixed_nr_of_samples_per_ray
         if self._exact:
             # producer already packed the samples densely in ray order: the compaction is a narrow view
-            cur = int(self.cur_nr_samples.item()) if known_nr_samples is None else int(known_nr_samples)   # the one host sync
+            nonempty = self._host_nonempty
+            if known_nr_samples is not None:
+                cur = int(known_nr_samples)
+            elif self._known_total is not None:       # a merge whose total followed from counts that were already on the host
+                cur = int(self._known_total)
+            elif self._ray_counts is not None:        # a march: its per-ray counts instead of the total -- the same one sync, and
+                c = self._ray_counts.cpu()            # the number of non-empty rays comes with it (see combine_uniform_samples_with_imp)
+                cur = int(c.sum())
+                nonempty = int((c > 0).sum())
+            else:
+                cur = int(self.cur_nr_samples.item())      # the one host sync of this call
             n = min(cur, self.max_nr_samples)
             out.max_nr_samples = n
             for name in ("samples_pos", "samples_pos_4d", "samples_dirs", "samples_z", "samples_dt", "samples_sdf"):
@@ -149,6 +166,8 @@ class RaySamplesPacked:
                                   torch.full((1,), n, dtype=torch.int32, device=self.samples_pos.device))
             out._exact = True
             out._dense = cur <= self.max_nr_samples     # (an overflowing pool leaves slots of dropped rays behind)
+            if n == cur:                                # (after the assignments above: they reset the host-side knowledge)
+                object.__setattr__(out, "_host_nonempty", nonempty)
             return out
         dev = self.samples_pos.device
         se = self.ray_start_end_idx.to(torch.int32).contiguous()
@@ -670,6 +689,12 @@ class VolumeRendering:
                L.ptr(out.samples_dirs), L.ptr(out.samples_z), L.ptr(out.samples_dt), L.ptr(out.samples_sdf),
                L.ptr(out.ray_fixed_dt), L.ptr(out.ray_start_end_idx), L.ptr(out.cur_nr_samples), L.ptr(scratch), L.stream())
         out._exact = True
+        # the reference syncs again when this container is compacted (sdf_utils.py:383-423 -> src/RaySamplesPacked.cu:44-54).  When
+        # the number of non-empty rays of `uni` is known on the host -- it came with the march's counts -- the total is too: a ray
+        # with n <= 1 samples yields none, every other ray n + nr_imp (combine_count_kernel), and a march leaves 0 or >= 3 per ray
+        if uni._host_nonempty is not None and uni._exact:
+            object.__setattr__(out, "_known_total", n_uni + uni._host_nonempty * int(imp.fixed_nr_of_samples_per_ray))
+            object.__setattr__(out, "_host_nonempty", uni._host_nonempty)
         return out
 
     # ---- backward passes

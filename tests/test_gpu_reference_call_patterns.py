@@ -302,7 +302,11 @@ def test_importance_sampling_sequence_with_views(world, port, dev):
         else:
             rs.remove_sdf()
         n_before = rs.samples_pos.shape[0]
-        rs = VolumeRendering.combine_uniform_samples_with_imp(o, d, tx, rs, imp).compact_to_valid_samples()
+        comb = VolumeRendering.combine_uniform_samples_with_imp(o, d, tx, rs, imp)
+        # round 4: the merged total follows from the march's per-ray counts, which were on the host once (a ray holds 0 or >= 3
+        # samples, a round adds 16 to every non-empty one): the compaction below does not sync -- and must get the same container
+        assert comb._known_total is not None and comb._known_total == int(comb.cur_nr_samples.item())
+        rs = comb.compact_to_valid_samples()
         se = rs.ray_start_end_idx
         cnt = (se[:, 1] - se[:, 0])
         assert rs.samples_pos.shape[0] == int(cnt.sum()) and rs.samples_pos.shape[0] >= n_before
