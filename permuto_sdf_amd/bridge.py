@@ -9,9 +9,13 @@ through the C ABI on torch's CURRENT stream (the reference uses the NULL stream)
 """
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib as L
+
+_COUNTS_ON_HOST_MAX_RAYS = 32768      # compact_to_valid_samples: up to here the march's per-ray counts travel instead of its total
 
 MASK64 = (1 << 64) - 1
 PCG_DEFAULT_STATE = 0x853C49E6748FEA9B
@@ -144,10 +148,14 @@ class RaySamplesPacked:
                 cur = int(known_nr_samples)
             elif self._known_total is not None:       # a merge whose total followed from counts that were already on the host
                 cur = int(self._known_total)
-            elif self._ray_counts is not None:        # a march: its per-ray counts instead of the total -- the same one sync, and
-                c = self._ray_counts.cpu()            # the number of non-empty rays comes with it (see combine_uniform_samples_with_imp)
-                cur = int(c.sum())
-                nonempty = int((c > 0).sum())
+            elif self._ray_counts is not None and R <= _COUNTS_ON_HOST_MAX_RAYS:
+                # a march: its per-ray counts instead of the total -- the same one sync, and the number of non-empty rays comes
+                # with it (see combine_uniform_samples_with_imp).  Training-sized batches only: a whole image's counts are a
+                # 1 MB pageable copy, and a torch CPU reduction over them wakes the intra-op thread pool (measured: +12 ms per
+                # 512x512 image in tools/cfg3_render.py on the GPU box) -- numpy, single thread, 16 KB at 4096 rays
+                c = self._ray_counts.cpu().numpy()
+                cur = int(c.sum(dtype=np.int64))
+                nonempty = int(np.count_nonzero(c))
             else:
                 cur = int(self.cur_nr_samples.item())      # the one host sync of this call
             n = min(cur, self.max_nr_samples)

@@ -319,6 +319,27 @@ def test_importance_sampling_sequence_with_views(world, port, dev):
             assert torch.allclose(rs.samples_sdf, rs.samples_pos.norm(dim=1, keepdim=True) - 0.3, atol=2e-6)
 
 
+def test_compaction_of_a_whole_image_reads_the_total_not_the_counts(world, dev, monkeypatch):
+    """above bridge._COUNTS_ON_HOST_MAX_RAYS rays the compaction of a march reads the 4-byte total (per-ray counts of a 512x512
+    image are a 1 MB copy and a threaded host reduction: +12 ms per image, measured); the container is the same either way, only
+    the host-side knowledge that lets the NEXT merge skip its sync is absent"""
+    from permuto_sdf_amd import bridge
+    sph, grid = world["sphere"], world["grid"]
+    o, d = T(world["o"], dev), T(world["d"], dev)
+    _, te, _, tx, _ = sph.ray_intersection(o, d)
+    a = grid.compute_samples_in_occupied_regions(o, d, te, tx, 1e-4, 32, False)
+    assert a._ray_counts is not None and o.shape[0] <= bridge._COUNTS_ON_HOST_MAX_RAYS
+    ca = a.compact_to_valid_samples()
+    assert ca._host_nonempty == int((a._ray_counts > 0).sum().item())
+    monkeypatch.setattr(bridge, "_COUNTS_ON_HOST_MAX_RAYS", o.shape[0] - 1)
+    b = grid.compute_samples_in_occupied_regions(o, d, te, tx, 1e-4, 32, False)
+    cb = b.compact_to_valid_samples()
+    assert cb._host_nonempty is None and cb._known_total is None
+    assert cb.samples_pos.shape == ca.samples_pos.shape and torch.equal(cb.samples_pos, ca.samples_pos)
+    assert torch.equal(cb.ray_start_end_idx, ca.ray_start_end_idx) and torch.equal(cb.samples_z, ca.samples_z)
+    assert int(cb.cur_nr_samples.item()) == int(ca.cur_nr_samples.item()) == ca.samples_pos.shape[0]
+
+
 def test_fused_evaluators_behind_reference_style_models(dev, monkeypatch):
     """PSDF_FUSE_REFERENCE_MLPS=1 (permuto_sdf_amd/reference_fusion.py): a model class built like the reference's `SDF`
     (models.py:132-203: encoding constructed first inside __init__, then a Linear/GELU nn.Sequential, forward = encoding ->
