@@ -24,7 +24,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics
 # AGPRs (otherwise every chain / transpose result is copied out with v_accvgpr_read and the kernel spills; the flag crashes
 # this compiler on mlp_bwd.hip, hence per file)
 EXTRA = {"mlp_bwd_split.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
-         "mlp_bwd_split_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+         # -fno-slp-vectorize: the operand split relies on v_fma_mixlo/hi_f16 being selected for fp16(fma(x, 1, -high)); the SLP
+         # vectoriser turns the two fmas of a pair into v_pk_fma_f32 + conversions (5 instead of 3 instructions per pair)
+         "mlp_bwd_split_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
          # the BASELINE net's instantiation alone: ILP-first scheduling (the others spill under it, see the file)
          "mlp_bwd_split_double.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 # .hip files that include another .hip file (rebuilt when that one changes)

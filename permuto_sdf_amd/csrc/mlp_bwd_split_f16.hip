@@ -17,8 +17,25 @@
 // Everything else -- 16-sample tiles on v_mfma_f32_16x16x32, one wave per SIMD, persistent dW accumulators, transposes as
 // MFMAs against a 0/1 operand, LDS-DMA staging of the next tile, one gradient image per workgroup + a summing launch -- is the
 // design of mlp_bwd_split.hip; see there for the measurements that led to it.
+// Round 4, second half (1.08 -> 0.92 ms on 2 M samples, tools/r04_mlp_sched_ab.sh / profiles/r04_mlp_sched_ab.txt): the kernel
+// is bound by what ONE wave can issue (2 670 instructions per tile at ~7 cycles each; the matrix pipe is busy a quarter of the
+// time and hardly ever beside the VALU), so the round went into the instruction stream:
+//   * the 176 dW accumulators are PINNED in accumulation registers (an empty asm with an "a" constraint on either side of
+//     their MFMA pair: the compiler then emits the AGPR form itself and still sees the MFMAs for its hazard bookkeeping) -- left
+//     alone, a changing subset was parked in AGPRs and copied to VGPRs and back around every use (100 - 230 v_accvgpr moves
+//     per tile, depending on the build);
+//   * an operand is split with v_cvt_pkrtz + v_fma_mixlo/hi_f16 (3 instead of 5 instructions per pair, see split2);
+//   * weight records are requested one k-step ahead of the MFMAs that need them, biases and final weights ahead of the
+//     activation blocks (38 -> 15 s_waitcnt per tile);
+//   * two GELU pairs are evaluated side by side (a dependent v_pk_fma_f32 needs a wait state: 117 -> 32 s_nop per tile);
+//   * the staging buffer keeps 64 zero-padded rows, so the layer-0 operand is read without predicates (-110 instructions);
+//   * dX is stored through one lane base + uniform row offsets (-100), bias sums run as register pairs (-110, 86 of them moves);
+//   * gelu' of the inner layers waits in LDS instead of in 32 registers, the dZ-side dW operand takes 4 registers instead of 8.
+// 2 000 instructions per tile now.  Measured and not kept: requesting weights without the sched_barrier pins (the compiler sinks
+// them back), a software-pipelined H-side split with sched_group_barrier patterns (the pattern solver rearranged the rest of the
+// region: slower), other scheduler strategies (max-ilp, iterative-*: more spills or longer).
 // Accuracy against float64: tests/test_gpu_mlp.py::test_split_f16_backward_matches_float64.  Built with
-// -mllvm -amdgpu-mfma-vgpr-form=1.
+// -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize (build.py).
 #include "psdf_common.h"
 
 namespace {
@@ -37,94 +54,19 @@ constexpr int RECL = NT * 2 * NP * 64;
 constexpr int OFF_W0 = 0, OFF_W1 = RECL, OFF_W2 = 2 * RECL, OFF_T2 = 3 * RECL, OFF_T1 = 4 * RECL, OFF_T0 = 5 * RECL;
 constexpr int off_f32(int nt0) { return 5 * RECL + nt0 * 2 * NP * 64; }
 constexpr int TAIL_FLOATS = 3 * HID + HID + 1;  // biases of the three hidden layers, final weights, final bias
-#if defined(PSDF_F16_PROTO_OCC)
-// MEASUREMENT BUILD ONLY (round 4, tools/r04_mlp_occupancy_proto.sh; never the shipped library): what would TWO waves per SIMD
-// buy?  The workgroup-cooperative design of DESIGN.md "Next" keeps 1/4 of the dW accumulators per wave (44 registers instead of
-// 176) so that eight waves share one CU.  This build emulates its per-wave resources without its LDS exchange: every dW product
-// of a layer lands in one of FOUR accumulators (wrong sums, same MFMA and VALU instruction mix), eight waves per workgroup.
-constexpr int NWAVES = 8;
-#else
 constexpr int NWAVES = 4;
-#endif
 constexpr size_t img_aligned(int nt0) { return ((size_t)off_f32(nt0) * 16 + TAIL_FLOATS * 4 + 15) / 16 * 16; }
 // gradient image (floats): dW1 [64][64 (K0 used)], dW2 [64][64], dW3 [64][64], db1, db2, db3 [64], dW4 [64], db4
 constexpr int G_W1 = 0, G_W2 = 4096, G_W3 = 8192, G_B1 = 12288, G_B2 = 12352, G_B3 = 12416, G_W4 = 12480, G_B4 = 12544,
               G_TOTAL = 12545;
 
-__device__ __forceinline__ float erf_fast(float a) {
-  const float t = fabsf(a), s = a * a;
-  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-  float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-  r = fmaf(r, s, u);
-  r = fmaf(r, t, -1.06777877e-1f);
-  r = fmaf(r, t, -6.34846687e-1f);
-  r = fmaf(r, t, -1.28717512e-1f);
-  r = fmaf(r, t, -t);
-  const float hi = copysignf(1.0f - __expf(r), a);
-  float q = -5.96761703e-4f;
-  q = fmaf(q, s, 4.99119423e-3f);
-  q = fmaf(q, s, -2.67681349e-2f);
-  q = fmaf(q, s, 1.12819925e-1f);
-  q = fmaf(q, s, -3.76125336e-1f);
-  q = fmaf(q, s, 1.28379166e-1f);
-  const float lo = fmaf(q, a, a);
-  return t > 0.927734375f ? hi : lo;
-}
-// gelu and its derivative Phi(z) + z phi(z) from one erf and one exp
-// Three interchangeable evaluators; the kernel picks per instantiation (see gelu_both below).
-// tools/gelu_fit_rational.py: gelu AND gelu' from ONE exponential and ONE reciprocal (the recompute needs both):
-//   E = exp(-z^2/2), t = 1/(1 + p|z|), Phi(-|z|) = t P6(t) E, cdf = z < 0 ? Phi(-|z|) : 1 - Phi(-|z|),
-//   gelu = z cdf, gelu' = cdf + z E / sqrt(2 pi).  17 instructions against ~30; error against float64: gelu 1.8e-7 |z|
-//   (the fp32 formula 0.5 z (1 + erf(z / sqrt 2)) itself: 1.1e-7 |z|), gelu' 1.9e-7.
-__device__ __forceinline__ void gelu_rational(float z, float& hval, float& gprime) {
-  const float E = __builtin_amdgcn_exp2f(z * z * -0.72134752044448170368f);
-  const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(z), 0.39f, 1.0f));
-  float q = 5.384693295e-02f;
-  q = fmaf(q, t, -2.582434118e-01f);
-  q = fmaf(q, t, 3.751679361e-01f);
-  q = fmaf(q, t, -1.663514599e-02f);
-  q = fmaf(q, t, 1.944366544e-01f);
-  q = fmaf(q, t, 1.514270604e-01f);
-  const float tail = q * t * E;
-  const float cdf = z < 0.f ? tail : 1.0f - tail;
-  hval = z * cdf;
-  gprime = fmaf(z, E * 0.3989422804014327f, cdf);
-}
-// torch's formula 0.5 z (1 + erf(z / sqrt 2)): one erf (itself one exp) and one more exp
-__device__ __forceinline__ void gelu_erf(float z, float& hval, float& gprime) {
-  const float cdf = fmaf(0.5f, erf_fast(z * 0.70710678118654752440f), 0.5f);
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
-  hval = z * cdf;
-  gprime = fmaf(z, pdf, cdf);
-}
-// tools/gelu_fit.py: e = Phi(-t) = exp2(P8(t)), t = min(|z|, 5.75); gelu = max(z, 0) - t e (error 8.6e-8 |z| against float64, the
-// fp32 erf formula itself has 1.06e-7 |z|); gelu' = (z < 0 ? e : 1 - e) + z phi(t) from the same e (1.5e-7)
-__device__ __forceinline__ void gelu_poly(float z, float& hval, float& gprime) {
-  const float t = fminf(fabsf(z), 5.75f);
-  float p = -2.772052994e-06f;
-  p = fmaf(p, t, 3.862077210e-05f);
-  p = fmaf(p, t, -1.825476502e-04f);
-  p = fmaf(p, t, -1.458701736e-04f);
-  p = fmaf(p, t, 7.075471804e-03f);
-  p = fmaf(p, t, -5.250502750e-02f);
-  p = fmaf(p, t, -4.592049122e-01f);
-  p = fmaf(p, t, -1.151105762e+00f);
-  p = fmaf(p, t, -1.000000000e+00f);
-  const float e = __builtin_amdgcn_exp2f(p);
-  hval = fmaf(-t, e, fmaxf(z, 0.f));
-  const float cdf = z < 0.f ? e : 1.0f - e;
-  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(t * t * -0.72134752044448170368f);
-  gprime = fmaf(copysignf(t, z), pdf, cdf);
-}
-// Measured on the headline batch (profiles/r02_mlp_bwd_prototype_timings.txt): rational 1.37 ms, erf 1.47 ms, poly 1.47 ms
-// for the double-staged instantiation (zero scratch in all three).  The widest instantiation (K0 > 48) is at the register
-// limit and the rational form's extra live values spill there (44 B scratch; a spill reload waits for the LDS-DMA in
-// flight), so it keeps erf.
-template <bool RATIONAL>
-__device__ __forceinline__ void gelu_both(float z, float& hval, float& gprime) {
-  if constexpr (RATIONAL) gelu_rational(z, hval, gprime);
-  else gelu_erf(z, hval, gprime);
-}
+// gelu AND gelu' = Phi(z) + z phi(z) from ONE exponential and ONE reciprocal (tools/gelu_fit_rational.py; the recompute needs
+// both):  E = exp(-z^2/2), t = 1/(1 + p|z|), Phi(-|z|) = t P6(t) E, cdf = z < 0 ? Phi(-|z|) : 1 - Phi(-|z|),
+//   gelu = z cdf, gelu' = cdf + z E / sqrt(2 pi).  Error against float64: gelu 1.8e-7 |z| (the fp32 formula
+//   0.5 z (1 + erf(z / sqrt 2)) itself: 1.1e-7 |z|), gelu' 1.9e-7.  (An erf-based and a pure-polynomial evaluator were measured
+//   beside it in round 2 -- 1.47 ms against 1.37 ms, profiles/r02_mlp_bwd_prototype_timings.txt -- and are gone.)
+// Written for TWO PAIRS at a time in packed fp32 arithmetic, same operations in the same order as the forward kernel's scalar
+// form (mlp.hip; bit-identical activations): gelu_rational4 below.
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
@@ -134,12 +76,24 @@ struct BP {  // the two fp16 pieces of one 8-element operand: p[0] = high, p[1] 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two fp32 -> {high pieces, low pieces}, each a packed pair (element 0 in the low half).  v_cvt_pkrtz rounds toward zero, so
 // the remainder v - high is exact in fp32 (24 - 11 = 13 significant bits); the low piece keeps its top 11.
+// `one` is 1.0f the optimiser cannot see through (an empty asm on a scalar register): fma(x, one, -high) must reach instruction
+// selection as an fma with an fp16 source and an fp16 result, which is v_fma_mixlo_f16 / v_fma_mixhi_f16 -- x * 1 - high formed
+// exactly and rounded once to fp16 (nearest even; subnormal results kept: the kernel runs with fp16 denormals on) -- ONE
+// instruction per element instead of two conversions back, a packed subtraction and a second packed conversion.  Needs
+// -fno-slp-vectorize (the SLP vectoriser packs the two fmas into v_pk_fma_f32 + conversions otherwise).  NOT inline asm: the
+// hazard recogniser must see the VALU write -- an MFMA that reads a register needs two wait states after a VALU wrote it (the
+// compiler puts an s_nop 1 there), and a build with the instruction in an asm statement computed garbage whenever the
+// scheduler happened to place one directly in front of an MFMA.
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  float one = 1.0f;
+  asm("" : "+s"(one));
   const auto h2 = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  const f32x2 r = f32x2{x0, x1} - f32x2{(float)h2[0], (float)h2[1]};
-  const auto l2 = __builtin_amdgcn_cvt_pkrtz(r.x, r.y);
+  h2_t l;
+  l[0] = (_Float16)__builtin_fmaf(x0, one, -(float)h2[0]);
+  l[1] = (_Float16)__builtin_fmaf(x1, one, -(float)h2[1]);
   hi = __builtin_bit_cast(uint32_t, h2);
-  lo = __builtin_bit_cast(uint32_t, l2);
+  lo = __builtin_bit_cast(uint32_t, l);
 }
 __device__ __forceinline__ void split8(const float (&x)[8], BP& o) {
   u32x4 q0, q1;
@@ -155,13 +109,14 @@ __device__ __forceinline__ void split8(const float (&x)[8], BP& o) {
 }
 // dW operands.  A transposed tile gives a lane only four samples (k-slots (g, 0..3) of the 32-deep MFMA); slots (g, 4..7)
 // carry ANOTHER PIECE of the same four samples, so that one MFMA sums two piece products:
-//   [a0|a0] x [b0|b1] = a0 b0 + a0 b1,   [a1|a1] x [b0|b1] = a1 b0 + a1 b1   (the last one is free: its K half was empty)
-// Two MFMAs per 16x16 block of dW (88 per tile; the bf16 scheme: 132).
+//   [a0|a1] x [b1|b1] = a0 b1 + a1 b1,   [a0|a1] x [b0|b0] = a0 b0 + a1 b0   (the fourth product is free: its K half was empty)
+// Two MFMAs per 16x16 block of dW (88 per tile; the bf16 scheme: 132).  The duplicated halves sit on the H side: its operand
+// lives for one column of blocks, the four dZ operands for the whole layer (4 registers each instead of 8).
 struct AT {  // dZ side
-  f16x8 t00, t11;
+  f16x8 t01;
 };
 struct BT {  // H side
-  f16x8 t01;
+  f16x8 t00, t11;
 };
 __device__ __forceinline__ f16x8 halves(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {
   const u32x4 q = {a0, a1, b0, b1};
@@ -172,28 +127,10 @@ __device__ __forceinline__ void split4(const f32x4& t, BT& o) {
   uint32_t ha, la, hb, lb;
   split2(t[0], t[1], ha, la);
   split2(t[2], t[3], hb, lb);
-  o.t01 = halves(ha, hb, la, lb);
+  o.t00 = halves(ha, hb, ha, hb);
+  o.t11 = halves(la, lb, la, lb);
 }
 
-// out[t] += W(tile t, k-step s) x operand pieces: three products, smallest first; two tiles at a time so that consecutive
-// MFMAs go to different accumulators.  w_s -> record [t = 0][s][piece 0][lane]; tile stride = 2*NP*64 records.
-template <int NTILE>
-__device__ __forceinline__ void mac16(f32x4 (&out)[NTILE], const BP& b, const u32x4* __restrict__ w_s) {
-#pragma unroll
-  for (int t0 = 0; t0 < NTILE; t0 += 2) {
-    f16x8 a[2][NP];
-#pragma unroll
-    for (int dt = 0; dt < 2; dt++)
-#pragma unroll
-      for (int p = 0; p < NP; p++)
-        if (t0 + dt < NTILE) a[dt][p] = __builtin_bit_cast(f16x8, w_s[(t0 + dt) * (2 * NP * 64) + p * 64]);
-#define PROD(PA, PB)                                                                  \
-  _Pragma("unroll") for (int dt = 0; dt < 2; dt++) if (t0 + dt < NTILE) out[t0 + dt] = \
-      MFMA16(a[dt][PA], b.p[PB], out[t0 + dt]);
-    PROD(1, 0) PROD(0, 1) PROD(0, 0)
-#undef PROD
-  }
-}
 // B operand of k-step s from the D tiles 2s, 2s+1 of an activation
 __device__ __forceinline__ void step_operand(const f32x4 (&act)[NT], int s, float (&x)[8]) {
 #pragma unroll
@@ -223,23 +160,53 @@ __device__ __forceinline__ f32x4 transpose_f32(const BP& b, f16x8 id) {
   o = MFMA16(b.p[0], id, o);
   return o;
 }
-// piece-wise transpose: dZ-side dW operands of a 16-feature tile, plus this lane's fp32 sum for the bias gradient
-__device__ __forceinline__ void transpose_pieces(const BP& b, f16x8 id, AT& out, float& sum, const f32x4& rT) {
+__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 sp2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 lo2(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
+// running sum of products over the samples of a lane.  PAIR: two partial sums (samples 4 g + {0, 1} and 4 g + {2, 3}: register
+// pairs as an MFMA leaves them, so the packed multiply-adds need no moves -- the scalar form cost 86 v_mov per tile), added in the
+// epilogue; the widest instantiation (K0 > 48) has no registers for the second half and keeps one sum
+template <bool PAIR> struct Sum;
+template <> struct Sum<true> {
+  f32x2 v;
+  __device__ __forceinline__ void clear() { v = f32x2{0.f, 0.f}; }
+  __device__ __forceinline__ void add(const f32x4& o, const f32x4& w) {
+    v = pk_fma2(lo2(o), lo2(w), v);
+    v = pk_fma2(hi2(o), hi2(w), v);
+  }
+  __device__ __forceinline__ float total() const { return v.x + v.y; }
+};
+template <> struct Sum<false> {
+  float v;
+  __device__ __forceinline__ void clear() { v = 0.f; }
+  __device__ __forceinline__ void add(const f32x4& o, const f32x4& w) { v += fmaf(o[0], w[0], o[1] * w[1]) + fmaf(o[2], w[2], o[3] * w[3]); }
+  __device__ __forceinline__ float total() const { return v; }
+};
+// piece-wise transpose: dZ-side dW operand of a 16-feature tile, plus this lane's fp32 sum for the bias gradient
+template <bool PAIR>
+__device__ __forceinline__ void transpose_pieces(const BP& b, f16x8 id, AT& out, Sum<PAIR>& sum, const f32x4& rT) {
   uint32_t q[NP][2];
 #pragma unroll
   for (int p = 0; p < NP; p++) {
     const f32x4 o = MFMA16(b.p[p], id, zero4());   // fp16-valued: the conversion back is exact
     // bias gradient: dZ of sample 4 g + r was evaluated on the mantissa of its dY; rT[r] restores the magnitude (globally scaled)
-    sum += fmaf(o[0], rT[0], o[1] * rT[1]) + fmaf(o[2], rT[2], o[3] * rT[3]);
+    sum.add(o, rT);
     q[p][0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o[0], o[1]));
     q[p][1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o[2], o[3]));
   }
-  out.t00 = halves(q[0][0], q[0][1], q[0][0], q[0][1]);
-  out.t11 = halves(q[1][0], q[1][1], q[1][0], q[1][1]);
+  out.t01 = halves(q[0][0], q[0][1], q[1][0], q[1][1]);
 }
+// The 176 dW accumulators live in ACCUMULATION registers for the whole kernel: the empty asm statements pin the value to an
+// AGPR on either side of its MFMA pair, and the compiler then emits the AGPR form of the two MFMAs itself (and keeps them in
+// its hazard bookkeeping -- an MFMA written in asm is invisible to it, see split2).  Left to the register allocator, a changing
+// subset of the accumulators was parked in AGPRs and moved to VGPRs and back around its pair (v_accvgpr_read x 4, two MFMAs,
+// v_accvgpr_write x 4: 100 - 230 moves per tile, depending on the build).
 __device__ __forceinline__ f32x4 dw_mac(f32x4 acc, const AT& A, const BT& B) {
-  acc = MFMA16(A.t11, B.t01, acc);   // smallest first
-  acc = MFMA16(A.t00, B.t01, acc);
+  asm("" : "+a"(acc));
+  acc = MFMA16(A.t01, B.t11, acc);   // smallest first
+  acc = MFMA16(A.t01, B.t00, acc);
+  asm("" : "+a"(acc));
   return acc;
 }
 template <int NTILE>
@@ -252,79 +219,91 @@ __device__ __forceinline__ void zero_init(f32x4 (&acc)[NTILE]) {
 #pragma unroll
   for (int t = 0; t < NTILE; t++) acc[t] = zero4();
 }
-// gelu_rational on a PAIR of values with packed fp32 arithmetic (v_pk_mul / v_pk_fma / v_pk_add: one issue slot for two
-// elements; with one wave per SIMD an instruction costs ~5 cycles whatever it is).  Same operations in the same order as the
-// scalar form (bit-identical); exp2, rcp, abs and the sign select stay per element: ~24 instructions per pair instead of 34.
-__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 sp2(float v) { return f32x2{v, v}; }
-__device__ __forceinline__ void gelu_rational2(f32x2 z, f32x2& hval, f32x2& gprime) {
-  const f32x2 ea = (z * z) * sp2(-0.72134752044448170368f);
-  const f32x2 E = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
-  const f32x2 az = {fabsf(z.x), fabsf(z.y)};
-  const f32x2 den = pk_fma2(az, sp2(0.39f), sp2(1.0f));
-  const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-  f32x2 q = sp2(5.384693295e-02f);
-  q = pk_fma2(q, t, sp2(-2.582434118e-01f));
-  q = pk_fma2(q, t, sp2(3.751679361e-01f));
-  q = pk_fma2(q, t, sp2(-1.663514599e-02f));
-  q = pk_fma2(q, t, sp2(1.944366544e-01f));
-  q = pk_fma2(q, t, sp2(1.514270604e-01f));
-  const f32x2 tail = (q * t) * E;
-  const f32x2 om = sp2(1.0f) - tail;
-  const f32x2 cdf = {z.x < 0.f ? tail.x : om.x, z.y < 0.f ? tail.y : om.y};
-  hval = z * cdf;
-  gprime = pk_fma2(z, E * sp2(0.3989422804014327f), cdf);
+// two PAIRS at once, statement by statement: a dependent v_pk_fma_f32 needs a wait state after the one that feeds it, and the
+// Horner chain of a single pair is nothing but such dependences (117 s_nop per tile) -- two chains side by side fill them
+__device__ __forceinline__ void gelu_rational4(f32x2 za, f32x2 zb, f32x2& ha, f32x2& hb, f32x2& ga, f32x2& gb) {
+  const f32x2 ea = (za * za) * sp2(-0.72134752044448170368f), eb = (zb * zb) * sp2(-0.72134752044448170368f);
+  const f32x2 Ea = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+  const f32x2 Eb = {__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
+  const f32x2 da = pk_fma2(f32x2{fabsf(za.x), fabsf(za.y)}, sp2(0.39f), sp2(1.0f));
+  const f32x2 db = pk_fma2(f32x2{fabsf(zb.x), fabsf(zb.y)}, sp2(0.39f), sp2(1.0f));
+  const f32x2 ta = {__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
+  const f32x2 tb = {__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+  f32x2 qa = sp2(5.384693295e-02f), qb = sp2(5.384693295e-02f);
+#define HORNER(C) qa = pk_fma2(qa, ta, sp2(C)); qb = pk_fma2(qb, tb, sp2(C));
+  HORNER(-2.582434118e-01f) HORNER(3.751679361e-01f) HORNER(-1.663514599e-02f) HORNER(1.944366544e-01f) HORNER(1.514270604e-01f)
+#undef HORNER
+  const f32x2 la = (qa * ta) * Ea, lb = (qb * tb) * Eb;
+  const f32x2 oa = sp2(1.0f) - la, ob = sp2(1.0f) - lb;
+  const f32x2 ca = {za.x < 0.f ? la.x : oa.x, za.y < 0.f ? la.y : oa.y};
+  const f32x2 cb = {zb.x < 0.f ? lb.x : ob.x, zb.y < 0.f ? lb.y : ob.y};
+  ha = za * ca;
+  hb = zb * cb;
+  ga = pk_fma2(za, Ea * sp2(0.3989422804014327f), ca);
+  gb = pk_fma2(zb, Eb * sp2(0.3989422804014327f), cb);
 }
 // in place: acc <- gelu(acc), gp <- gelu'(acc)
-template <bool RATIONAL>
 __device__ __forceinline__ void act_both(f32x4 (&acc)[NT], f32x4 (&gp)[NT]) {
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-#if defined(PSDF_F16_PACKED_GELU)
-#pragma unroll
-    for (int r = 0; r < 4; r += 2) {
-      f32x2 hv, d;
-      gelu_rational2(f32x2{acc[t][r], acc[t][r + 1]}, hv, d);
-      acc[t][r] = hv.x;
-      acc[t][r + 1] = hv.y;
-      gp[t][r] = d.x;
-      gp[t][r + 1] = d.y;
-    }
-#else
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      float hv, d;
-      gelu_both<RATIONAL>(acc[t][r], hv, d);
-      acc[t][r] = hv;
-      gp[t][r] = d;
-    }
-#endif
+    f32x2 ha, hb, ga, gb;
+    gelu_rational4(f32x2{acc[t][0], acc[t][1]}, f32x2{acc[t][2], acc[t][3]}, ha, hb, ga, gb);
+    acc[t] = f32x4{ha.x, ha.y, hb.x, hb.y};
+    gp[t] = f32x4{ga.x, ga.y, gb.x, gb.y};
   }
 }
-// chain layer over the two k-steps of `in`; per_step(s, pieces) sees the operand pieces of each k-step
+// chain layer over the two k-steps of `in`; per_step(s, pieces) sees the operand pieces of each k-step.
+// The weight records of a k-step (NTILE tiles x 2 pieces) are requested BEFORE the operand of that step is split, and those of
+// step 1 before the MFMAs of step 0 are issued: the LDS round trip runs under the VALU work instead of in front of the MFMAs
+template <int NTILE>
+__device__ __forceinline__ void load_w(f16x8 (&a)[NTILE][NP], const u32x4* __restrict__ w_s) {
+#pragma unroll
+  for (int t = 0; t < NTILE; t++)
+#pragma unroll
+    for (int p = 0; p < NP; p++) a[t][p] = __builtin_bit_cast(f16x8, w_s[t * (2 * NP * 64) + p * 64]);
+}
+// out[t] += W(tile t) x operand pieces: three products, smallest first; two tiles at a time so that consecutive MFMAs go to
+// different accumulators
+template <int NTILE>
+__device__ __forceinline__ void mac16r(f32x4 (&out)[NTILE], const BP& b, const f16x8 (&a)[NTILE][NP]) {
+#pragma unroll
+  for (int t0 = 0; t0 < NTILE; t0 += 2) {
+#define PROD(PA, PB)                                                                  \
+  _Pragma("unroll") for (int dt = 0; dt < 2; dt++) if (t0 + dt < NTILE) out[t0 + dt] = \
+      MFMA16(a[t0 + dt][PA], b.p[PB], out[t0 + dt]);
+    PROD(1, 0) PROD(0, 1) PROD(0, 0)
+#undef PROD
+  }
+}
 template <int NTILE, typename F>
 __device__ __forceinline__ void chain(const f32x4 (&in)[NT], f32x4 (&out)[NTILE], const u32x4* __restrict__ w, int lane,
                                       F&& per_step) {
-#pragma unroll
-  for (int s = 0; s < 2; s++) {
+  f16x8 w0[NTILE][NP], w1[NTILE][NP];
+  load_w<NTILE>(w0, w + lane);
+  __builtin_amdgcn_sched_barrier(0);
+  {
     float x[8];
-    step_operand(in, s, x);
+    step_operand(in, 0, x);
     BP b;
     split8(x, b);
-    mac16<NTILE>(out, b, w + s * (NP * 64) + lane);
-    per_step(s, b);
+    load_w<NTILE>(w1, w + (NP * 64) + lane);
+    __builtin_amdgcn_sched_barrier(0);
+    mac16r<NTILE>(out, b, w0);
+    per_step(0, b);
+  }
+  {
+    float x[8];
+    step_operand(in, 1, x);
+    BP b;
+    split8(x, b);
+    mac16r<NTILE>(out, b, w1);
+    per_step(1, b);
   }
 }
 // backward of one layer: dH chain (hands the pieces of dZ to the transposes), then dW[to][ti] += dZ(to) x H(ti)
-// backward of one layer: dH chain (hands the pieces of dZ to the transposes), then dW[to][ti] += dZ(to) x H(ti)
-#if defined(PSDF_F16_PROTO_OCC)
-#define PSDF_DW_COLS 1
-#else
-#define PSDF_DW_COLS NTI
-#endif
-template <int NTO, int NTI>
+template <int NTO, int NTI, bool PAIR>
 __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO], const u32x4* __restrict__ wT, int lane,
-                                          const f16x8 (&id)[2], const f32x4 (&hT)[NTI], f32x4 (&dW)[NT][PSDF_DW_COLS], float (&db)[NT],
+                                          const f16x8 (&id)[2], const f32x4 (&hT)[NTI], f32x4 (&dW)[NT][NTI], Sum<PAIR> (&db)[NT],
                                           const f32x4& rT) {
   AT A[NT];
   chain<NTO>(dz, dh, wT, lane, [&](int s, const BP& b) {
@@ -335,13 +314,8 @@ __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO
   for (int ti = 0; ti < NTI; ti++) {
     BT B;
     split4(hT[ti] * rT, B);      // H of sample 4 g + r carries that sample's dY magnitude (see the header)
-#if defined(PSDF_F16_PROTO_OCC)
-#pragma unroll
-    for (int to = 0; to < NT; to++) dW[(to + ti) & 3][0] = dw_mac(dW[(to + ti) & 3][0], A[to], B);
-#else
 #pragma unroll
     for (int to = 0; to < NT; to++) dW[to][ti] = dw_mac(dW[to][ti], A[to], B);
-#endif
   }
 }
 
@@ -384,7 +358,9 @@ __device__ __forceinline__ void dy_parts(float dy, float& mant, float& pow2) {
 // DOUBLE: the staged inputs are double buffered and serve the whole tile (K0 <= 36: it fits beside the image in 160 KB of
 // LDS).  Otherwise ONE staging buffer per wave: it is read at the top of the tile and refilled at once for the next tile;
 // the feature-lane copy of X that the last layer's dW needs comes from global memory (an L2 hit: the tile was just staged).
-template <int NT0, bool DOUBLE>
+// GLDS: gelu' of the two inner layers waits in LDS (8 KB per wave) between the forward sweep and the backward chain instead of
+// in 32 registers -- own-lane records, no synchronisation; the host picks it whenever 32 KB more fit into the 160 KB
+template <int NT0, bool DOUBLE, bool GLDS>
 __global__ void __launch_bounds__(NWAVES * 64, 1)
     mlp_bwd_split_f16_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
                              const u32x4* __restrict__ img, const uint32_t* __restrict__ absmax, float* __restrict__ dX,
@@ -400,11 +376,6 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   const float* tail = reinterpret_cast<const float*>(lds + OFF_F32);
   const int lane_k = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f16x8 id[2] = {ident_op(0, lane_k), ident_op(1, lane_k)};
-#if defined(PSDF_F16_PROTO_OCC)
-  f32x4 dW1[NT][1], dW2[NT][1], dW3[NT][1];
-#pragma unroll
-  for (int to = 0; to < NT; to++) dW1[to][0] = dW2[to][0] = dW3[to][0] = zero4();
-#else
   f32x4 dW1[NT][NT0], dW2[NT][NT], dW3[NT][NT];
 #pragma unroll
   for (int to = 0; to < NT; to++) {
@@ -413,12 +384,26 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 #pragma unroll
     for (int ti = 0; ti < NT0; ti++) dW1[to][ti] = zero4();
   }
-#endif
-  float db1[NT] = {0.f, 0.f, 0.f, 0.f}, db2[NT] = {0.f, 0.f, 0.f, 0.f}, db3[NT] = {0.f, 0.f, 0.f, 0.f},
-        dw4[NT] = {0.f, 0.f, 0.f, 0.f}, db4 = 0.f;
+  constexpr bool PAIR = NT0 == 3;
+  Sum<PAIR> db1[NT], db2[NT], db3[NT], dw4[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    db1[t].clear(); db2[t].clear(); db3[t].clear(); dw4[t].clear();
+  }
+  float db4 = 0.f;
   const int64_t ntiles = (N + 15) / 16;
-  const int stage_floats = rows4 * 16 + 64;
+  // staging buffer of a tile: 64 rows of 16 samples (rows < rows4 arrive by DMA, the rest are ZERO, written once below: the
+  // layer-0 operand and the feature-lane copy of X are then read without a predicate or an index clamp -- 16 predicated
+  // ds_read_b32 with their own address arithmetic were 110 instructions per tile), then dY (16 values in four copies: the
+  // request writes one value per lane)
+  constexpr int STAGE_ROWS = 64, stage_floats = STAGE_ROWS * 16 + 64, OFF_DY = STAGE_ROWS * 16;
   float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED) + wave * (DOUBLE ? 2 : 1) * stage_floats;
+  for (int i = rows4 * 16 + lane_k; i < STAGE_ROWS * 16; i += 64) {
+    stage[i] = 0.f;
+    if (DOUBLE) stage[stage_floats + i] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // The inputs of the NEXT tile are requested with global_load_lds while this one is computed.  16-byte form (N % 4 == 0):
   // one instruction brings 16 rows x 16 samples (lane = row 16 j + (lane >> 2), samples 4 (lane & 3) .. + 3) to
   // buf[row * 16 + sample]; the rows past the last multiple of 16 and dY come with the 4-byte form (lane = row 4 i + g,
@@ -448,7 +433,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
                                        (__attribute__((address_space(3))) void*)(buf + i * 64), 4, 0, 0);
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + nn),
-                                     (__attribute__((address_space(3))) void*)(buf + rows4 * 16), 4, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(buf + OFF_DY), 4, 0, 0);
   };
   const int64_t tile0 = (int64_t)blockIdx.x * NWAVES + wave, tstride = (int64_t)gridDim.x * NWAVES;
   if (tile0 < ntiles) prefetch(tile0, stage);
@@ -465,52 +450,71 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     const bool live = n < N;
     // ---------------- forward recompute; h1, h2 leave the sweep as fp32 feature-lane tiles
     f32x4 a[NT], g1[NT], b[NT], g2[NT], h1T[NT], h2T[NT];
+    f32x4* gl = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED +
+                                         (size_t)NWAVES * (DOUBLE ? 2 : 1) * stage_floats * 4) + wave * (2 * NT * 64) + lane;
     bias_init<NT>(a, tail, g);
     {
+      f16x8 w00[NT][NP], w01[NT][NP];
+      load_w<NT>(w00, lds + OFF_W0 + lane);
       float xs[2][8];
 #pragma unroll
       for (int s = 0; s < 2; s++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          const int k = 32 * s + 8 * g + j;  // layer 0: natural k order (the image is packed to match)
-          xs[s][j] = k < K0 ? xb[k * 16 + c] : 0.f;
+          const int k = 32 * s + 8 * g + j;  // layer 0: natural k order (the image is packed to match); rows >= K0 are zero
+          xs[s][j] = xb[k * 16 + c];   // (their weights are zero too)
         }
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        BP bx;
-        split8(xs[s], bx);
-        mac16<NT>(a, bx, lds + OFF_W0 + s * (NP * 64) + lane);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      BP bx;
+      split8(xs[0], bx);
+      load_w<NT>(w01, lds + OFF_W0 + (NP * 64) + lane);
+      __builtin_amdgcn_sched_barrier(0);
+      mac16r<NT>(a, bx, w00);
+      split8(xs[1], bx);
+      mac16r<NT>(a, bx, w01);
     }
     // single staging buffer: take the two dY operands now and refill the buffer for the next tile at once
     f32x4 dyT_early = zero4();
     float dy_early = 0.f;
     if (!DOUBLE) {
-      dyT_early = *reinterpret_cast<const f32x4*>(xb + rows4 * 16 + 4 * g);
-      dy_early = xb[rows4 * 16 + c];
+      dyT_early = *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g);
+      dy_early = xb[OFF_DY + c];
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the LDS reads above have returned before the DMA overwrites
       if (tile + tstride < ntiles) prefetch(tile + tstride, stage);
     }
-    act_both<true>(a, g1);  // a = h1
-    bias_init<NT>(b, tail + HID, g);
+    bias_init<NT>(b, tail + HID, g);      // (requested ahead of the activation block: b is dead until the chain)
+    act_both(a, g1);  // a = h1
+    if constexpr (GLDS) {
+#pragma unroll
+      for (int t = 0; t < NT; t++) gl[t * 64] = g1[t];
+    }
     chain<NT>(a, b, lds + OFF_W1, lane, [&](int s, const BP& p) {
       h1T[2 * s] = transpose_f32(p, id[0]);
       h1T[2 * s + 1] = transpose_f32(p, id[1]);
     });
-    act_both<true>(b, g2);  // b = h2
     bias_init<NT>(a, tail + 2 * HID, g);
+    act_both(b, g2);  // b = h2
+    if constexpr (GLDS) {
+#pragma unroll
+      for (int t = 0; t < NT; t++) gl[(NT + t) * 64] = g2[t];
+    }
     chain<NT>(b, a, lds + OFF_W2, lane, [&](int s, const BP& p) {
       h2T[2 * s] = transpose_f32(p, id[0]);
       h2T[2 * s + 1] = transpose_f32(p, id[1]);
     });
-    f32x4 dz[NT];
-    act_both<true>(a, dz);  // a = h3, dz = gelu'(z3) for now
+    f32x4 dz[NT], w4[NT];
+    {
+      const float* wf0 = tail + 3 * HID;
+#pragma unroll
+      for (int t = 0; t < NT; t++) w4[t] = *reinterpret_cast<const f32x4*>(wf0 + 16 * t + 4 * g);
+    }
+    act_both(a, dz);  // a = h3, dz = gelu'(z3) for now
     // ---------------- output layer: dW4 = sum dy h3, db4 = sum dy, dZ3 = w4 dy gelu'(z3); samples past N carry dy = 0,
     // which zeroes every contribution of theirs below
     f32x4 rT;   // 2^(e(n) + kscale) of the samples 4 g + r: what their H / dZ carry into the parameter gradients
     {
-      f32x4 dyT = DOUBLE ? *reinterpret_cast<const f32x4*>(xb + rows4 * 16 + 4 * g) : dyT_early;  // samples 4 g + r
+      f32x4 dyT = DOUBLE ? *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g) : dyT_early;  // samples 4 g + r
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const bool in = n0 + 4 * g + r < N;
@@ -530,42 +534,40 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 #pragma unroll
         for (int u = 0; u < 2; u++) {
           const f32x4 h3T = transpose_f32(p, id[u]);
-          dw4[2 * s + u] += fmaf(h3T[0], dyT[0], fmaf(h3T[1], dyT[1], fmaf(h3T[2], dyT[2], h3T[3] * dyT[3])));
+          dw4[2 * s + u].add(h3T, dyT);
         }
       }
     }
     // the chain of sample n runs on the mantissa of its dY (magnitude in [2^4, 2^5)); dX is multiplied by 2^(e(n) - 4) at the store
     float dy, dy_pow2;
-    dy_parts(live ? (DOUBLE ? xb[rows4 * 16 + c] : dy_early) : 0.f, dy, dy_pow2);
-    const float* wf = tail + 3 * HID;
+    dy_parts(live ? (DOUBLE ? xb[OFF_DY + c] : dy_early) : 0.f, dy, dy_pow2);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wf + 16 * t + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; r++) dz[t][r] *= w4[r] * dy;
+      for (int r = 0; r < 4; r++) dz[t][r] *= w4[t][r] * dy;
     }
     // ---------------- layer 3
     zero_init<NT>(a);
-    layer_bwd<NT, NT>(dz, a, lds + OFF_T2, lane, id, h2T, dW3, db3, rT);  // a = dH2^T
+    layer_bwd<NT, NT, PAIR>(dz, a, lds + OFF_T2, lane, id, h2T, dW3, db3, rT);  // a = dH2^T
 #pragma unroll
-    for (int t = 0; t < NT; t++) a[t] *= g2[t];                       // dZ2^T
+    for (int t = 0; t < NT; t++) a[t] *= GLDS ? gl[(NT + t) * 64] : g2[t];   // dZ2^T
     // ---------------- layer 2 (the prefetch goes out here: late enough that the early part of the tile does not wait on
     // it, early enough for an HBM round trip before the next tile)
     if (DOUBLE && tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats);
     zero_init<NT>(dz);
-    layer_bwd<NT, NT>(a, dz, lds + OFF_T1, lane, id, h1T, dW2, db2, rT);  // dz = dH1^T
+    layer_bwd<NT, NT, PAIR>(a, dz, lds + OFF_T1, lane, id, h1T, dW2, db2, rT);  // dz = dH1^T
 #pragma unroll
-    for (int t = 0; t < NT; t++) dz[t] *= g1[t];                      // dZ1^T
+    for (int t = 0; t < NT; t++) dz[t] *= GLDS ? gl[t * 64] : g1[t];         // dZ1^T
     // ---------------- layer 1: H = X in feature-lane order, straight from the staged rows
     f32x4 xT[NT0], dx[NT0];
 #pragma unroll
     for (int u = 0; u < NT0; u++) {
       const int feat = 16 * u + c;
       xT[u] = zero4();
-      if (feat < K0) {
-        if (DOUBLE) {
-          xT[u] = *reinterpret_cast<const f32x4*>(xb + feat * 16 + 4 * g);
-        } else {   // samples n0 + 4 g + r of feature `feat` (clamped at the end of the batch: their dZ is zero)
+      if (DOUBLE) {
+        xT[u] = *reinterpret_cast<const f32x4*>(xb + feat * 16 + 4 * g);       // (zero rows past K0)
+      } else if (feat < K0) {
+        {   // samples n0 + 4 g + r of feature `feat` (clamped at the end of the batch: their dZ is zero)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             int64_t nn = n0 + 4 * g + r;
@@ -576,15 +578,22 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       }
     }
     zero_init<NT0>(dx);
-    layer_bwd<NT0, NT0>(dz, dx, lds + OFF_T0, lane, id, xT, dW1, db1, rT);  // dx = dX^T
-    if (dX) {
+    layer_bwd<NT0, NT0, PAIR>(dz, dx, lds + OFF_T0, lane, id, xT, dW1, db1, rT);  // dx = dX^T
+    if (dX && live) {
+      // row 16 t + 4 g + r: the lane's base (rows 4 g, sample n) once per tile, then a uniform row offset per store (it was a
+      // 64-bit multiply-add per lane and store); tiles wholly inside K0 need no lane predicate
+      float* p0 = dX + (int64_t)(4 * g) * N + n;
 #pragma unroll
-      for (int t = 0; t < NT0; t++)
+      for (int t = 0; t < NT0; t++) {
+        if (16 * (t + 1) <= K0) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int k = 16 * t + 4 * g + r;
-          if (k < K0 && live) dX[(int64_t)k * N + n] = dx[t][r] * dy_pow2;
+          for (int r = 0; r < 4; r++) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
+        } else if (16 * t < K0) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            if (16 * t + 4 * g + r < K0) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
         }
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -601,11 +610,6 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int row = (16 * to + 4 * g + r) * 64;  // [out][in]
-#if defined(PSDF_F16_PROTO_OCC)
-          G[G_W2 + row + c] += dW2[to][0][r];
-          G[G_W3 + row + c] += dW3[to][0][r];
-          G[G_W1 + row + c] += dW1[to][0][r];
-#else
 #pragma unroll
           for (int ti = 0; ti < NT; ti++) {
             G[G_W2 + row + 16 * ti + c] += dW2[to][ti][r];
@@ -613,11 +617,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
           }
 #pragma unroll
           for (int ti = 0; ti < NT0; ti++) G[G_W1 + row + 16 * ti + c] += dW1[to][ti][r];
-#endif
         }
 #pragma unroll
       for (int t = 0; t < NT; t++) {  // lane (f = c, g) holds the partial of its four samples: add the four groups
-        float v1 = db1[t], v2 = db2[t], v3 = db3[t], v4 = dw4[t];
+        float v1 = db1[t].total(), v2 = db2[t].total(), v3 = db3[t].total(), v4 = dw4[t].total();
         v1 += __shfl_xor(v1, 16, 64); v2 += __shfl_xor(v2, 16, 64); v3 += __shfl_xor(v3, 16, 64); v4 += __shfl_xor(v4, 16, 64);
         v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); v3 += __shfl_xor(v3, 32, 64); v4 += __shfl_xor(v4, 32, 64);
         if (g == 0) {
@@ -772,10 +775,12 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
   if (K0 < 1 || K0 > 64) return PSDF_ERR_UNSUPPORTED;
   const int rows4 = (K0 + 3) & ~3;
   const int nt0 = K0 <= 48 ? 3 : 4;
-  const size_t stage_bytes = (size_t)NWAVES * (rows4 * 16 + 64) * 4;
+  const size_t stage_bytes = (size_t)NWAVES * (64 * 16 + 64) * 4;
   const size_t img_bytes = img_aligned(nt0);
-  const size_t lds_bytes = img_bytes + 2 * stage_bytes;          // always double buffered: the image is 95 KB
-  if (lds_bytes > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
+  const size_t g_bytes = (size_t)NWAVES * 2 * NT * 64 * 16;
+  if (img_bytes + 2 * stage_bytes > 160 * 1024) return PSDF_ERR_UNSUPPORTED;   // always double buffered: the image is 95 KB
+  const bool glds = img_bytes + 2 * stage_bytes + g_bytes <= 160 * 1024;
+  const size_t lds_bytes = img_bytes + 2 * stage_bytes + (glds ? g_bytes : 0);
   if (N <= 0 || !X || !weights || !biases || !dY) return PSDF_ERR_ARG;
   for (int l = 0; l < 4; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
@@ -793,9 +798,9 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
 #define PACK(NT0_)                                                                                                         \
   hipLaunchKernelGGL(mlp_split_pack_kernel<NT0_>, dim3((pack_threads + 255) / 256), dim3(256), 0, st, K0, weights[0],        \
                      weights[1], weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], rec, absmax)
-#define MAIN(NT0_)                                                                                                          \
+#define MAIN(NT0_, GLDS_)                                                                                                   \
   do {                                                                                                                      \
-    auto kern = mlp_bwd_split_f16_kernel<NT0_, true>;                                                                        \
+    auto kern = mlp_bwd_split_f16_kernel<NT0_, true, GLDS_>;                                                                 \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);       \
     if (e != hipSuccess) return (int)e;                                                                                     \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,                  \
@@ -807,7 +812,8 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
     ab = ab < 1 ? 1 : (ab > 512 ? 512 : ab);
     hipLaunchKernelGGL(mlp_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, N, dY, absmax);
   }
-  if (nt0 == 3) MAIN(3); else MAIN(4);
+  if (nt0 == 3) { if (glds) MAIN(3, true); else MAIN(3, false); }
+  else { if (glds) MAIN(4, true); else MAIN(4, false); }
 #undef PACK
 #undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256, 16), dim3(256), 0, st, partial, absmax, (int)blocks, K0,
