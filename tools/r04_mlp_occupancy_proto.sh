@@ -3,6 +3,8 @@
 # with -DPSDF_F16_PROTO_OCC (eight waves per workgroup, four dW accumulators per layer and wave: WRONG sums, the same MFMA / VALU
 # instruction mix, none of the LDS exchange the real design needs) and times the bench step's MLP backward with it.
 # A measurement build: the library it produces is never shipped (lib/variants/ is git-ignored).
+# The -DPSDF_F16_PROTO_OCC switch lived in csrc/mlp_bwd_split_f16.hip up to commit 2b8b417 (it left with the rewrite of the
+# kernel's instruction stream in the second half of round 4): check that commit out to repeat the measurement.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R/permuto_sdf_amd
 F="-O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wno-unused-result --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1"
 mkdir -p lib/variants
