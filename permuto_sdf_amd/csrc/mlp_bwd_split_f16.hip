@@ -65,8 +65,8 @@ constexpr int G_W1 = 0, G_W2 = 4096, G_W3 = 8192, G_B1 = 12288, G_B2 = 12352, G_
 //   gelu = z cdf, gelu' = cdf + z E / sqrt(2 pi).  Error against float64: gelu 1.8e-7 |z| (the fp32 formula
 //   0.5 z (1 + erf(z / sqrt 2)) itself: 1.1e-7 |z|), gelu' 1.9e-7.  (An erf-based and a pure-polynomial evaluator were measured
 //   beside it in round 2 -- 1.47 ms against 1.37 ms, profiles/r02_mlp_bwd_prototype_timings.txt -- and are gone.)
-// Written for TWO PAIRS at a time in packed fp32 arithmetic, same operations in the same order as the forward kernel's scalar
-// form (mlp.hip; bit-identical activations): gelu_rational4 below.
+// Written for TWO PAIRS at a time in packed fp32 arithmetic: gelu_rational4 below.  (The forward kernels evaluate the same
+// fit as max(z, 0) - |z| Phi(-|z|), mlp_device.h: equal up to the last bit or two of an fp32 evaluation.)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
