@@ -355,17 +355,18 @@ __device__ __forceinline__ void dy_parts(float dy, float& mant, float& pow2) {
 // X [K0, N], dY [1, N], dX [K0, N] (optional) feature-major; img = the LDS image (mlp_split_pack_kernel); partial
 // [gridDim.x][G_TOTAL] receives this workgroup's gradient image (of dY * 2^k: mlp_split_reduce_kernel takes the factor out
 // again).  rows4 = K0 rounded up to a multiple of 4.
-// DOUBLE: the staged inputs are double buffered and serve the whole tile (K0 <= 36: it fits beside the image in 160 KB of
-// LDS).  Otherwise ONE staging buffer per wave: it is read at the top of the tile and refilled at once for the next tile;
-// the feature-lane copy of X that the last layer's dW needs comes from global memory (an L2 hit: the tile was just staged).
-// GLDS: gelu' of the two inner layers waits in LDS (8 KB per wave) between the forward sweep and the backward chain instead of
-// in 32 registers -- own-lane records, no synchronisation; the host picks it whenever 32 KB more fit into the 160 KB
-template <int NT0, bool DOUBLE, bool GLDS>
+// The staged inputs are double buffered (two buffers per wave beside the image: 130 KB of LDS for K0 <= 48, 134 KB beyond; the
+// single-buffer form of round 3 went with the image that needed it).
+// GLDS (the three-tile instantiation, K0 <= 48): gelu' of the two inner layers waits in LDS (8 KB per wave) between the forward
+// sweep and the backward chain instead of in 32 registers -- own-lane records, no synchronisation; with four input tiles the
+// 32 KB do not fit beside the larger image (167 KB) and the values stay in registers
+template <int NT0>
 __global__ void __launch_bounds__(NWAVES * 64, 1)
     mlp_bwd_split_f16_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
                              const u32x4* __restrict__ img, const uint32_t* __restrict__ absmax, float* __restrict__ dX,
                              float* __restrict__ partial) {
   extern __shared__ __align__(16) u32x4 lds[];
+  constexpr bool GLDS = NT0 == 3;
   float sc, isc;
   const int kscale = dy_scale(absmax[0], sc, isc);      // 2^kscale * max|dY| in [2^4, 2^5)
   constexpr size_t IMG_ALIGNED = img_aligned(NT0);
@@ -397,10 +398,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   // ds_read_b32 with their own address arithmetic were 110 instructions per tile), then dY (16 values in four copies: the
   // request writes one value per lane)
   constexpr int STAGE_ROWS = 64, stage_floats = STAGE_ROWS * 16 + 64, OFF_DY = STAGE_ROWS * 16;
-  float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED) + wave * (DOUBLE ? 2 : 1) * stage_floats;
+  float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED) + wave * 2 * stage_floats;
   for (int i = rows4 * 16 + lane_k; i < STAGE_ROWS * 16; i += 64) {
     stage[i] = 0.f;
-    if (DOUBLE) stage[stage_floats + i] = 0.f;
+    stage[stage_floats + i] = 0.f;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   int cur = 0;
   for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // LDS-DMA completion is not tracked by the compiler
-    const float* xb = stage + (DOUBLE ? cur : 0) * stage_floats;
+    const float* xb = stage + cur * stage_floats;
     // loop-invariant lane arithmetic (addresses, masks) is cheap to redo and expensive to keep: hoisted out of the loop it
     // ends up in scratch, and every scratch reload waits (vmcnt) for the LDS-DMA prefetch in flight
     int lane_l = lane_k;
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     // ---------------- forward recompute; h1, h2 leave the sweep as fp32 feature-lane tiles
     f32x4 a[NT], g1[NT], b[NT], g2[NT], h1T[NT], h2T[NT];
     f32x4* gl = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED +
-                                         (size_t)NWAVES * (DOUBLE ? 2 : 1) * stage_floats * 4) + wave * (2 * NT * 64) + lane;
+                                         (size_t)NWAVES * 2 * stage_floats * 4) + wave * (2 * NT * 64) + lane;
     bias_init<NT>(a, tail, g);
     {
       f16x8 w00[NT][NP], w01[NT][NP];
@@ -472,16 +473,6 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       mac16r<NT>(a, bx, w00);
       split8(xs[1], bx);
       mac16r<NT>(a, bx, w01);
-    }
-    // single staging buffer: take the two dY operands now and refill the buffer for the next tile at once
-    f32x4 dyT_early = zero4();
-    float dy_early = 0.f;
-    if (!DOUBLE) {
-      dyT_early = *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g);
-      dy_early = xb[OFF_DY + c];
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the LDS reads above have returned before the DMA overwrites
-      if (tile + tstride < ntiles) prefetch(tile + tstride, stage);
     }
     bias_init<NT>(b, tail + HID, g);      // (requested ahead of the activation block: b is dead until the chain)
     act_both(a, g1);  // a = h1
@@ -514,7 +505,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     // which zeroes every contribution of theirs below
     f32x4 rT;   // 2^(e(n) + kscale) of the samples 4 g + r: what their H / dZ carry into the parameter gradients
     {
-      f32x4 dyT = DOUBLE ? *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g) : dyT_early;  // samples 4 g + r
+      f32x4 dyT = *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g);  // samples 4 g + r
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const bool in = n0 + 4 * g + r < N;
@@ -540,7 +531,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     }
     // the chain of sample n runs on the mantissa of its dY (magnitude in [2^4, 2^5)); dX is multiplied by 2^(e(n) - 4) at the store
     float dy, dy_pow2;
-    dy_parts(live ? (DOUBLE ? xb[OFF_DY + c] : dy_early) : 0.f, dy, dy_pow2);
+    dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
 #pragma unroll
@@ -553,7 +544,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     for (int t = 0; t < NT; t++) a[t] *= GLDS ? gl[(NT + t) * 64] : g2[t];   // dZ2^T
     // ---------------- layer 2 (the prefetch goes out here: late enough that the early part of the tile does not wait on
     // it, early enough for an HBM round trip before the next tile)
-    if (DOUBLE && tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats);
+    if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats);
     zero_init<NT>(dz);
     layer_bwd<NT, NT, PAIR>(a, dz, lds + OFF_T1, lane, id, h1T, dW2, db2, rT);  // dz = dH1^T
 #pragma unroll
@@ -563,19 +554,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 #pragma unroll
     for (int u = 0; u < NT0; u++) {
       const int feat = 16 * u + c;
-      xT[u] = zero4();
-      if (DOUBLE) {
-        xT[u] = *reinterpret_cast<const f32x4*>(xb + feat * 16 + 4 * g);       // (zero rows past K0)
-      } else if (feat < K0) {
-        {   // samples n0 + 4 g + r of feature `feat` (clamped at the end of the batch: their dZ is zero)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            int64_t nn = n0 + 4 * g + r;
-            nn = nn < N ? nn : N - 1;
-            xT[u][r] = X[(int64_t)feat * N + nn];
-          }
-        }
-      }
+      xT[u] = *reinterpret_cast<const f32x4*>(xb + feat * 16 + 4 * g);       // (zero rows past K0)
     }
     zero_init<NT0>(dx);
     layer_bwd<NT0, NT0, PAIR>(dz, dx, lds + OFF_T0, lane, id, xT, dW1, db1, rT);  // dx = dX^T
@@ -777,10 +756,9 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
   const int nt0 = K0 <= 48 ? 3 : 4;
   const size_t stage_bytes = (size_t)NWAVES * (64 * 16 + 64) * 4;
   const size_t img_bytes = img_aligned(nt0);
-  const size_t g_bytes = (size_t)NWAVES * 2 * NT * 64 * 16;
-  if (img_bytes + 2 * stage_bytes > 160 * 1024) return PSDF_ERR_UNSUPPORTED;   // always double buffered: the image is 95 KB
-  const bool glds = img_bytes + 2 * stage_bytes + g_bytes <= 160 * 1024;
-  const size_t lds_bytes = img_bytes + 2 * stage_bytes + (glds ? g_bytes : 0);
+  const size_t g_bytes = nt0 == 3 ? (size_t)NWAVES * 2 * NT * 64 * 16 : 0;     // gelu' of the inner layers (see GLDS)
+  const size_t lds_bytes = img_bytes + 2 * stage_bytes + g_bytes;              // 159.0 KB (K0 <= 48) / 131.0 KB
+  if (lds_bytes > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
   if (N <= 0 || !X || !weights || !biases || !dY) return PSDF_ERR_ARG;
   for (int l = 0; l < 4; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
@@ -798,9 +776,9 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
 #define PACK(NT0_)                                                                                                         \
   hipLaunchKernelGGL(mlp_split_pack_kernel<NT0_>, dim3((pack_threads + 255) / 256), dim3(256), 0, st, K0, weights[0],        \
                      weights[1], weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], rec, absmax)
-#define MAIN(NT0_, GLDS_)                                                                                                   \
+#define MAIN(NT0_)                                                                                                          \
   do {                                                                                                                      \
-    auto kern = mlp_bwd_split_f16_kernel<NT0_, true, GLDS_>;                                                                 \
+    auto kern = mlp_bwd_split_f16_kernel<NT0_>;                                                                              \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);       \
     if (e != hipSuccess) return (int)e;                                                                                     \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,                  \
@@ -812,8 +790,7 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
     ab = ab < 1 ? 1 : (ab > 512 ? 512 : ab);
     hipLaunchKernelGGL(mlp_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, N, dY, absmax);
   }
-  if (nt0 == 3) { if (glds) MAIN(3, true); else MAIN(3, false); }
-  else { if (glds) MAIN(4, true); else MAIN(4, false); }
+  if (nt0 == 3) MAIN(3); else MAIN(4);
 #undef PACK
 #undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256, 16), dim3(256), 0, st, partial, absmax, (int)blocks, K0,

@@ -12,7 +12,7 @@ mlp_bwd_split_f16_kernel before they went to the GPU: it reproduced the measured
 as 16 000 = the plain SUM of VALU, MFMA and wait times (one wave overlaps nothing), over-estimated what requesting weights
 earlier would buy (-9 % predicted, -1.6 % measured) and was right about the direction of every instruction-count change.
 
-    python tools/isa_loop_model.py permuto_sdf_amd/lib/obj/mlp_bwd_split_f16.o mlp_bwd_split_f16_kernelILi3ELb1ELb1E [-p] [-r]
+    python tools/isa_loop_model.py permuto_sdf_amd/lib/obj/mlp_bwd_split_f16.o mlp_bwd_split_f16_kernelILi3E [-p] [-r]
       -p  print the class string      -r  model cycles per 60-instruction region
 The loop = the longest backward branch of the kernel.  Branches are taken as fall-through (not-taken paths are counted)."""
 import collections
