@@ -202,13 +202,16 @@ __device__ __forceinline__ void transpose_pieces(const BP& b, f16x8 id, AT& out,
 // its hazard bookkeeping -- an MFMA written in asm is invisible to it, see split2).  Left to the register allocator, a changing
 // subset of the accumulators was parked in AGPRs and moved to VGPRs and back around its pair (v_accvgpr_read x 4, two MFMAs,
 // v_accvgpr_write x 4: 100 - 230 moves per tile, depending on the build).
+template <bool PIN = true>
 __device__ __forceinline__ f32x4 dw_mac(f32x4 acc, const AT& A, const BT& B) {
-  asm("" : "+a"(acc));
+  if constexpr (PIN) asm("" : "+a"(acc));
   acc = MFMA16(A.t01, B.t11, acc);   // smallest first
   acc = MFMA16(A.t01, B.t00, acc);
-  asm("" : "+a"(acc));
+  if constexpr (PIN) asm("" : "+a"(acc));
   return acc;
 }
+// (PIN = false: the wave-pair kernel below.  A kernel whose budget is 256 registers gets 128 + 128 as soon as anything in it asks
+// for an accumulation register; without such a request the whole budget is VGPRs and the MFMAs use their VGPR form throughout.)
 template <int NTILE>
 __device__ __forceinline__ void bias_init(f32x4 (&acc)[NTILE], const float* __restrict__ b, int g) {
 #pragma unroll
@@ -620,6 +623,493 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   for (int e = threadIdx.x; e < G_TOTAL; e += NWAVES * 64) dst[e] = G[e];
 }
 
+// ====================================================================================== wave-pair form (round 5)
+// The kernel above needs the whole register file of a SIMD for ONE wave (176 dW accumulators), and one in-order wave overlaps
+// nothing: its VALU issue (7 200 cycles per tile), its MFMAs (4 400) and its waits (2 600) simply add up.  Here the NET is cut in
+// two instead of the work list: the two waves of a PAIR own the output-neuron tiles {0, 1} and {2, 3} of every layer -- of the
+// forward recompute, of the dH chain, of the activation derivatives, of the bias sums -- and half of every dW (88 accumulators
+// each: dW3 / dW2 by input-neuron tiles, dW1 by output-neuron tiles), so that a wave fits 256 registers and TWO waves share a SIMD.
+// What a wave lacks for a 64-deep product is its partner's k-step (two tiles = one 32-deep MFMA step): every chain layer
+// hands its operand pieces over through a 2-KB LDS slot (lane-linear 16-byte records: the partner's lane needs exactly what the
+// same lane of the owner holds), five hand-overs per tile (h1, h2, dZ3, dZ2, dZ1), two alternating slots per pair, one flag word
+// per wave (a post counter; LDS executes a wave's DS instructions in order, so the data are in place when the counter is).  The
+// dZ-side dW operands of the partner's tiles are transposed again locally from the pieces that arrive anyway (4 MFMAs per layer:
+// cheaper than a sixth and seventh hand-over); layer 0 splits all of X on both waves (24 instructions).  Partners sit on
+// DIFFERENT SIMDs (waves 2p, 2p+1); the two waves of one SIMD belong to different pairs and drift freely against each other,
+// which is where the VALU of one meets the MFMAs and the waits of the other.  The staged inputs (one double buffer per pair) are
+// requested half by each wave; the "dZ1" post of a tile doubles as "my share of the next tile's inputs has landed".
+// LDS: image 93 KB + 4 x 8.5 KB staging + 4 x 8 KB slots = 159.1 KB (three input tiles only: K0 <= 48).
+constexpr int PAIR_WAVES = 8;
+// weight records of a chain layer: requested right before their MFMAs (W_LATE) or a step ahead (W_EARLY: + 16 registers)
+#ifdef PSDF_PAIR_WPF
+#define W_EARLY(x) x
+#define W_LATE(x)
+#else
+#define W_EARLY(x)
+#define W_LATE(x) x
+#endif
+#ifndef PSDF_PAIR_SUM_PAIR
+#define PSDF_PAIR_SUM_PAIR false
+#endif
+constexpr int XCH_SLOT = 2 * NP * 64, XCH_PAIR = 2 * XCH_SLOT;     // records: [slot 2][half 2][piece 2][lane 64]
+
+template <int NTILE>
+__device__ __forceinline__ void act_both_n(f32x4 (&acc)[NTILE], f32x4 (&gp)[NTILE]) {
+#pragma unroll
+  for (int t = 0; t < NTILE; t++) {
+    f32x2 ha, hb, ga, gb;
+    gelu_rational4(f32x2{acc[t][0], acc[t][1]}, f32x2{acc[t][2], acc[t][3]}, ha, hb, ga, gb);
+    acc[t] = f32x4{ha.x, ha.y, hb.x, hb.y};
+    gp[t] = f32x4{ga.x, ga.y, gb.x, gb.y};
+  }
+}
+// the wave's own k-step: its two tiles in the k order of step_operand
+__device__ __forceinline__ void own_operand(const f32x4 (&act)[2], float (&x)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    x[j] = act[0][j];
+    x[4 + j] = act[1][j];
+  }
+}
+// dZ-side dW operand of a tile whose bias sum belongs to the partner
+__device__ __forceinline__ void transpose_pieces_nosum(const BP& b, f16x8 id, AT& out) {
+  uint32_t q[NP][2];
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const f32x4 o = MFMA16(b.p[p], id, zero4());
+    q[p][0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o[0], o[1]));
+    q[p][1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o[2], o[3]));
+  }
+  out.t01 = halves(q[0][0], q[0][1], q[1][0], q[1][1]);
+}
+typedef __attribute__((address_space(3))) volatile uint32_t lds_flag_t;
+struct Link {
+  u32x4* mine;                  // slot 0, this wave's half, this lane
+  int their_delta;              // the partner's half of a slot, relative to `mine` (records)
+  lds_flag_t* my_flag;          // (explicit LDS pointers: a volatile access through a generic pointer stays a flat_ instruction)
+  lds_flag_t* their_flag;
+  uint32_t seq;                 // posts so far (both waves of a pair post in the same order)
+  int slot;
+  __device__ __forceinline__ void post(const BP& b) {
+    u32x4* d = mine + slot * XCH_SLOT;
+    d[0] = __builtin_bit_cast(u32x4, b.p[0]);
+    d[64] = __builtin_bit_cast(u32x4, b.p[1]);
+    asm volatile("" ::: "memory");
+    seq++;
+    *my_flag = seq;             // behind the records in the wave's DS queue
+    asm volatile("" ::: "memory");
+  }
+  __device__ __forceinline__ void take(BP& b) {
+    // (bounded: a partner that never posts -- a bug -- must end in wrong numbers that a test sees, not in a hung device)
+#pragma unroll 1
+    for (int spin = 0; spin < (1 << 24); spin++) {
+      const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)*their_flag);
+      if ((int32_t)(v - seq) >= 0) break;
+#ifndef PSDF_PAIR_NOSLEEP
+      __builtin_amdgcn_s_sleep(1);
+#endif
+    }
+    asm volatile("" ::: "memory");
+    const u32x4* s = mine + their_delta + slot * XCH_SLOT;
+    b.p[0] = __builtin_bit_cast(f16x8, s[0]);
+    b.p[1] = __builtin_bit_cast(f16x8, s[64]);
+    slot ^= 1;
+  }
+};
+// One chain layer of a pair is three steps: post_own (split the own two tiles, hand the pieces to the partner), mac_step with the
+// own pieces, take + mac_step with the partner's.  Everything that does not feed the NEXT post (transposes of the partner's
+// pieces, the dW products of the layer, the dW4 sums) is issued AFTER that post: a wave is then 25 - 40 MFMAs away from its next
+// take when it posts, and a partner that runs a few hundred cycles behind costs nothing (the first build took straight after its
+// own step and waited 1 000 cycles per hand-over, profiles/r05_mlp_pair_ab.txt).
+__device__ __forceinline__ void post_own(const f32x4 (&in)[2], BP& b, Link& lk) {
+  float x[8];
+  own_operand(in, x);
+  split8(x, b);
+  lk.post(b);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// out += W[tiles][one k-step] x pieces; w = records of the wave's first output tile, that k-step, this lane
+template <int NTILE>
+__device__ __forceinline__ void mac_step(f32x4 (&out)[NTILE], const BP& b, const u32x4* __restrict__ w) {
+  f16x8 a[NTILE][NP];
+  load_w<NTILE>(a, w);
+  mac16r<NTILE>(out, b, a);
+}
+
+template <int NT0>
+__global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
+    mlp_bwd_split_f16_pair_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
+                                  const u32x4* __restrict__ img, const uint32_t* __restrict__ absmax, float* __restrict__ dX,
+                                  float* __restrict__ partial) {
+  static_assert(NT0 == 3, "the pair form holds three input tiles (K0 <= 48)");
+  extern __shared__ __align__(16) u32x4 lds[];
+  float sc, isc;
+  const int kscale = dy_scale((uint32_t)__builtin_amdgcn_readfirstlane((int)absmax[0]), sc, isc);   // (uniform: scalar registers)
+  constexpr size_t IMG_ALIGNED = img_aligned(NT0);
+  constexpr int OFF_F32 = off_f32(NT0);
+  constexpr int NREC = (int)(IMG_ALIGNED / 16);
+  for (int i = threadIdx.x; i < NREC; i += PAIR_WAVES * 64) lds[i] = img[i];
+  const float* tail = reinterpret_cast<const float*>(lds + OFF_F32);
+  const int lane_k = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wave >> 1, half = wave & 1;
+  const f16x8 id[2] = {ident_op(0, lane_k), ident_op(1, lane_k)};
+  // dW3 / dW2 [dZ tile: own 0, own 1, partner's 0, partner's 1][own H tile]; dW1 [own dZ tile][X tile]
+  f32x4 dW3[NT][2], dW2[NT][2], dW1[2][NT0];
+#pragma unroll
+  for (int to = 0; to < NT; to++)
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++) dW2[to][ti] = dW3[to][ti] = zero4();
+#pragma unroll
+  for (int to = 0; to < 2; to++)
+#pragma unroll
+    for (int ti = 0; ti < NT0; ti++) dW1[to][ti] = zero4();
+  Sum<PSDF_PAIR_SUM_PAIR> db1[2], db2[2], db3[2], dw4[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    db1[t].clear(); db2[t].clear(); db3[t].clear(); dw4[t].clear();
+  }
+  float db4 = 0.f;
+  const int64_t ntiles = (N + 15) / 16;
+  constexpr int STAGE_ROWS = 64, stage_floats = STAGE_ROWS * 16 + 64, OFF_DY = STAGE_ROWS * 16;
+  constexpr int NPAIR = PAIR_WAVES / 2;
+  char* dyn = reinterpret_cast<char*>(lds) + IMG_ALIGNED;
+  float* stage = reinterpret_cast<float*>(dyn) + pair * 2 * stage_floats;
+  u32x4* xch = reinterpret_cast<u32x4*>(dyn + (size_t)NPAIR * 2 * stage_floats * 4) + pair * XCH_PAIR;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(dyn + (size_t)NPAIR * 2 * stage_floats * 4 + (size_t)NPAIR * XCH_PAIR * 16);
+  if (threadIdx.x < PAIR_WAVES) flags[threadIdx.x] = 0u;
+  for (int i = rows4 * 16 + lane_k + 64 * half; i < STAGE_ROWS * 16; i += 128) {
+    stage[i] = 0.f;
+    stage[stage_floats + i] = 0.f;
+  }
+  const bool wide_dma = (N & 3) == 0 && N >= 4;
+  // the requests of a tile are dealt out to the two waves alternately; dY goes with the second
+  auto prefetch = [&](int64_t t, float* buf, int lane_k) {    // (the lane is passed in: hoisted lane arithmetic ends up in scratch)
+    const int c = lane_k & 15, g = lane_k >> 4;
+    int64_t nn = t * 16 + c;
+    nn = nn < N ? nn : N - 1;
+    int i0 = 0;
+    if (wide_dma) {
+      int64_t n4 = t * 16 + 4 * (lane_k & 3);
+      n4 = n4 + 3 < N ? n4 : N - 4;
+      const int n16 = rows4 >> 4;
+      for (int j = half; j < n16; j += 2) {
+        const int k = 16 * j + (lane_k >> 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)(k < K0 ? k : K0 - 1) * N + n4),
+                                         (__attribute__((address_space(3))) void*)(buf + j * 256), 16, 0, 0);
+      }
+      i0 = n16 * 4;
+    }
+    for (int i = i0 + half; i < (rows4 >> 2); i += 2) {
+      int k = 4 * i + g;
+      k = k < K0 ? k : K0 - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)k * N + nn),
+                                       (__attribute__((address_space(3))) void*)(buf + i * 64), 4, 0, 0);
+    }
+    if (half)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + nn),
+                                       (__attribute__((address_space(3))) void*)(buf + OFF_DY), 4, 0, 0);
+  };
+  const int64_t tile0 = (int64_t)blockIdx.x * NPAIR + pair, tstride = (int64_t)gridDim.x * NPAIR;
+  if (tile0 < ntiles) prefetch(tile0, stage, lane_k);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();               // image, zero rows, flag words, the first tile's inputs
+  Link lk;
+  lk.mine = xch + half * (NP * 64) + lane_k;
+  lk.their_delta = half ? -(NP * 64) : (NP * 64);
+  lk.my_flag = (lds_flag_t*)(flags + wave);
+  lk.their_flag = (lds_flag_t*)(flags + (wave ^ 1));
+  lk.seq = 0u;
+  lk.slot = 0;
+  const int tile_rec = 2 * NP * 64;          // records per tile of a layer image
+  int cur = 0;
+  for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
+    const float* xb = stage + cur * stage_floats;
+    int lane_l = lane_k;
+    asm volatile("" : "+v"(lane_l));
+    const int lane = lane_l, c = lane & 15, g = lane >> 4;
+    const int64_t n0 = tile * 16, n = n0 + c;
+    const bool live = n < N;
+    const int own0 = 2 * half;               // the wave's first tile of every hidden layer
+    // ---------------- forward recompute of the own tiles
+    f32x4 a[2], g1[2], b[2], g2[2], h1T[2], h2T[2];
+    const int own_step = half * (NP * 64), oth_step = (half ^ 1) * (NP * 64);
+    bias_init<2>(a, tail + 16 * own0, g);
+    {
+      f16x8 w00[2][NP], w01[2][NP];
+      const u32x4* w0 = lds + OFF_W0 + own0 * tile_rec + lane;
+      load_w<2>(w00, w0);
+      float xs[2][8];
+#pragma unroll
+      for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) xs[s][j] = xb[(32 * s + 8 * g + j) * 16 + c];
+      __builtin_amdgcn_sched_barrier(0);
+      BP bx;
+      split8(xs[0], bx);
+      load_w<2>(w01, w0 + NP * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      mac16r<2>(a, bx, w00);
+      split8(xs[1], bx);
+      mac16r<2>(a, bx, w01);
+    }
+    // per-sample factors of the tile (samples 4 g + r): rT = 2^(e(n) + kscale) of what H / dZ carry into the parameter
+    // gradients, dyT = dY 2^kscale for dW4 / db4; branch-free
+    f32x4 rT, dyT = *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bool in = n0 + 4 * g + r < N;
+      const int ex = (int)(__float_as_uint(dyT[r]) >> 23) & 255;
+      int er = ex + kscale - CHAIN_EXP + H_PRESCALE_EXP;
+      er = er < 1 ? 0 : (er > 254 ? 254 : er);
+      uint32_t bits = (uint32_t)er << 23;
+      bits = ex > CHAIN_EXP ? bits : 0u;
+      bits = ex == 255 ? 0x3F800000u : bits;
+      rT[r] = __uint_as_float(in ? bits : 0u);
+      dyT[r] = in ? dyT[r] * sc : 0.f;
+    }
+    float dy, dy_pow2;
+    dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
+    bias_init<2>(b, tail + HID + 16 * own0, g);
+    act_both_n<2>(a, g1);  // a = h1 (own tiles)
+    {
+      BP po, pp;
+      const u32x4* w = lds + OFF_W1 + own0 * tile_rec + lane;
+      f16x8 wo[2][NP], wp[2][NP];
+      W_EARLY(load_w<2>(wo, w + own_step));
+      post_own(a, po, lk);
+      W_EARLY(load_w<2>(wp, w + oth_step));
+      W_LATE(load_w<2>(wo, w + own_step));
+      mac16r<2>(b, po, wo);
+      h1T[0] = transpose_f32(po, id[0]);
+      h1T[1] = transpose_f32(po, id[1]);
+      W_LATE(load_w<2>(wp, w + oth_step));
+      lk.take(pp);
+#ifndef PSDF_PAIR_LATE_PREFETCH
+      // the partner has posted h1 of THIS tile, so it is done reading the other staging buffer: the next tile's inputs are
+      // requested here, most of a tile ahead of the s_waitcnt that covers them (an HBM round trip under load is longer than a layer)
+      if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats, lane);
+#endif
+      mac16r<2>(b, pp, wp);
+    }
+    bias_init<2>(a, tail + 2 * HID + 16 * own0, g);
+    act_both_n<2>(b, g2);  // b = h2
+    {
+      BP po, pp;
+      const u32x4* w = lds + OFF_W2 + own0 * tile_rec + lane;
+      f16x8 wo[2][NP], wp[2][NP];
+      W_EARLY(load_w<2>(wo, w + own_step));
+      post_own(b, po, lk);
+      W_EARLY(load_w<2>(wp, w + oth_step));
+      W_LATE(load_w<2>(wo, w + own_step));
+      mac16r<2>(a, po, wo);
+      h2T[0] = transpose_f32(po, id[0]);
+      h2T[1] = transpose_f32(po, id[1]);
+      W_LATE(load_w<2>(wp, w + oth_step));
+      lk.take(pp);
+      mac16r<2>(a, pp, wp);
+    }
+    f32x4 dz[2];
+    act_both_n<2>(a, dz);  // a = h3, dz = gelu'(z3)
+    // ---------------- output layer: dZ3 = w4 dy gelu'(z3) on the mantissa of dY (dX is multiplied by 2^(e(n) - 4) at the store)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(tail + 3 * HID + 16 * (own0 + t) + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; r++) dz[t][r] *= w4[r] * dy;
+    }
+    // ---------------- layer 3
+    AT Ao[2], Ap[2];
+    BP pp3;
+    {
+      BP po;
+      const u32x4* w = lds + OFF_T2 + own0 * tile_rec + lane;
+      f16x8 wo[2][NP], wp[2][NP];
+      W_EARLY(load_w<2>(wo, w + own_step));
+      post_own(dz, po, lk);
+      // (behind the post) dW4 = sum dy h3 on the own tiles, db4 on the first wave of the pair
+      if (half == 0) db4 += (dyT[0] + dyT[1]) + (dyT[2] + dyT[3]);
+      {
+        float x[8];
+        own_operand(a, x);
+        BP p;
+        split8(x, p);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const f32x4 h3T = transpose_f32(p, id[u]);
+          dw4[u].add(h3T, dyT);
+        }
+      }
+      zero_init<2>(a);
+      W_EARLY(load_w<2>(wp, w + oth_step));
+      W_LATE(load_w<2>(wo, w + own_step));
+      mac16r<2>(a, po, wo);
+      transpose_pieces(po, id[0], Ao[0], db3[0], rT);
+      transpose_pieces(po, id[1], Ao[1], db3[1], rT);
+      W_LATE(load_w<2>(wp, w + oth_step));
+      lk.take(pp3);
+      mac16r<2>(a, pp3, wp);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) a[t] *= g2[t];   // dZ2 (own tiles)
+    // ---------------- layer 2
+    BP pp2;
+    {
+      BP po;
+      const u32x4* w = lds + OFF_T1 + own0 * tile_rec + lane;
+      f16x8 wo[2][NP], wp[2][NP];
+      W_EARLY(load_w<2>(wo, w + own_step));
+      post_own(a, po, lk);
+#ifdef PSDF_PAIR_LATE_PREFETCH
+      if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats, lane);
+#endif
+      // (behind the post) the rest of layer 3: the partner's dZ3 tiles transposed, dW3 += dZ3^T (H2 of the own tiles)
+      transpose_pieces_nosum(pp3, id[0], Ap[0]);
+      transpose_pieces_nosum(pp3, id[1], Ap[1]);
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++) {
+        BT B;
+        split4(h2T[ti] * rT, B);
+        dW3[0][ti] = dw_mac<false>(dW3[0][ti], Ao[0], B);
+        dW3[1][ti] = dw_mac<false>(dW3[1][ti], Ao[1], B);
+        dW3[2][ti] = dw_mac<false>(dW3[2][ti], Ap[0], B);
+        dW3[3][ti] = dw_mac<false>(dW3[3][ti], Ap[1], B);
+      }
+      zero_init<2>(dz);
+      W_EARLY(load_w<2>(wp, w + oth_step));
+      W_LATE(load_w<2>(wo, w + own_step));
+      mac16r<2>(dz, po, wo);
+      transpose_pieces(po, id[0], Ao[0], db2[0], rT);
+      transpose_pieces(po, id[1], Ao[1], db2[1], rT);
+      W_LATE(load_w<2>(wp, w + oth_step));
+      lk.take(pp2);
+      mac16r<2>(dz, pp2, wp);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++) dz[t] *= g1[t];   // dZ1 (own tiles)
+    // ---------------- layer 1: dW1 rows of the own dZ1 tiles against all of X; dX tiles {0, 1} on the first wave, {2} on the second
+    {
+      BP po, pp;
+      // this wave's requests for the next tile must have landed before its post says so (see the header)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      post_own(dz, po, lk);
+      // (behind the post) the rest of layer 2
+      transpose_pieces_nosum(pp2, id[0], Ap[0]);
+      transpose_pieces_nosum(pp2, id[1], Ap[1]);
+#pragma unroll
+      for (int ti = 0; ti < 2; ti++) {
+        BT B;
+        split4(h1T[ti] * rT, B);
+        dW2[0][ti] = dw_mac<false>(dW2[0][ti], Ao[0], B);
+        dW2[1][ti] = dw_mac<false>(dW2[1][ti], Ao[1], B);
+        dW2[2][ti] = dw_mac<false>(dW2[2][ti], Ap[0], B);
+        dW2[3][ti] = dw_mac<false>(dW2[3][ti], Ap[1], B);
+      }
+      transpose_pieces(po, id[0], Ao[0], db1[0], rT);
+      transpose_pieces(po, id[1], Ao[1], db1[1], rT);
+#pragma unroll
+      for (int u = 0; u < NT0; u++) {
+        const f32x4 xT = *reinterpret_cast<const f32x4*>(xb + (16 * u + c) * 16 + 4 * g);
+        BT B;
+        split4(xT * rT, B);
+        dW1[0][u] = dw_mac<false>(dW1[0][u], Ao[0], B);
+        dW1[1][u] = dw_mac<false>(dW1[1][u], Ao[1], B);
+      }
+      float* p0 = dX + (int64_t)(4 * g) * N + n;
+      if (half == 0) {
+        f32x4 dx[2];
+        zero_init<2>(dx);
+        const u32x4* w = lds + OFF_T0 + lane;
+        mac_step<2>(dx, po, w + own_step);
+        lk.take(pp);
+        mac_step<2>(dx, pp, w + oth_step);
+        if (dX && live) {
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            if (16 * (t + 1) <= K0) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
+            } else if (16 * t < K0) {
+#pragma unroll
+              for (int r = 0; r < 4; r++)
+                if (16 * t + 4 * g + r < K0) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
+            }
+          }
+        }
+      } else {
+        f32x4 dx[1];
+        zero_init<1>(dx);
+        const u32x4* w = lds + OFF_T0 + 2 * tile_rec + lane;
+        mac_step<1>(dx, po, w + own_step);
+        lk.take(pp);
+        mac_step<1>(dx, pp, w + oth_step);
+        if (dX && live) {
+          if (48 <= K0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) p0[(int64_t)(32 + r) * N] = dx[0][r] * dy_pow2;
+          } else if (32 < K0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (32 + 4 * g + r < K0) p0[(int64_t)(32 + r) * N] = dx[0][r] * dy_pow2;
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---------------- wave accumulators -> workgroup image -> this workgroup's slot.  The two waves of a pair own disjoint parts
+  // of the image: one round per pair
+  const int lane = lane_k, c = lane & 15, g = lane >> 4;
+  __syncthreads();
+  float* G = reinterpret_cast<float*>(lds);
+  for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) G[e] = 0.f;
+  __syncthreads();
+  for (int w = 0; w < NPAIR; w++) {
+    if (pair == w) {
+#pragma unroll
+      for (int q = 0; q < NT; q++) {
+        const int to = q < 2 ? 2 * half + q : 2 * (half ^ 1) + (q - 2);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = (16 * to + 4 * g + r) * 64;  // [out][in]
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            G[G_W2 + row + 16 * (2 * half + t) + c] += dW2[q][t][r];
+            G[G_W3 + row + 16 * (2 * half + t) + c] += dW3[q][t][r];
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = (16 * (2 * half + t) + 4 * g + r) * 64;
+#pragma unroll
+          for (int ti = 0; ti < NT0; ti++) G[G_W1 + row + 16 * ti + c] += dW1[t][ti][r];
+        }
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        float v1 = db1[t].total(), v2 = db2[t].total(), v3 = db3[t].total(), v4 = dw4[t].total();
+        v1 += __shfl_xor(v1, 16, 64); v2 += __shfl_xor(v2, 16, 64); v3 += __shfl_xor(v3, 16, 64); v4 += __shfl_xor(v4, 16, 64);
+        v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); v3 += __shfl_xor(v3, 32, 64); v4 += __shfl_xor(v4, 32, 64);
+        if (g == 0) {
+          const int f = 16 * (2 * half + t) + c;
+          G[G_B1 + f] += v1;
+          G[G_B2 + f] += v2;
+          G[G_B3 + f] += v3;
+          G[G_W4 + f] += v4;
+        }
+      }
+      float b4 = db4;
+      b4 += __shfl_xor(b4, 16, 64);
+      b4 += __shfl_xor(b4, 32, 64);
+      if (lane == 0 && half == 0) G[G_B4] += b4;
+    }
+    __syncthreads();
+  }
+  float* dst = partial + (size_t)blockIdx.x * G_TOTAL;
+  for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) dst[e] = G[e];
+}
+
 // Sum of the workgroup images, accumulated into the torch-layout gradients (dW_l [out, in], db_l)
 __global__ void mlp_split_reduce_kernel(const float* __restrict__ partial, const uint32_t* __restrict__ absmax, int nimg, int K0, float* __restrict__ dW0,
                                         float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ dW3,
@@ -741,7 +1231,15 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
 
 }  // namespace
 
+#ifndef PSDF_MLP_BWD_F16_PAIR_DEFAULT
+#define PSDF_MLP_BWD_F16_PAIR_DEFAULT 0
+#endif
+static int g_f16_form = 0;   // form of the last launch: 1 = one wave per SIMD, 2 = wave pairs
+
 extern "C" {
+
+// 0 = no split-fp16 backward yet, 1 = the last one ran mlp_bwd_split_f16_kernel, 2 = mlp_bwd_split_f16_pair_kernel
+int psdf_mlp_backward_split_f16_form(void) { return g_f16_form; }
 
 // Same contract as psdf_mlp_backward (include/psdf.h) for dims = {K0 <= 64, 64, 64, 64, 1} with dW / db requested; returns
 // PSDF_ERR_UNSUPPORTED (-2) for everything else and when the library's per-stream scratch is unavailable (stream capture).
@@ -764,8 +1262,14 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int64_t ntiles = (N + 15) / 16;
-  int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;
-  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
+  // PSDF_MLP_BWD_F16_FORM: "pair" = the wave-pair kernel (two waves per SIMD, K0 <= 48), "one" = one wave per SIMD; read at
+  // every call so that tests and benches can A/B the two in one process
+  const char* form = getenv("PSDF_MLP_BWD_F16_FORM");
+  const bool pair_form = nt0 == 3 && (form ? form[0] == 'p' : PSDF_MLP_BWD_F16_PAIR_DEFAULT);
+  const size_t pair_lds = img_bytes + (size_t)(PAIR_WAVES / 2) * 2 * (64 * 16 + 64) * 4 + (size_t)(PAIR_WAVES / 2) * XCH_PAIR * 16 + 64;
+  g_f16_form = pair_form ? 2 : 1;
+  int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;   // four tiles in flight per workgroup in either form
+  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave (pair) walks many tiles
   const size_t part_bytes = (size_t)blocks * G_TOTAL * sizeof(float);
   char* scratch = (char*)psdf::stream_scratch(img_bytes + 16 + part_bytes, st);   // NULL while capturing
   if (!scratch) return PSDF_ERR_UNSUPPORTED;
@@ -790,7 +1294,13 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
     ab = ab < 1 ? 1 : (ab > 512 ? 512 : ab);
     hipLaunchKernelGGL(mlp_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, N, dY, absmax);
   }
-  if (nt0 == 3) MAIN(3); else MAIN(4);
+  if (pair_form) {
+    auto kern = mlp_bwd_split_f16_pair_kernel<3>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PAIR_WAVES * 64), pair_lds, st, N, K0, rows4, X, dY,
+                       reinterpret_cast<const u32x4*>(rec), absmax, dX, partial);
+  } else if (nt0 == 3) MAIN(3); else MAIN(4);
 #undef PACK
 #undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256, 16), dim3(256), 0, st, partial, absmax, (int)blocks, K0,
