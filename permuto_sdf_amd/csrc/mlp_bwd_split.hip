@@ -304,7 +304,11 @@ __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO
 template <int NT0, bool DOUBLE>
 __global__ void __launch_bounds__(NWAVES * 64, 1)
     mlp_bwd_split_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
-                         const u32x4* __restrict__ img, float* __restrict__ dX, float* __restrict__ partial) {
+                         const u32x4* __restrict__ img, float* __restrict__ dX, float* __restrict__ partial,
+                         const uint32_t* __restrict__ only_if) {
+  // only_if: NULL, or a device word that must be non-zero for this launch to do anything -- the split-fp16 kernels queue
+  // this one behind themselves for the batches that leave their range (mlp_bwd_split_f16.hip, "range guard")
+  if (only_if && only_if[0] == 0u) return;
   extern __shared__ __align__(16) u32x4 lds[];
   constexpr size_t IMG_ALIGNED = img_aligned(NT0);
   constexpr int OFF_F32 = off_f32(NT0);
@@ -534,7 +538,8 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
 __global__ void mlp_split_reduce_kernel(const float* __restrict__ partial, int nimg, int K0, float* __restrict__ dW0,
                                         float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ dW3,
                                         float* __restrict__ db0, float* __restrict__ db1, float* __restrict__ db2,
-                                        float* __restrict__ db3) {
+                                        float* __restrict__ db3, const uint32_t* __restrict__ only_if) {
+  if (only_if && only_if[0] == 0u) return;
   // blockIdx.y = a slice of the images (a serial loop over 256 images per element left the chip idle: 63 us); the slices
   // meet in the destination with one float atomic each (the destinations are accumulated into anyway)
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -628,16 +633,23 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
 // single-staged instantiations spill under that strategy (108 / 64 B of scratch) and stay with the default one.
 namespace psdf {
 int mlp_bwd_split_launch_double(unsigned blocks, size_t lds_bytes, hipStream_t st, int64_t N, int K0, int rows4, const float* X,
-                                const float* dY, const void* rec, float* dX, float* partial);
+                                const float* dY, const void* rec, float* dX, float* partial, const uint32_t* only_if);
+// psdf_mlp_backward_split with the caller's scratch (mlp_backward_split_scratch_bytes of it, 16-byte aligned; NULL = the
+// library's per-stream scratch) and an optional device-side condition (see mlp_bwd_split_kernel)
+size_t mlp_backward_split_scratch_bytes(int K0, int64_t N);
+int mlp_backward_split_impl(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                            const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                            hipStream_t st, char* scratch, const uint32_t* only_if);
 }
 #if defined(PSDF_SPLIT_TU_DOUBLE)
 int psdf::mlp_bwd_split_launch_double(unsigned blocks, size_t lds_bytes, hipStream_t st, int64_t N, int K0, int rows4,
-                                      const float* X, const float* dY, const void* rec, float* dX, float* partial) {
+                                      const float* X, const float* dY, const void* rec, float* dX, float* partial,
+                                      const uint32_t* only_if) {
   auto kern = mlp_bwd_split_kernel<3, true>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,
-                     reinterpret_cast<const u32x4*>(rec), dX, partial);
+                     reinterpret_cast<const u32x4*>(rec), dX, partial, only_if);
   return PSDF_OK;
 }
 #else
@@ -651,6 +663,22 @@ extern "C" {
 int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
                             const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
                             void* stream) {
+  return psdf::mlp_backward_split_impl(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, (hipStream_t)stream, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+static int64_t split_blocks(int64_t N) {
+  const int64_t ntiles = (N + 15) / 16;
+  int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;
+  return blocks > 256 ? 256 : blocks;  // one workgroup per CU; each wave walks many tiles
+}
+size_t psdf::mlp_backward_split_scratch_bytes(int K0, int64_t N) {
+  return img_aligned(K0 <= 48 ? 3 : 4) + (size_t)split_blocks(N) * G_TOTAL * sizeof(float);
+}
+int psdf::mlp_backward_split_impl(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                                  const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                                  hipStream_t st, char* scratch, const uint32_t* only_if) {
   if (n_layers != 4 || !dims || dims[1] != HID || dims[2] != HID || dims[3] != HID || dims[4] != 1 || !dW || !db)
     return PSDF_ERR_UNSUPPORTED;
   const int K0 = dims[0];
@@ -665,12 +693,9 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
   if (N <= 0 || !X || !weights || !biases || !dY) return PSDF_ERR_ARG;
   for (int l = 0; l < 4; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const int64_t ntiles = (N + 15) / 16;
-  int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;
-  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
+  const int64_t blocks = split_blocks(N);
   const size_t part_bytes = (size_t)blocks * G_TOTAL * sizeof(float);
-  char* scratch = (char*)psdf::stream_scratch(img_bytes + part_bytes, st);   // NULL while capturing
+  if (!scratch) scratch = (char*)psdf::stream_scratch(img_bytes + part_bytes, st);   // NULL while capturing
   if (!scratch) return PSDF_ERR_UNSUPPORTED;
   uint16_t* rec = reinterpret_cast<uint16_t*>(scratch);
   float* partial = reinterpret_cast<float*>(scratch + img_bytes);
@@ -684,12 +709,12 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);       \
     if (e != hipSuccess) return (int)e;                                                                                     \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,                  \
-                       reinterpret_cast<const u32x4*>(rec), dX, partial);                                                   \
+                       reinterpret_cast<const u32x4*>(rec), dX, partial, only_if);                                          \
   } while (0)
   if (nt0 == 3) {
     PACK(3);
     if (dbl) {
-      const int rc = psdf::mlp_bwd_split_launch_double((unsigned)blocks, lds_bytes, st, N, K0, rows4, X, dY, rec, dX, partial);
+      const int rc = psdf::mlp_bwd_split_launch_double((unsigned)blocks, lds_bytes, st, N, K0, rows4, X, dY, rec, dX, partial, only_if);
       if (rc != PSDF_OK) return rc;
     } else {
       MAIN(3, false);
@@ -701,10 +726,8 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
 #undef PACK
 #undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256, 16), dim3(256), 0, st, partial, (int)blocks, K0, dW[0],
-                     dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
+                     dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3], only_if);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
-
-}  // extern "C"
 #endif  // PSDF_SPLIT_TU_DOUBLE

@@ -37,6 +37,8 @@
 // Accuracy against float64: tests/test_gpu_mlp.py::test_split_f16_backward_matches_float64.  Built with
 // -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize (build.py).
 #include "psdf_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -322,6 +324,29 @@ __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO
   }
 }
 
+// Range guard.  The two-piece scheme holds while every input and hidden activation stays below 2^8 in magnitude (the H-side
+// dW operand is pre-scaled by 2^8 and fp16 ends at 65504) and every weight below 65504.  The kernels keep the largest |x|, |h|
+// they meet (one v_max3_f32 per two values, 32 per tile) and raise the launch's guard word (absmax[1]) when it reaches
+// RANGE_LIMIT; the pack kernel does the same for the weights.  A raised word makes the summing launch drop the images and lets
+// the three-piece bf16 kernel -- queued behind every launch, a no-op while the word is zero -- redo the batch (dX is
+// overwritten): psdf_mlp_backward_split_f16 below.
+constexpr float RANGE_LIMIT = 255.0f;
+__device__ __forceinline__ float amax_of(float m, const f32x4& v) {
+  m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v[0])), __builtin_fabsf(v[1]));
+  return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v[2])), __builtin_fabsf(v[3]));
+}
+__device__ __forceinline__ float amax_of8(float m, const float (&x)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(x[j])), __builtin_fabsf(x[j + 1]));
+  return m;
+}
+// end of a kernel: one atomic per wave that saw a value out of range (NaN compares false: a NaN batch is NaN in every kernel)
+__device__ __forceinline__ void range_report(float m, uint32_t* guard) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m >= RANGE_LIMIT) atomicOr(guard, 1u);
+}
+
 // 2^k with max|dY| * 2^k in [2^4, 2^5) (k clamped to +-100; 1 when dY is all zero / not finite): bits = max over the batch of
 // the bit pattern of |dY| (mlp_absmax_kernel)
 __device__ __forceinline__ int dy_scale(uint32_t bits, float& sc, float& isc) {
@@ -366,10 +391,11 @@ __device__ __forceinline__ void dy_parts(float dy, float& mant, float& pow2) {
 template <int NT0>
 __global__ void __launch_bounds__(NWAVES * 64, 1)
     mlp_bwd_split_f16_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
-                             const u32x4* __restrict__ img, const uint32_t* __restrict__ absmax, float* __restrict__ dX,
+                             const u32x4* __restrict__ img, uint32_t* __restrict__ absmax, float* __restrict__ dX,
                              float* __restrict__ partial) {
   extern __shared__ __align__(16) u32x4 lds[];
   constexpr bool GLDS = NT0 == 3;
+  uint32_t out_of_range = 0u;   // range guard: some lane of this wave met |input| or |hidden activation| >= RANGE_LIMIT (uniform)
   float sc, isc;
   const int kscale = dy_scale(absmax[0], sc, isc);      // 2^kscale * max|dY| in [2^4, 2^5)
   constexpr size_t IMG_ALIGNED = img_aligned(NT0);
@@ -454,6 +480,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     const bool live = n < N;
     // ---------------- forward recompute; h1, h2 leave the sweep as fp32 feature-lane tiles
     f32x4 a[NT], g1[NT], b[NT], g2[NT], h1T[NT], h2T[NT];
+    float seen;            // largest |input|, |hidden activation| of this lane in this tile: lives through the forward sweep only
     f32x4* gl = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + IMG_ALIGNED +
                                          (size_t)NWAVES * 2 * stage_floats * 4) + wave * (2 * NT * 64) + lane;
     bias_init<NT>(a, tail, g);
@@ -476,9 +503,12 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       mac16r<NT>(a, bx, w00);
       split8(xs[1], bx);
       mac16r<NT>(a, bx, w01);
+      seen = amax_of8(amax_of8(0.f, xs[0]), xs[1]);
     }
     bias_init<NT>(b, tail + HID, g);      // (requested ahead of the activation block: b is dead until the chain)
     act_both(a, g1);  // a = h1
+#pragma unroll
+    for (int t = 0; t < NT; t++) seen = amax_of(seen, a[t]);
     if constexpr (GLDS) {
 #pragma unroll
       for (int t = 0; t < NT; t++) gl[t * 64] = g1[t];
@@ -489,6 +519,8 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     });
     bias_init<NT>(a, tail + 2 * HID, g);
     act_both(b, g2);  // b = h2
+#pragma unroll
+    for (int t = 0; t < NT; t++) seen = amax_of(seen, b[t]);
     if constexpr (GLDS) {
 #pragma unroll
       for (int t = 0; t < NT; t++) gl[(NT + t) * 64] = g2[t];
@@ -504,6 +536,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
       for (int t = 0; t < NT; t++) w4[t] = *reinterpret_cast<const f32x4*>(wf0 + 16 * t + 4 * g);
     }
     act_both(a, dz);  // a = h3, dz = gelu'(z3) for now
+#pragma unroll
+    for (int t = 0; t < NT; t++) seen = amax_of(seen, a[t]);
+    out_of_range |= __builtin_amdgcn_ballot_w64(seen >= RANGE_LIMIT) != 0ull ? 1u : 0u;
     // ---------------- output layer: dW4 = sum dy h3, db4 = sum dy, dZ3 = w4 dy gelu'(z3); samples past N carry dy = 0,
     // which zeroes every contribution of theirs below
     f32x4 rT;   // 2^(e(n) + kscale) of the samples 4 g + r: what their H / dZ carry into the parameter gradients
@@ -579,6 +614,7 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (out_of_range && lane_k == 0) atomicOr(absmax + 1, 1u);
   // ---------------- wave accumulators -> workgroup image (the weight images are dead) -> this workgroup's slot
   const int lane = lane_k, c = lane & 15, g = lane >> 4;
   __syncthreads();
@@ -739,10 +775,11 @@ __device__ __forceinline__ void mac_step(f32x4 (&out)[NTILE], const BP& b, const
 template <int NT0>
 __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
     mlp_bwd_split_f16_pair_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
-                                  const u32x4* __restrict__ img, const uint32_t* __restrict__ absmax, float* __restrict__ dX,
+                                  const u32x4* __restrict__ img, uint32_t* __restrict__ absmax, float* __restrict__ dX,
                                   float* __restrict__ partial) {
   static_assert(NT0 == 3, "the pair form holds three input tiles (K0 <= 48)");
   extern __shared__ __align__(16) u32x4 lds[];
+  uint32_t out_of_range = 0u;   // range guard (uniform; see the one-wave kernel)
   float sc, isc;
   const int kscale = dy_scale((uint32_t)__builtin_amdgcn_readfirstlane((int)absmax[0]), sc, isc);   // (uniform: scalar registers)
   constexpr size_t IMG_ALIGNED = img_aligned(NT0);
@@ -832,6 +869,7 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
     const int own0 = 2 * half;               // the wave's first tile of every hidden layer
     // ---------------- forward recompute of the own tiles
     f32x4 a[2], g1[2], b[2], g2[2], h1T[2], h2T[2];
+    float seen;
     const int own_step = half * (NP * 64), oth_step = (half ^ 1) * (NP * 64);
     bias_init<2>(a, tail + 16 * own0, g);
     {
@@ -851,6 +889,7 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
       mac16r<2>(a, bx, w00);
       split8(xs[1], bx);
       mac16r<2>(a, bx, w01);
+      seen = half ? 0.f : amax_of8(amax_of8(0.f, xs[0]), xs[1]);     // (both waves read the same inputs)
     }
     // per-sample factors of the tile (samples 4 g + r): rT = 2^(e(n) + kscale) of what H / dZ carry into the parameter
     // gradients, dyT = dY 2^kscale for dW4 / db4; branch-free
@@ -871,6 +910,7 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
     dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
     bias_init<2>(b, tail + HID + 16 * own0, g);
     act_both_n<2>(a, g1);  // a = h1 (own tiles)
+    seen = amax_of(amax_of(seen, a[0]), a[1]);
     {
       BP po, pp;
       const u32x4* w = lds + OFF_W1 + own0 * tile_rec + lane;
@@ -893,6 +933,7 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
     }
     bias_init<2>(a, tail + 2 * HID + 16 * own0, g);
     act_both_n<2>(b, g2);  // b = h2
+    seen = amax_of(amax_of(seen, b[0]), b[1]);
     {
       BP po, pp;
       const u32x4* w = lds + OFF_W2 + own0 * tile_rec + lane;
@@ -910,6 +951,8 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
     }
     f32x4 dz[2];
     act_both_n<2>(a, dz);  // a = h3, dz = gelu'(z3)
+    seen = amax_of(amax_of(seen, a[0]), a[1]);
+    out_of_range |= __builtin_amdgcn_ballot_w64(seen >= RANGE_LIMIT) != 0ull ? 1u : 0u;
     // ---------------- output layer: dZ3 = w4 dy gelu'(z3) on the mantissa of dY (dX is multiplied by 2^(e(n) - 4) at the store)
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -1056,6 +1099,7 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (out_of_range && lane_k == 0) atomicOr(absmax + 1, 1u);
   // ---------------- wave accumulators -> workgroup image -> this workgroup's slot.  The two waves of a pair own disjoint parts
   // of the image: one round per pair
   const int lane = lane_k, c = lane & 15, g = lane >> 4;
@@ -1111,13 +1155,19 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
 }
 
 // Sum of the workgroup images, accumulated into the torch-layout gradients (dW_l [out, in], db_l)
+// guard_drops: the launch has a bf16 launch queued behind it that redoes the batch when the range guard is raised (absmax[1]):
+// the images are then dropped here.  events (host-mapped, may be NULL): count of raised guards, for the one-time warning.
 __global__ void mlp_split_reduce_kernel(const float* __restrict__ partial, const uint32_t* __restrict__ absmax, int nimg, int K0, float* __restrict__ dW0,
                                         float* __restrict__ dW1, float* __restrict__ dW2, float* __restrict__ dW3,
                                         float* __restrict__ db0, float* __restrict__ db1, float* __restrict__ db2,
-                                        float* __restrict__ db3) {
+                                        float* __restrict__ db3, int guard_drops, volatile uint32_t* events) {
   // blockIdx.y = a slice of the images (a serial loop over 256 images per element left the chip idle: 63 us); the slices
   // meet in the destination with one float atomic each (the destinations are accumulated into anyway)
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (absmax[1]) {
+    if (events && e == 0 && blockIdx.y == 0) events[0] = events[0] + 1u;
+    if (guard_drops) return;
+  }
   if (e >= G_TOTAL) return;
   float s = 0.f;
   for (int b = blockIdx.y; b < nimg; b += gridDim.y) s += partial[(size_t)b * G_TOTAL + e];
@@ -1178,7 +1228,7 @@ __global__ void __launch_bounds__(256) mlp_absmax_kernel(int64_t N, const float*
 }
 
 // The LDS image from the torch-layout parameters: thread = (image 0..5, tile, k-step, lane) writes its two 16-byte
-// records (one per piece); the tail threads copy biases / final weights; the last thread clears the |dY| maximum slot.
+// records (one per piece); the tail threads copy biases / final weights.
 template <int NT0>
 __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, const float* __restrict__ W1,
                                       const float* __restrict__ W2, const float* __restrict__ W3,
@@ -1207,13 +1257,16 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
       }
     }
     u32x4 hi, lo;
+    float wmax = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       uint32_t h, l;
       split2(w[2 * i], w[2 * i + 1], h, l);
       hi[i] = h;
       lo[i] = l;
+      wmax = __builtin_fmaxf(__builtin_fmaxf(wmax, __builtin_fabsf(w[2 * i])), __builtin_fabsf(w[2 * i + 1]));
     }
+    if (wmax >= 65504.f) atomicOr(absmax + 1, 1u);    // range guard (the words are cleared by a memset in front of this launch)
     u32x4* dst = reinterpret_cast<u32x4*>(rec) + (off[im] + ((tile * 2 + s) * NP) * 64 + lane);
     dst[0] = hi;
     dst[64] = lo;
@@ -1225,7 +1278,6 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
     else if (e < 3 * HID) tail[e] = b2[e - 2 * HID];
     else if (e < 4 * HID) tail[e] = W3[e - 3 * HID];
     else if (e == 4 * HID) tail[e] = b3[0];
-    else if (e == 4 * HID + 1) absmax[0] = 0u;
   }
 }
 
@@ -1235,6 +1287,26 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
 #define PSDF_MLP_BWD_F16_PAIR_DEFAULT 0
 #endif
 static int g_f16_form = 0;   // form of the last launch: 1 = one wave per SIMD, 2 = wave pairs
+namespace psdf {
+size_t mlp_backward_split_scratch_bytes(int K0, int64_t N);      // mlp_bwd_split.hip
+int mlp_backward_split_impl(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                            const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
+                            hipStream_t st, char* scratch, const uint32_t* only_if);
+}
+// one host-mapped word the summing launches count raised range guards into (NULL when the allocation fails: no warning then)
+static uint32_t g_range_warned = 0;
+static volatile uint32_t* range_events() {
+  static uint32_t* dev_ptr = [] {
+    uint32_t* h = nullptr;
+    if (hipHostMalloc((void**)&h, 64, hipHostMallocMapped) != hipSuccess || !h) {
+      (void)hipGetLastError();
+      return (uint32_t*)nullptr;
+    }
+    h[0] = 0u;
+    return h;
+  }();
+  return dev_ptr;
+}
 
 extern "C" {
 
@@ -1270,13 +1342,25 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
   g_f16_form = pair_form ? 2 : 1;
   int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;   // four tiles in flight per workgroup in either form
   if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave (pair) walks many tiles
-  const size_t part_bytes = (size_t)blocks * G_TOTAL * sizeof(float);
-  char* scratch = (char*)psdf::stream_scratch(img_bytes + 16 + part_bytes, st);   // NULL while capturing
+  const size_t part_bytes = ((size_t)blocks * G_TOTAL * sizeof(float) + 15) & ~(size_t)15;
+  // range guard (see RANGE_LIMIT): nets the three-piece bf16 kernel covers (K0 <= 52) get that kernel queued behind this one,
+  // conditional on the guard word; wider inputs (53 .. 64: no such kernel) keep the saturating arithmetic and only count the event
+  const bool guarded = K0 <= 52 && !getenv("PSDF_MLP_F16_NO_GUARD");
+  const size_t fb_bytes = guarded ? psdf::mlp_backward_split_scratch_bytes(K0, N) : 0;
+  char* scratch = (char*)psdf::stream_scratch(img_bytes + 16 + part_bytes + fb_bytes, st);   // NULL while capturing
   if (!scratch) return PSDF_ERR_UNSUPPORTED;
   uint32_t* rec = reinterpret_cast<uint32_t*>(scratch);
-  uint32_t* absmax = reinterpret_cast<uint32_t*>(scratch + img_bytes);
+  uint32_t* absmax = reinterpret_cast<uint32_t*>(scratch + img_bytes);      // [0] max |dY| bits, [1] range guard
   float* partial = reinterpret_cast<float*>(scratch + img_bytes + 16);
-  const int pack_threads = (5 * NT + nt0) * 2 * 64 + TAIL_FLOATS + 1;
+  volatile uint32_t* events = range_events();
+  if (events && events[0] != g_range_warned) {      // raised by an EARLIER call (the word is written by the device)
+    if (!g_range_warned)
+      fprintf(stderr, "psdf: MLP inputs / activations beyond the split-fp16 range (|value| >= 255): such batches are redone by the "
+                      "three-piece bf16 kernel (slower); PSDF_MLP_BWD_SPLIT=bf16 selects it outright\n");
+    g_range_warned = events[0];
+  }
+  if (hipMemsetAsync(absmax, 0, 16, st) != hipSuccess) return PSDF_ERR_UNSUPPORTED;
+  const int pack_threads = (5 * NT + nt0) * 2 * 64 + TAIL_FLOATS;
 #define PACK(NT0_)                                                                                                         \
   hipLaunchKernelGGL(mlp_split_pack_kernel<NT0_>, dim3((pack_threads + 255) / 256), dim3(256), 0, st, K0, weights[0],        \
                      weights[1], weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], rec, absmax)
@@ -1304,9 +1388,20 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
 #undef PACK
 #undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256, 16), dim3(256), 0, st, partial, absmax, (int)blocks, K0,
-                     dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
+                     dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3], guarded ? 1 : 0, events);
   PSDF_LAUNCH_CHECK();
+  if (guarded) {
+    const int rc = psdf::mlp_backward_split_impl(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, st,
+                                                 scratch + img_bytes + 16 + part_bytes, absmax + 1);
+    if (rc != PSDF_OK) return rc;
+  }
   return PSDF_OK;
+}
+
+// how many launches raised the range guard so far (the device counts into host-mapped memory: exact after a synchronisation)
+unsigned psdf_mlp_f16_range_events(void) {
+  volatile uint32_t* e = range_events();
+  return e ? e[0] : 0u;
 }
 
 }  // extern "C"

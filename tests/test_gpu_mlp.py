@@ -428,7 +428,8 @@ def test_unfused_widths_raise_unless_opted_in(dev):
                                   # width, the full 64 rows (no zero-padded row in the staging buffer), fewer than 16 rows (no
                                   # 16-byte request at all), a batch smaller than one tile
                                   (52, 262_144), (64, 65_536), (5, 4_096), (36, 8)])
-def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale):
+@pytest.mark.parametrize("form", ["one", "pair"])
+def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypatch):
     """csrc/mlp_bwd_split_f16.hip (two fp16 pieces per fp32 operand, three products; gradient chain evaluated on dY * 2^k with k
     from max|dY|): every gradient against a float64 evaluation, for upstream gradients of ordinary size, tiny (1e-7: every
     value would be an fp16 subnormal without the scaling), large (3e4: would overflow fp16), and spread over six decades
@@ -438,6 +439,9 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale):
     import ctypes
     from permuto_sdf_amd import _lib as L
     from permuto_sdf_amd.mlp import _dims_array, _zero_grads
+    # form: one wave per SIMD (the default) or the wave-pair kernel of round 5 (two waves per SIMD, K0 <= 48; wider inputs
+    # run the one-wave kernel under either setting -- the form query below says which one ran)
+    monkeypatch.setenv("PSDF_MLP_BWD_F16_FORM", form)
     torch.manual_seed(K0 + N % 7)
     dims = [K0, 64, 64, 64, 1]
     lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
@@ -463,6 +467,9 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale):
     rc = fn(L.c_i(4), _dims_array(dims), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx), arr(dWs), arr(dbs),
             L.stream())
     assert rc == 0, rc
+    which = L.lib().psdf_mlp_backward_split_f16_form
+    which.restype = ctypes.c_int
+    assert which() == (2 if (form == "pair" and K0 <= 48) else 1)
     got = [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
     names = ["dX", "dW1", "db1", "dW2", "db2", "dW3", "db3", "dW4", "db4"]
     errs = {}
@@ -485,6 +492,79 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale):
     fn2 = L.lib().psdf_mlp_backward_split_f16
     assert fn2(L.c_i(4), _dims_array([36, 32, 32, 32, 1]), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx),
                arr(dWs), arr(dbs), L.stream()) == -2
+
+
+@pytest.mark.parametrize("form", ["one", "pair"])
+@pytest.mark.parametrize("what", ["inputs", "hidden", "weights"])
+def test_split_f16_backward_range_guard(dev, what, form, monkeypatch):
+    """The two-piece fp16 arithmetic holds for |inputs|, |hidden activations| < 2^8 (the H-side operand of the parameter-gradient
+    products is pre-scaled by 2^8) and |weights| < 65504.  Outside, the kernel raises a guard word, its summing launch drops
+    the clipped images and the three-piece bf16 kernel queued behind it redoes the batch: the gradients are right (float64,
+    the same 2e-5 bar) instead of silently clipped, and the event is counted (psdf_mlp_f16_range_events).  A batch inside the
+    range leaves the counter alone."""
+    import copy
+    import ctypes
+    from permuto_sdf_amd import _lib as L
+    from permuto_sdf_amd.mlp import _dims_array, _zero_grads
+    monkeypatch.setenv("PSDF_MLP_BWD_F16_FORM", form)
+    torch.manual_seed(11)
+    K0, N = 36, 262_144 + 48
+    dims = [K0, 64, 64, 64, 1]
+    lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
+    x = torch.randn(N, K0, device=dev)
+    if what == "inputs":
+        x[N // 3, 5] = 300.0                       # one value of one sample beyond 255
+    elif what == "hidden":
+        with torch.no_grad():
+            lin[0].bias[7] = 400.0                 # h1[:, 7] ~ 400 for every sample
+    else:
+        with torch.no_grad():
+            lin[1].weight[3, 9] = 7.0e4            # a weight fp16 cannot hold
+    net = torch.nn.Sequential(lin[0], torch.nn.GELU(), lin[1], torch.nn.GELU(), lin[2], torch.nn.GELU(), lin[3]).to(dev)
+    gy = torch.randn(N, 1, device=dev)
+    events = L.lib().psdf_mlp_f16_range_events
+    events.restype = ctypes.c_uint
+    fn = L.lib().psdf_mlp_backward_split_f16
+    fn.restype = ctypes.c_int
+    arr = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+
+    fn_bf16 = L.lib().psdf_mlp_backward_split
+    fn_bf16.restype = ctypes.c_int
+
+    def run(xin):
+        x_fm, gy_fm = xin.t().contiguous(), gy.t().contiguous()
+        ws = [m.weight.detach().contiguous() for m in net if isinstance(m, torch.nn.Linear)]
+        bs = [m.bias.detach().contiguous() for m in net if isinstance(m, torch.nn.Linear)]
+
+        def call(f):
+            dx = torch.empty((K0, N), device=dev)
+            dWs, dbs = _zero_grads(dims, dev)
+            rc = f(L.c_i(4), _dims_array(dims), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(gy_fm), L.ptr(dx), arr(dWs), arr(dbs),
+                   L.stream())
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+            return [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
+        got = call(fn)
+        if what == "weights":
+            # a 7e4 weight makes activations of 1e5: fp32 itself is 1e-4 away from float64 there; the statement is that the batch
+            # was handed to the three-piece kernel, i.e. equals that kernel's own answer (up to the order of its float atomics)
+            ref = [t.double() for t in call(fn_bf16)]
+        else:
+            net64 = copy.deepcopy(net).double()
+            x64 = xin.double().requires_grad_(True)
+            net64(x64).backward(gy.double())
+            ref = [x64.grad] + [p.grad for p in net64.parameters()]
+        return {i: float((g.double() - r).abs().max()) / float(r.abs().max()) for i, (g, r) in enumerate(zip(got, ref))}
+
+    before = int(events())
+    errs = run(x)
+    print("range guard (%s, %s): worst %.1e" % (what, form, max(errs.values())), errs)
+    assert int(events()) == before + 1
+    assert max(errs.values()) <= 2e-5, errs
+    if what == "inputs":
+        mid = int(events())
+        errs = run(torch.randn(N, K0, device=dev))
+        assert int(events()) == mid and max(errs.values()) <= 2e-5, errs
 
 
 @pytest.mark.parametrize("K0,N", [(36, 200_003), (52, 70_000), (20, 4_097), (64, 33)])
