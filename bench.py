@@ -192,6 +192,41 @@ def main():
         per_rank = {"ms_per_step": [float(x[0]) for x in allr], "comm_wait_ms": [float(x[1]) for x in allr]}
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
+    # self-certification of an N > 1 run (gathered on every rank, printed by rank 0): which physical device each rank ran on
+    # (uuid / PCI bus id: N distinct ones, or the run says otherwise), the collective library's version, and whether the
+    # replicas still hold bit-identical parameters after the timed steps (a checksum per rank, MIN == MAX over ranks)
+    cert = None
+    if world > 1:
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            ident = "%s|%s|%s" % (getattr(pr, "uuid", "?"), getattr(pr, "pci_bus_id", "?"), getattr(pr, "name", "?"))
+            try:
+                ident += "|bus=%s" % torch.cuda.get_device_properties(dev).pci_bus_id
+            except Exception:
+                pass
+            idents = [None] * world
+            torch.distributed.all_gather_object(idents, ident)
+            ck = torch.zeros(2, dtype=torch.float64, device=cdev)
+            with torch.no_grad():
+                ps = [hp.enc.lattice_values] + [l.weight for l in hp.mlp.layers] + [l.bias for l in hp.mlp.layers]
+                ck[0] = sum(float(p.detach().double().sum()) for p in ps)
+                ck[1] = sum(float((p.detach().double() * p.detach().double()).sum()) for p in ps)
+            lo, hi = ck.clone(), ck.clone()
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+            single = os.environ.get("PSDF_BENCH_SINGLE_DEVICE") == "1"
+            cert = {"devices": idents, "distinct_devices": len(set(idents)),
+                    "single_device_development_run": single,
+                    "replicas_bit_identical": bool((lo == hi).all()),
+                    "parameter_checksum": [float(lo[0]), float(lo[1])],
+                    "backend": torch.distributed.get_backend(),
+                    "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version())
+                                     if torch.distributed.get_backend() == "nccl" else None),
+                    "torch": torch.__version__, "hip": getattr(torch.version, "hip", None)}
+            if not single and torch.distributed.get_backend() == "nccl" and len(set(idents)) != world:
+                cert["error"] = "ranks share a device: %d distinct devices for %d ranks" % (len(set(idents)), world)
+        except Exception as e:
+            cert = {"error": repr(e)}
 
     if rank == 0:
         ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
@@ -253,6 +288,19 @@ def main():
             cands = sorted((f for f in os.listdir(prof) if f.endswith("pmc_hbm_traffic.json")), reverse=True)
             src = next((f for f in cands if want in json.load(open(os.path.join(prof, f))).get("kernels", {})), cands[0])
             pmc = json.load(open(os.path.join(prof, src)))
+            # the counters are quoted only for the kernels they were taken from: the summary records a hash of csrc/ (tools/
+            # pmc_hbm_traffic.sh); a kernel source changed since then -> null + the reason, never yesterday's figure
+            import hashlib
+            csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "permuto_sdf_amd", "csrc")
+            hh = hashlib.sha256()
+            for f in sorted(os.listdir(csrc)):
+                if f.endswith((".hip", ".h")):
+                    hh.update(f.encode())
+                    hh.update(open(os.path.join(csrc, f), "rb").read())
+            if pmc.get("csrc_sha256") != hh.hexdigest():
+                roof["traffic_stale"] = ("profiles/%s was collected from other kernel sources (csrc hash %s..., now %s...): re-run "
+                                         "tools/pmc_hbm_traffic.sh" % (src, str(pmc.get("csrc_sha256"))[:12], hh.hexdigest()[:12]))
+                raise LookupError("stale")
             key = {"enc_bwd": ["encode_bwd_kernel", "encode_bwd_reduce_kernel"],
                    "mlp_bwd": [next(k for k in ("mlp_bwd_split_f16_kernel" if f16 else "mlp_bwd_split_kernel", "mlp_bwd_split_kernel",
                                                 "mlp_bwd_kernel") if k in pmc["kernels"])]}[dom]
@@ -305,7 +353,7 @@ def main():
         }
         if world > 1:
             from permuto_sdf_amd.parallel import _mode_default
-            out["dp"] = {"per_rank": per_rank, "reduce": _mode_default() + (" (reduce-scatter + all-gather per bucket)" if _mode_default() == "reduce_scatter" else ""),
+            out["dp"] = {"certificate": cert, "per_rank": per_rank, "reduce": _mode_default() + (" (reduce-scatter + all-gather per bucket)" if _mode_default() == "reduce_scatter" else ""),
                          "optimizer": (hp.last_dp or {}).get("optimizer", "replicated"),
                          "optimizer_note": "sharded: the lattice gradient is reduce-scattered in place, every rank runs AdamW on the "
                                            "1/world of the table it owns and the PARAMETERS are all-gathered (parallel.ShardedUpdate; "
@@ -360,6 +408,74 @@ def main():
             del hp24
         except Exception as e:  # the extra row must never take the headline down
             extra["L24_52-64-64-64-1"] = {"error": repr(e)}
+    # ---- extra rows that make the headline hard to discount: (a) the SAME step with 24-bit MLP operands in both directions
+    # (three bf16 pieces, six products: what the reference's fp32 cuBLAS evaluation corresponds to), (b) cfg 2 as SURVEY.md 8(d)
+    # words it -- 2 097 152 points uniform in the radius-0.5 ball instead of ray-ordered samples --, unsorted and Morton-sorted
+    if world == 1 and not args.no_extra:
+        import copy as _copy
+
+        def _timed(h, r, nrm, k):
+            for _ in range(3):
+                h.step(r, rgb, nrm, gt)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(k):
+                h.step(r, rgb, nrm, gt)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) / k
+        Kx = max(5, K // 2)
+        saved_env = {k_: os.environ.get(k_) for k_ in ("PSDF_MLP_FWD_SPLIT", "PSDF_MLP_BWD_SPLIT")}
+        try:
+            os.environ["PSDF_MLP_FWD_SPLIT"] = "bf16"
+            os.environ["PSDF_MLP_BWD_SPLIT"] = "bf16"
+            hpb = SdfHotPath(nr_levels=NR_LEVELS, hidden=64, out_channels=1, device=dev, seed=0)
+            dtb = _timed(hpb, rs, normals, Kx)
+            extra["fp32_equivalent_24bit"] = {
+                "ms_per_step": dtb * 1e3, "samples_per_s": N / dtb, "steps": Kx,
+                "kernel_paths": {"mlp_forward": int(_lp(ctypes.c_int(2))), "mlp_backward": int(_lp(ctypes.c_int(1)))},
+                "arithmetic_bits": {"mlp_forward": 24, "mlp_backward": 24},
+                "note": "the headline's step with PSDF_MLP_FWD_SPLIT=bf16 PSDF_MLP_BWD_SPLIT=bf16: every fp32 MLP operand as three bf16 "
+                        "pieces, six products kept, fp32 accumulation (fp32 rounding level against float64: "
+                        "tests/test_gpu_mlp.py::test_split_bf16_backward_matches_float64, ::test_split_bf16_forward_keeps_fp32_accuracy)"}
+            del hpb
+        except Exception as e:
+            extra["fp32_equivalent_24bit"] = {"error": repr(e)}
+        finally:
+            for k_, v_ in saved_env.items():
+                if v_ is None:
+                    os.environ.pop(k_, None)
+                else:
+                    os.environ[k_] = v_
+        try:
+            g = torch.Generator(device="cpu").manual_seed(parallel.rank_seed(11, rank))
+            u = torch.randn(N, 3, generator=g)
+            ball = (u / u.norm(dim=1, keepdim=True) * 0.5 * torch.rand(N, 1, generator=g) ** (1.0 / 3.0)).to(dev).contiguous()
+            rows = {}
+            for name in ("unsorted", "morton_sorted"):
+                pts = ball
+                if name == "morton_sorted":
+                    q = ((ball + 0.5).clamp(0, 1 - 1e-7) * 1024).to(torch.int64)
+
+                    def _spread(v):
+                        v = (v | (v << 16)) & 0x030000FF
+                        v = (v | (v << 8)) & 0x0300F00F
+                        v = (v | (v << 4)) & 0x030C30C3
+                        return (v | (v << 2)) & 0x09249249
+                    code = _spread(q[:, 0]) | (_spread(q[:, 1]) << 1) | (_spread(q[:, 2]) << 2)
+                    pts = ball[torch.argsort(code)].contiguous()
+                rsb = _copy.copy(rs)
+                rsb.samples_pos = pts
+                nb = torch.nn.functional.normalize(pts, dim=1).contiguous()
+                hpc = SdfHotPath(nr_levels=NR_LEVELS, hidden=64, out_channels=1, device=dev, seed=0)
+                dtc = _timed(hpc, rsb, nb, Kx)
+                rows[name] = {"ms_per_step": dtc * 1e3, "samples_per_s": N / dtc, "steps": Kx}
+                del hpc
+            extra["cfg2_ball_points"] = dict(rows, note="the headline's step (same kernels, same arithmetic) on %d points drawn uniformly "
+                                                         "in the radius-0.5 ball (SURVEY.md 8(d)'s wording of cfg 2) instead of "
+                                                         "ray-ordered samples; the points are grouped 128 to a 'ray' for the compositing "
+                                                         "stage; morton_sorted: the same points ordered by a 30-bit Morton code" % N)
+        except Exception as e:
+            extra["cfg2_ball_points"] = {"error": repr(e)}
     # ---- the other half of BASELINE.json's metric, "train iters/sec" (cfg 4), and the cfg 3 / cfg 5 figures.  Every one of
     # them is guarded: nothing here can take the headline down.  cfg 4 runs in this process (and this process group: under
     # N > 1 every rank steps its own rays, gradients all-reduced over RCCL); cfg 3 / cfg 5 are one-GPU inference figures and

@@ -583,7 +583,9 @@ template <int NT0>
 __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, const float* __restrict__ W1,
                                       const float* __restrict__ W2, const float* __restrict__ W3,
                                       const float* __restrict__ b0, const float* __restrict__ b1,
-                                      const float* __restrict__ b2, const float* __restrict__ b3, uint16_t* __restrict__ rec) {
+                                      const float* __restrict__ b2, const float* __restrict__ b3, uint16_t* __restrict__ rec,
+                                      const uint32_t* __restrict__ only_if) {
+  if (only_if && only_if[0] == 0u) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   constexpr int PER_IMG = NT * 2 * 64, PER_T0 = NT0 * 2 * 64, NTHR = 5 * PER_IMG + PER_T0;
   if (t < NTHR) {
@@ -702,7 +704,7 @@ int psdf::mlp_backward_split_impl(int n_layers, const int* dims, int64_t N, cons
   const int pack_threads = (5 * NT + nt0) * 2 * 64 + TAIL_FLOATS;
 #define PACK(NT0_)                                                                                                         \
   hipLaunchKernelGGL(mlp_split_pack_kernel<NT0_>, dim3((pack_threads + 255) / 256), dim3(256), 0, st, K0, weights[0],        \
-                     weights[1], weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], rec)
+                     weights[1], weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], rec, only_if)
 #define MAIN(NT0_, DBL_)                                                                                                    \
   do {                                                                                                                      \
     auto kern = mlp_bwd_split_kernel<NT0_, DBL_>;                                                                            \

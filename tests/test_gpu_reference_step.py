@@ -98,9 +98,12 @@ def test_step_with_the_reference_samples(parity, mode):
 
 
 # whole-step bars (dense max, lattice max, lattice L2), per state: measured deviations in parentheses, over seven runs
+# `late` has NO gradient bar: measured 7e-5 .. 2.5e-2 (dense), 2e-2 .. 4.4e-1 (lattice max), 7e-3 .. 7.5e-2 (lattice L2) -- a bar
+# above that would pass a 100 % error, i.e. carry no information (review of round 4); what is asserted there is the samplers'
+# agreement and the loss, and the gradients are held by test_step_with_the_reference_samples (shared samples, <= 5e-5).
 WHOLE_STEP_BARS = {"early": (1e-2, 5e-2, 2e-2),      # (2e-5 .. 2e-4, 1e-5 .. 2e-3, 3e-5 .. 1.4e-3)
                    "mask": (1e-2, 5e-2, 2e-2),       # (4e-6 .. 2e-5, 2e-5, 3e-5)
-                   "late": (1e-1, 1.0, 3e-1)}        # (7e-5 .. 2.5e-2, 2e-2 .. 4.4e-1, 7e-3 .. 7.5e-2)
+                   "late": None}
 
 
 @pytest.mark.parametrize("mode", ["early", "late", "mask"])
@@ -112,14 +115,14 @@ def test_whole_step_within_the_reference_own_noise(parity, mode):
     its weight by 10 %, and it is one of the handful of samples near the surface that carry the whole gradient -- measured over
     seven runs: dense gradients 7e-5 .. 2.5e-2 apart, the SDF lattice 2e-2 .. 4.4e-1 (max) / 7e-3 .. 7.5e-2 (L2), with the
     reference against ITSELF (hidden units of its SDF MLP re-numbered) showing 2e-2 .. 5e-2 / 7e-3 .. 1.1e-2 on the lattice.  So
-    the gradient bars here only catch a wrong step (a missing loss term moves them by O(1)); the precise statement is
-    test_step_with_the_reference_samples."""
+    the `early` / `mask` gradient bars only catch a wrong step (a missing loss term moves them by O(1)), `late` has none, and the
+    precise statement about the gradients is test_step_with_the_reference_samples."""
     c = parity["cases"][mode]
     noise = c["reference_self_noise"]
     print("  reference against itself (hidden units re-numbered): dense %.1e  lattice max %.1e L2 %.1e" % (
         noise["worst_dense"], noise["worst_lattice"], noise["worst_lattice_l2"]))
     _report(c, ("manual", "autograd"))
-    bar_dense, bar_lat, bar_l2 = WHOLE_STEP_BARS[mode]
+    bars = WHOLE_STEP_BARS[mode]
     for n in ("manual", "autograd"):
         m = c[n]
         assert m["nr_fg_samples"] == c["reference_terms"]["nr_fg_samples"]          # same rays, same counts (bit-exact samplers)
@@ -127,6 +130,9 @@ def test_whole_step_within_the_reference_own_noise(parity, mode):
         assert st["same_count"] and st["same_ranges"], st
         assert st["identical"] >= 0.9 * st["of"] and st["max_abs_dz"] <= 1e-3, st
         assert m["loss_rel"] <= 1e-4, (n, m["loss_rel"])
+        if bars is None:
+            continue
+        bar_dense, bar_lat, bar_l2 = bars
         assert m["worst_dense"] <= max(bar_dense, 3 * noise["worst_dense"]), (n, m["worst_dense"], noise["worst_dense"])
         assert m["worst_lattice"] <= max(bar_lat, 3 * noise["worst_lattice"]), (n, m["worst_lattice"], noise["worst_lattice"])
         assert m["worst_lattice_l2"] <= max(bar_l2, 3 * noise["worst_lattice_l2"]), (n, m["worst_lattice_l2"])

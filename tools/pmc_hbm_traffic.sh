@@ -49,6 +49,14 @@ doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (
                      "FETCH_SIZE as reported (fetch_correction = 1: its raw value equals 8 XCDs x the table bytes + the positions); "
                      "WRITE_SIZE calibrated exact on encode_fwd (294912 KiB = 36*2097152*4 B)",
        "kernels": {n: v for n, v in res.items() if v}}
+# provenance: hash of the kernel sources the counters were taken from; bench.py quotes `traffic` only while it still matches
+import hashlib, os
+csrc = os.path.join(os.environ["GRAFT_REPO_ROOT"], "permuto_sdf_amd", "csrc")
+h = hashlib.sha256()
+for f in sorted(os.listdir(csrc)):
+    if f.endswith((".hip", ".h")):
+        h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+doc["csrc_sha256"] = h.hexdigest()
 json.dump(doc, open(out + ".json", "w"), indent=1)
 print(json.dumps(doc["kernels"], indent=1))
 PY
