@@ -59,6 +59,11 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
     float points_scaling, const float* grad_sliced, float* grad_lattice, float* grad_positions, void* workspace,
     int64_t workspace_bytes, void* stream);
+/* debug query: how the last balanced binning launch of psdf_encode_backward_ws dealt its resident round of workgroups over the
+   levels (counts[0 .. nr_levels)); returns nr_levels, 0 when no balanced launch has run.  Shares follow the measured duration
+   of each level's workgroups in the previous call (PSDF_ENC_BWD_BALANCE=0: equal shares); closed levels fall to the minimum. */
+int psdf_encode_backward_level_shares(int* counts, int max_levels);
+
 
 /* replaces: permutohedral_encoding `double_backward_from_positions_gpu` (create_graph=True at models.py:245-251) */
 int psdf_encode_double_backward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float*

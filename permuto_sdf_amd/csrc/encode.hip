@@ -16,6 +16,8 @@
 #include <cstdio>
 #include "encode_device.h"
 #include <vector>
+#include <mutex>
+#include <cstring>
 
 namespace {
 
@@ -386,6 +388,18 @@ __device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, in
 // when the pointer is NULL).  grad_sliced2 (optional): the PLAIN backward's scatter of a second upstream gradient rides along,
 // row_r += w (q_r g + bary_r g2) -- a training step scatters both onto the same rows of the same simplices (the double backward
 // of the normals and the backward of the features), so one simplex, one run combine, one queue pass and one reduce serve both.
+// Workgroups per level (round 5).  The launch is ONE resident round of workgroups, and with an equal share per level the
+// coarse levels (everything absorbed by the LDS cache) were done in half the time of the fine ones (everything queued): level
+// durations 0.29 .. 0.55 ms inside a 0.57-ms kernel (profiles/r03_enc_profile_levels.txt), closed levels of a coarse-to-fine
+// window holding their share for nothing.  With a plan (n > 0) the grid is one-dimensional, workgroup i serves the level whose
+// range [first[l], first[l + 1]) holds it, and it reports its duration (100-MHz ticks, tagged with the launch's generation)
+// into host-mapped memory; the host re-deals the round in proportion to count x duration at the next call (encode_balance).
+struct LevelPlan {
+  int n;                    // 0: rectangular grid (blockIdx.y = level)
+  uint32_t gen;             // low 8 bits tag the entries of `times`
+  uint32_t* times;          // [workgroups] or NULL
+  uint16_t first[42];
+};
 template <int P, int F, bool LATTICE, bool POS, bool QUEUE, bool DBL = false>
 #if !defined(PSDF_ENC_QWAVES)
 #define PSDF_ENC_QWAVES 5
@@ -397,18 +411,35 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
                       const float* __restrict__ grad_sliced, float* __restrict__ grad_lattice,
                       float* __restrict__ grad_positions, Queues Q, const float* __restrict__ dd_positions = nullptr,
                       float* __restrict__ grad_grad_sliced = nullptr, int pad_points = 0,
-                      const float* __restrict__ grad_sliced2 = nullptr) {
+                      const float* __restrict__ grad_sliced2 = nullptr, LevelPlan plan = LevelPlan{}) {
   static_assert(!(DBL && POS), "the double backward has no position output");
   extern __shared__ __align__(16) float lds[];
 #if defined(PSDF_ENC_PROFILE)
   const long long psdf_prof_t0 = (long long)wall_clock64();
 #endif
-  const int level = blockIdx.y;
+  int level = blockIdx.y, bx = blockIdx.x, gx = gridDim.x;
+  long long plan_t0 = 0;
+  if (plan.n) {
+    level = 0;
+    for (int l = 1; l < plan.n; l++)
+      if ((int)blockIdx.x >= (int)plan.first[l]) level = l;
+    bx = (int)blockIdx.x - (int)plan.first[level];
+    gx = (int)plan.first[level + 1] - (int)plan.first[level];
+    plan_t0 = (long long)wall_clock64();
+  }
+  // duration of this workgroup, for the host's next deal (at least 1 tick: 0 means "not written")
+  auto plan_report = [&]() {
+    if (plan.n && plan.times && threadIdx.x == 0) {
+      long long dt = (long long)wall_clock64() - plan_t0;
+      dt = dt < 1 ? 1 : (dt > 0xFFFFFF ? 0xFFFFFF : dt);
+      __hip_atomic_store(plan.times + blockIdx.x, ((plan.gen & 255u) << 24) | (uint32_t)dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  };
   const int64_t ntiles = (N + PSDF_BLOCK - 1) / PSDF_BLOCK;
   if (level >= L) {
     if (DBL) {   // concatenated-point channels: grad_g = u_d * points_scaling
       const int e = level - L;
-      for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      for (int64_t tile = bx; tile < ntiles; tile += gx) {
         const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
         if (n >= N) continue;
         float u[P];
@@ -426,7 +457,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
     }
     if (POS) {
       const int e = level - L;
-      for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      for (int64_t tile = bx; tile < ntiles; tile += gx) {
         const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
         if (n >= N) continue;
 #pragma unroll
@@ -437,17 +468,19 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
         }
       }
     }
+    plan_report();
     return;
   }
   if (window[level] == 0.f) {   // closed level (workgroup-uniform, before any barrier): every contribution carries the factor 0
     if (DBL && grad_grad_sliced) {
-      for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      for (int64_t tile = bx; tile < ntiles; tile += gx) {
         const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
         if (n >= N) continue;
 #pragma unroll
         for (int f = 0; f < F; f++) grad_grad_sliced[((int64_t)level * F + f) * N + n] = 0.f;
       }
     }
+    plan_report();
     return;
   }
   using SCache = ScatterCache<F, QUEUE ? 4096 : 8192>;
@@ -472,7 +505,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
   constexpr int SPT = QUEUE ? QUEUE_SPT : 1;
   constexpr int NC = SPT * (P + 1);
   const int64_t ntiles_w = (N + (int64_t)PSDF_BLOCK * SPT - 1) / ((int64_t)PSDF_BLOCK * SPT);
-  for (int64_t tile = blockIdx.x; tile < ntiles_w; tile += gridDim.x, iter++) {
+  for (int64_t tile = bx; tile < ntiles_w; tile += gx, iter++) {
     uint32_t crow[NC];
     float cval[NC][F];
     bool pending[NC];
@@ -641,6 +674,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
   }
   // (a cache that was switched off in queue mode has been drained and its LDS re-used: nothing to flush)
   if (LATTICE && !(QUEUE && !use_cache)) sc.flush(grad_lattice + tbase);
+  plan_report();
 #if defined(PSDF_ENC_PROFILE)
   if (QUEUE && threadIdx.x == 0) {   // per-level duration of the workgroups (wall clock ticks), into the tail of the queue counters
     const long long dt = (long long)wall_clock64() - psdf_prof_t0;
@@ -1096,8 +1130,9 @@ static bool queue_plan(int pos_dim, int nr_feat, int64_t N, int nr_levels, int c
   // workgroups per CU) instead of the 128 KiB that fit: the coarse levels' queues are nearly empty, so with one workgroup per
   // (level, partition) and 16 partitions only half the CUs had work (16 levels: reduce + binning 0.966 -> 0.905 ms with 32).
   const int base = (nr_feat <= 2) ? 14 : (nr_feat <= 4 ? 13 : 12);   // rows/partition * F * 4 B <= 128 KiB
-  int shift = base - 1;
-  if (((capacity + (1 << shift) - 1) >> shift) > Q_MAX_PARTS) shift = base;   // very large tables: keep the partition count
+  static const int delta = getenv("PSDF_ENC_QUEUE_SLICE_LOG2_DELTA") ? atoi(getenv("PSDF_ENC_QUEUE_SLICE_LOG2_DELTA")) : 1;   // A/B switch
+  int shift = base - (delta < 0 ? 0 : (delta > 3 ? 3 : delta));
+  while (shift < base && ((capacity + (1 << shift) - 1) >> shift) > Q_MAX_PARTS) shift++;   // large tables: keep the partition count
   const int rpp = 1 << shift;
   const int np = (capacity + rpp - 1) / rpp;
   if (np > Q_MAX_PARTS || rpp * nr_feat * 4 > 128 * 1024) return false;
@@ -1154,6 +1189,150 @@ static int device_cus() {
   return cus[dev];
 }
 
+}  // extern "C"
+
+// The deal of one resident round of binning workgroups over the levels (see LevelPlan).  State of the previous call per process:
+// the plan it launched with and the host-mapped array its workgroups report their durations into (two arrays, used alternately,
+// entries tagged with the call's generation: a call never reads what an older or an unfinished launch wrote as if it were the
+// previous one's).  share_l <- 1/2 share_l + 1/2 (count_l x mean duration_l) / sum: a level whose workgroups ran longer gets
+// more of them next time; a closed level (its workgroups return at once) falls to the minimum.  PSDF_ENC_BWD_BALANCE=0: equal shares.
+namespace {
+struct EncBalance {
+  int levels = 0, total = 0, kind = 0, bucket = -1;
+  const void* ident = nullptr;   // the lattice the launches belong to (encodings of one shape have different cost profiles)
+  uint32_t gen = 0;
+  uint64_t last_use = 0;
+  std::vector<int> counts;
+  uint32_t* times[2] = {nullptr, nullptr};
+};
+constexpr int BAL_MAX_WG = 8192, BAL_MIN_PER_LEVEL = 4, BAL_STATES = 16;
+std::mutex g_shares_mu;
+std::vector<int> g_last_shares;
+
+// returns false when the plan cannot be used (equal shares through the rectangular grid then).  kind: 0 backward, 1 double
+// backward.  One state per (lattice, kind, levels, size class of N: quarter octaves, round size) -- a training step alternates between
+// several shapes and its sample count moves a little from step to step --, at most BAL_STATES of them (least recently used
+// one is re-used).
+bool encode_balance(int nr_levels, int64_t N, int total, int64_t super_tiles, LevelPlan& plan, const void* ident, int kind = 0) {
+  static const bool off = getenv("PSDF_ENC_BWD_BALANCE") && atoi(getenv("PSDF_ENC_BWD_BALANCE")) == 0;
+  static std::mutex mu;
+  static EncBalance states[BAL_STATES];
+  static uint64_t tick = 0;
+  // (batches below 2^18 points: a training step's 49 152 samples have fewer super-tiles per level than a level's equal share of
+  // the round, and the measured effect is inside the run-to-run noise, 449 / 447 it/s with against 471 / 438 without: off)
+  if (off || nr_levels > 40 || total > BAL_MAX_WG || total < nr_levels * BAL_MIN_PER_LEVEL || N < ((int64_t)1 << 18)) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  int bucket = 0;
+  for (int64_t v = N; v > 1; v >>= 1) bucket += 4;
+  {
+    const int64_t top = (int64_t)1 << (bucket / 4);
+    bucket += (int)(((N - top) * 4) / top);
+  }
+  EncBalance* Bp = nullptr;
+  for (auto& st_ : states)
+    if (st_.times[0] && st_.ident == ident && st_.kind == kind && st_.levels == nr_levels && st_.bucket == bucket && st_.total == total) Bp = &st_;
+  if (!Bp) {
+    for (auto& st_ : states)
+      if (!Bp || st_.last_use < Bp->last_use) Bp = &st_;
+    if (!Bp->times[0]) {
+      for (int i = 0; i < 2; i++) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, BAL_MAX_WG * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess || !h) {
+          (void)hipGetLastError();
+          if (i == 1) (void)hipHostFree(Bp->times[0]);
+          Bp->times[0] = Bp->times[1] = nullptr;
+          return false;
+        }
+        Bp->times[i] = (uint32_t*)h;
+      }
+    }
+    memset(Bp->times[0], 0, BAL_MAX_WG * sizeof(uint32_t));     // (a launch of the state's previous owner may still write: its
+    memset(Bp->times[1], 0, BAL_MAX_WG * sizeof(uint32_t));     // entries carry an older generation tag and are ignored)
+    Bp->levels = 0;
+  }
+  EncBalance& B = *Bp;
+  B.last_use = ++tick;
+  if (!B.times[0] || !B.times[1]) return false;
+  const int cap = (int)(super_tiles < total ? super_tiles : total);       // more workgroups than super-tiles of a level: idle ones
+  if (B.levels != nr_levels || (int)B.counts.size() != nr_levels) {
+    B.levels = nr_levels;
+    B.kind = kind;
+    B.ident = ident;
+    B.bucket = bucket;
+    B.total = total;
+    B.counts.assign(nr_levels, total / nr_levels);
+  } else {
+    // what the previous call's workgroups reported (all of them, with its tag -- otherwise the launch is still running, or
+    // another shape ran in between: keep the deal)
+    const volatile uint32_t* t = B.times[B.gen & 1];
+    std::vector<double> work(nr_levels, 0.0);
+    bool complete = true;
+    int id = 0;
+    double sum = 0.0;
+    for (int l = 0; l < nr_levels && complete; l++) {
+      double acc = 0.0;
+      for (int b = 0; b < B.counts[l]; b++, id++) {
+        const uint32_t v = t[id];
+        if ((v >> 24) != (B.gen & 255u) || (v & 0xFFFFFFu) == 0u) {
+          complete = false;
+          break;
+        }
+        acc += (double)(v & 0xFFFFFFu);
+      }
+      work[l] = acc;       // = count x mean duration
+      sum += acc;
+    }
+    if (complete && sum > 0.0) {
+      std::vector<double> want(nr_levels);
+      for (int l = 0; l < nr_levels; l++) want[l] = 0.5 * B.counts[l] + 0.5 * total * work[l] / sum;
+      int used = 0;
+      for (int l = 0; l < nr_levels; l++) {
+        int c = (int)(want[l] + 0.5);
+        c = c < BAL_MIN_PER_LEVEL ? BAL_MIN_PER_LEVEL : (c > cap ? cap : c);
+        B.counts[l] = c;
+        used += c;
+      }
+      // never more than one resident round: take the excess from the largest shares
+      while (used > total) {
+        int big = 0;
+        for (int l = 1; l < nr_levels; l++)
+          if (B.counts[l] > B.counts[big]) big = l;
+        if (B.counts[big] <= BAL_MIN_PER_LEVEL) break;
+        B.counts[big]--;
+        used--;
+      }
+    }
+  }
+  B.gen++;
+  plan.n = nr_levels;
+  plan.gen = B.gen;
+  plan.times = B.times[B.gen & 1];
+  int at = 0;
+  for (int l = 0; l < nr_levels; l++) {
+    if (B.counts[l] > cap) B.counts[l] = cap;
+    if (B.counts[l] < 1) B.counts[l] = 1;
+    plan.first[l] = (uint16_t)at;
+    at += B.counts[l];
+  }
+  plan.first[nr_levels] = (uint16_t)at;
+  {
+    std::lock_guard<std::mutex> l2(g_shares_mu);
+    g_last_shares = B.counts;
+  }
+  return at <= BAL_MAX_WG;
+}
+}  // namespace
+
+extern "C" {
+
+// the deal of the last balanced launch (debug query): counts[0 .. nr_levels), returns nr_levels (0: none yet)
+int psdf_encode_backward_level_shares(int* counts, int max_levels) {
+  std::lock_guard<std::mutex> lock(g_shares_mu);
+  const int n = (int)g_last_shares.size();
+  for (int l = 0; l < n && l < max_levels; l++) counts[l] = g_last_shares[l];
+  return n;
+}
+
 int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
                             const float* lattice, const float* scale_factor, const float* shifts, const float* window,
                             int concat_points, float points_scaling, const float* grad_sliced, float* grad_lattice,
@@ -1195,8 +1374,16 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
 // size of a whole walk: measured on the bench batch (2 M points; 3 workgroups fit a CU, 768 in all) 16 levels x 48 = 768
 // workgroups 0.96 ms, x 40 1.09, x 56 1.26 (just over one round), x 96 (two rounds) 1.03, x 128 1.10; 24 levels x 32 best.
 // (Those figures are from the 3-workgroups-per-CU state of the kernel; 5 fit now -- 80 per level at 16 levels -- by the same rule.)
+#define BWD_PLAN(P_, F_)                                                                                          \
+  hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, true, false, true>), dim3(plan.first[nr_levels]), dim3(PSDF_BLOCK), \
+                     (ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int)), st, N, nr_levels,    \
+                     (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, \
+                     points_scaling, grad_sliced, grad_lattice, (float*)nullptr, Q, (const float*)nullptr,          \
+                     (float*)nullptr, 0, (const float*)nullptr, plan)
 #define BWD_PF(P_, F_)                                                                                           \
   do {                                                                                                           \
+    LevelPlan plan{};                                                                                            \
+    bool balanced = false;                                                                                       \
     if (use_queue) {                                                                                             \
       int per_cu = 0;                                                                                            \
       const size_t shm = ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                  \
@@ -1210,6 +1397,9 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
         const int64_t super_tiles = (N + (int64_t)PSDF_BLOCK * QUEUE_SPT - 1) / ((int64_t)PSDF_BLOCK * QUEUE_SPT); \
         if (gx > super_tiles) gx = super_tiles;                                                                  \
         grid.x = (unsigned)(gx < 1 ? 1 : gx);                                                                    \
+        /* lattice-only binning launches: the round is dealt over the levels by their measured cost */           \
+        if (!(grad_positions && pos_fused))                                                                      \
+          balanced = encode_balance(nr_levels, N, per_cu * device_cus(), super_tiles, plan, lattice);                     \
       } else {                                                                                                   \
         (void)hipGetLastError();                                                                                 \
       }                                                                                                          \
@@ -1219,14 +1409,15 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
       /* kernel for the positions -- the fused form adds the position gradient with float atomics from inside the */ \
       /* binning kernel: +0.98 ms at 2 M points x 16 levels against 0.63 ms for the separate kernel (round 4) */   \
       grid.y = nr_levels;                                                                                        \
-      BWD(P_, F_, true, false, true);                                                                            \
+      if (balanced) BWD_PLAN(P_, F_); else BWD(P_, F_, true, false, true);                                       \
       launch_bwd_pos<P_, F_>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window,        \
                              points_scaling, pad_points(concat_points), grad_sliced, (const unsigned char*)nullptr, \
                              grad_positions, st);                                                                 \
     } else if (use_queue && grad_positions)                                                                      \
       BWD(P_, F_, true, true, true);                                                                             \
-    else if (use_queue)                                                                                          \
-      BWD(P_, F_, true, false, true);                                                                            \
+    else if (use_queue) {                                                                                        \
+      if (balanced) BWD_PLAN(P_, F_); else BWD(P_, F_, true, false, true);                                       \
+    }                                                                                                            \
     else if (grad_lattice && grad_positions)                                                                     \
       BWD(P_, F_, true, true, false);                                                                            \
     else if (grad_lattice)                                                                                       \
@@ -1255,6 +1446,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   else
     return PSDF_ERR_UNSUPPORTED;
 #undef BWD_PF
+#undef BWD_PLAN
 #undef BWD
   psdf::g_last_path[psdf::PATH_ENCODE_BWD] = use_queue ? 2 : (grad_lattice ? 1 : 3);
 #if defined(PSDF_ENC_PROFILE)
@@ -1356,10 +1548,16 @@ int psdf_encode_double_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_l
       (void)hipGetLastError();                                                                                           \
     const int64_t super_tiles = (N + (int64_t)PSDF_BLOCK * QUEUE_SPT - 1) / ((int64_t)PSDF_BLOCK * QUEUE_SPT);           \
     if (gx > super_tiles) gx = super_tiles;                                                                              \
-    hipLaunchKernelGGL(kern, dim3((unsigned)(gx < 1 ? 1 : gx), Lt), dim3(PSDF_BLOCK), shm, st, N, nr_levels,             \
+    /* the round dealt over the levels by their measured cost (the concatenated-point channels are levels of the deal): */ \
+    /* a training step's coarse-to-fine window leaves levels closed, whose workgroups return at once */                   \
+    LevelPlan plan{};                                                                                                    \
+    dim3 g2((unsigned)(gx < 1 ? 1 : gx), Lt);                                                                            \
+    if (per_cu > 0 && encode_balance(Lt, N, per_cu * device_cus(), super_tiles, plan, lattice, 1)) g2 = dim3(plan.first[Lt]);       \
+    else plan = LevelPlan{};                                                                                             \
+    hipLaunchKernelGGL(kern, g2, dim3(PSDF_BLOCK), shm, st, N, nr_levels,                                                \
                        (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,     \
                        points_scaling, grad_sliced, grad_lattice, (float*)nullptr, Q, dd_positions, grad_grad_sliced,    \
-                       pad_points(concat_points), grad_sliced_direct);                                                   \
+                       pad_points(concat_points), grad_sliced_direct, plan);                                             \
     const size_t lds_b = (size_t)(1 << Q.shift) * F_ * sizeof(float);                                                    \
     hipError_t e2 = hipFuncSetAttribute((const void*)encode_bwd_reduce_kernel<F_>,                                       \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);                         \
