@@ -4,7 +4,9 @@ Two back-ends with the same numpy call surface:
   * ``Oracle("port")``: oracle/libpsdf_oracle.so, our plain-C restatement (oracle/psdf_oracle.c), always buildable
     with gcc (``build()`` does it on demand);
   * ``Oracle("ref")``:  oracle/_ref/libpsdf_ref.so, the REFERENCE's own kernel headers compiled for the CPU
-    (``make -C oracle ref``; only where /root/reference exists, the built .so travels to the GPU box).
+    (``make -C oracle ref``; only where /root/reference exists, the built .so travels to the GPU box);
+  * ``Oracle("ref_fma")``: the same headers built with floating-point contraction on (``make -C oracle ref_fma``), the
+    way nvcc builds them by default -- used only by tools/fma_contraction_gap.py to COUNT what contraction changes.
 Every method takes / returns numpy arrays (float32 / int32 / bool) and mirrors one reference kernel launch
 including the host-side allocation semantics of src/*.cu (zeros / ones / empty initial values).
 """
@@ -17,6 +19,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_LIB = os.path.join(HERE, "libpsdf_oracle.so")
 REF_LIB = os.path.join(HERE, "_ref", "libpsdf_ref.so")
+REF_FMA_LIB = os.path.join(HERE, "_ref", "libpsdf_ref_fma.so")     # the same headers, floating-point contraction on (Makefile)
 PCG_STATE = 0x853C49E6748FEA9B
 PCG_INC = 0xDA3E39CB94B95BDB
 
@@ -89,6 +92,14 @@ class Oracle:
             if not have_ref():
                 raise FileNotFoundError(REF_LIB)
             self.lib = ctypes.CDLL(REF_LIB)
+            self.pre = "ref_"
+        elif kind == "ref_fma":
+            if not os.path.exists(REF_FMA_LIB):
+                if os.path.isdir("/root/reference/kernels"):
+                    subprocess.run(["make", "-C", HERE, "ref_fma"], check=True, stdout=subprocess.DEVNULL)
+                else:
+                    raise FileNotFoundError(REF_FMA_LIB)
+            self.lib = ctypes.CDLL(REF_FMA_LIB)
             self.pre = "ref_"
         else:
             raise ValueError(kind)
@@ -296,7 +307,7 @@ class Oracle:
     # ---- volume rendering; s is a Samples
     def _head(self, s):
         M = len(s.z)
-        return (c_i(s.R),) + ((c_i(M),) if self.kind == "ref" else ()) + s.ri()
+        return (c_i(s.R),) + ((c_i(M),) if self.kind != "port" else ()) + s.ri()
 
     def volume_render_nerf(self, s, rgb, sigma):
         rgb, sigma = f32(rgb), f32(sigma).reshape(-1, 1)
