@@ -1011,11 +1011,17 @@ EncConv& enc_conv_state() {
 template <int P_, int F_, int POS_LPB>
 static void launch_bwd_pos_lpb(int64_t N, int nr_levels, int Lt, int capacity, const float* positions, const float* lattice,
                                const float* scale_factor, const float* shifts, const float* window, float points_scaling, int pad,
-                               const float* grad_sliced, const unsigned char* skip, float* grad_positions, hipStream_t st) {
+                               const float* grad_sliced, const unsigned char* skip, float* grad_positions, hipStream_t st,
+                               bool capturing) {
   static const bool force_atomics = getenv("PSDF_ENC_POS_ATOMICS") && atoi(getenv("PSDF_ENC_POS_ATOMICS")) != 0;
   const unsigned nb = psdf_blocks(N, PSDF_BLOCK);
   const int groups = (Lt + POS_LPB - 1) / POS_LPB;
-  float* slabs = (groups > 1 && !force_atomics) ? (float*)psdf::stream_scratch((size_t)groups * N * P_ * sizeof(float), st) : nullptr;
+  // The slabs are per-stream scratch that is never handed back: capped (PSDF_ENC_POS_SLAB_MAX_MB, default 256 MiB = 1.7 M points
+  // at 24 + 2 levels) -- a multi-million-sample render pass takes the float-atomic form (same time, profiles/r04_enc_ab.jsonl:
+  // what the slabs buy is run-to-run identical normals, which matters to the training step's curvature term at its 49 K samples)
+  static const size_t slab_cap = (size_t)(getenv("PSDF_ENC_POS_SLAB_MAX_MB") ? atoll(getenv("PSDF_ENC_POS_SLAB_MAX_MB")) : 256) << 20;
+  const size_t slab_bytes = (size_t)groups * N * P_ * sizeof(float);
+  float* slabs = (groups > 1 && !force_atomics && !capturing && slab_bytes <= slab_cap) ? (float*)psdf::stream_scratch(slab_bytes, st) : nullptr;
   if (slabs) {
     hipLaunchKernelGGL((encode_bwd_pos_kernel<P_, F_, true, POS_LPB>), dim3(nb, groups), dim3(PSDF_BLOCK), 0, st, N, nr_levels, Lt,
                        (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window,
@@ -1033,15 +1039,18 @@ template <int P_, int F_>
 static void launch_bwd_pos(int64_t N, int nr_levels, int Lt, int capacity, const float* positions, const float* lattice,
                            const float* scale_factor, const float* shifts, const float* window, float points_scaling, int pad,
                            const float* grad_sliced, const unsigned char* skip, float* grad_positions, hipStream_t st) {
-  if (psdf::stream_scratch(16, st) == nullptr)     // stream capture (the sphere tracer's graph): float atomics, as measured in round 2
+  // (the capture state is probed once per launch: while a graph is being captured -- the sphere tracer's -- there is no
+  // stream-ordered scratch and the float-atomic form runs, as measured in round 2)
+  const bool capturing = psdf::stream_scratch(16, st) == nullptr;
+  if (capturing)
     launch_bwd_pos_lpb<P_, F_, 4>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window, points_scaling,
-                                  pad, grad_sliced, skip, grad_positions, st);
+                                  pad, grad_sliced, skip, grad_positions, st, true);
   else if (N >= ((int64_t)1 << 17))
     launch_bwd_pos_lpb<P_, F_, 2>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window, points_scaling,
-                                  pad, grad_sliced, skip, grad_positions, st);
+                                  pad, grad_sliced, skip, grad_positions, st, false);
   else
     launch_bwd_pos_lpb<P_, F_, 8>(N, nr_levels, Lt, capacity, positions, lattice, scale_factor, shifts, window, points_scaling,
-                                  pad, grad_sliced, skip, grad_positions, st);
+                                  pad, grad_sliced, skip, grad_positions, st, false);
 }
 
 extern "C" {

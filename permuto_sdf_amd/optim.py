@@ -40,6 +40,21 @@ class FusedAdamW(torch.optim.Optimizer):
         for p in getattr(self, "_touched", {}):
             self._rebuild_active(p)
 
+    def state_dict(self, allow_partial=False):
+        """Under the sharded data-parallel update (step(owned=...), parallel.ShardedUpdate) a rank holds the moments of the
+        ranges it owns and ZEROS elsewhere: saving that as it is and resuming -- on one rank, with another world size, or in
+        replicated mode -- would silently restart most of the table from zero moments.  So it is refused: use
+        `parallel.consolidated_state_dict(optimizer)` (a sum over the ranks of the moments of the sharded parameters: every
+        element has exactly one owner) or pass allow_partial=True for this rank's partial view."""
+        sharded = getattr(self, "_sharded_params", None)
+        if sharded and not allow_partial:
+            from . import parallel
+            if parallel.world_size() > 1:
+                raise L.PsdfError("FusedAdamW.state_dict(): %d parameter(s) are updated sharded over %d ranks -- this rank holds only "
+                                  "its own ranges' moments; save parallel.consolidated_state_dict(optimizer) instead"
+                                  % (len(sharded), parallel.world_size()))
+        return super().state_dict()
+
     @torch.no_grad()
     def step(self, grad_scale=1.0, owned=None):
         """owned (data parallel, parallel.ShardedUpdate): {param: [(lo, hi), ...]} -- element ranges of the FLAT parameter that
@@ -49,6 +64,10 @@ class FusedAdamW(torch.optim.Optimizer):
         aligned (touched-rows parameters: block aligned).  Moments of ranges a rank never owns stay zero and are never read."""
         import ctypes
         owned = owned or {}
+        if owned:
+            if not hasattr(self, "_sharded_params"):
+                self._sharded_params = set()
+            self._sharded_params.update(owned.keys())
         self.generation += 1
         for group in self.param_groups:
             b1, b2 = group["betas"]

@@ -453,3 +453,37 @@ def allreduce_module_grads(modules, buckets=None):
     if own:
         buckets.finish()
     return buckets
+
+
+def consolidated_state_dict(optimizer):
+    """state_dict of an optimiser whose large parameters are updated sharded (ShardedUpdate): the moments of those parameters
+    summed over the ranks -- a rank's moments outside the ranges it owns are zero and every element has exactly one owner, so the
+    sum IS the full state -- in a copy (the live state keeps its sharded form: a later consolidation must not add gathered copies
+    to the owners' values).  Collective: call it on every rank; every rank returns the same dict.  Without sharded parameters or
+    with one rank it is optimizer.state_dict()."""
+    sd = optimizer.state_dict(allow_partial=True) if "allow_partial" in optimizer.state_dict.__code__.co_varnames else optimizer.state_dict()
+    sharded = getattr(optimizer, "_sharded_params", None)
+    if not sharded or world_size() <= 1 or _loopback is not None:
+        return sd
+    # param -> index in the state dict (torch numbers parameters in group order)
+    index, i = {}, 0
+    for g in optimizer.param_groups:
+        for p in g["params"]:
+            index[p] = i
+            i += 1
+    state = dict(sd["state"])
+    for p in sorted(sharded, key=lambda q: index[q]):
+        st = dict(state[index[p]])
+        for k in ("exp_avg", "exp_avg_sq"):
+            t = st[k].detach().clone()
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+            st[k] = t
+        state[index[p]] = st
+    sd = dict(sd)
+    sd["state"] = state
+    return sd

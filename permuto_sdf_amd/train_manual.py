@@ -94,10 +94,23 @@ class ManualTrainer(Trainer):
         return self._side
 
     # ------------------------------------------------------------------ next step's sampling, first half, ahead of time
-    def _prefetch_valid(self, git):
+    def _prefetch_valid(self, git, reel=None):
+        """reel: the image reel the coming step samples from (None: not checked).  A prefetch drawn from ANOTHER reel must be
+        dropped by the step's own validity test too -- step() skips its seeding on the strength of this answer."""
         pf = self._prefetched
         return (pf is not None and pf["git"] == git and pf["nr_rays"] == self.nr_rays and self._hand_written_step_applies()
+                and (reel is None or pf["reel"] == id(reel))
                 and "_draw_rays" not in self.__dict__ and "_samples" not in self.__dict__)
+
+    def _drop_prefetch(self):
+        """A prefetch that does not fit the coming step is undone as far as the random streams go: the jitter generators
+        (process-global PCG32 streams of the occupancy grid / ray sampler / volume renderer, advanced once by the prefetched
+        launches) return to their state before it.  The caller re-seeds torch's generators for its iteration."""
+        pf, self._prefetched = self._prefetched, None
+        if pf is not None and pf.get("pcg") is not None:
+            from .bridge import OccupancyGrid, RaySampler, VolumeRendering
+            for cls, (st, inc) in zip((OccupancyGrid, RaySampler, VolumeRendering), pf["pcg"]):
+                cls._rng.state, cls._rng.inc = st, inc
 
     def _launch_prefetch(self, reel, next_git):
         """The march is the largest kernel of the step (0.21 ms) and runs on 12 waves: nothing it needs -- the grid, the image
@@ -122,13 +135,15 @@ class ManualTrainer(Trainer):
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
+        from .bridge import OccupancyGrid, RaySampler, VolumeRendering
+        pcg = [(c._rng.state, c._rng.inc) for c in (OccupancyGrid, RaySampler, VolumeRendering)]     # (see _drop_prefetch)
         parallel.seed_generators(parallel.step_seed(self._seed, parallel.rank(), next_git), self.dev)
         with torch.cuda.stream(side), torch.no_grad():
             rays = self._draw_rays(reel)
             begun = self._samples_begin(rays[0], rays[1], True)
             done = torch.cuda.Event()
             done.record(side)
-        self._prefetched = dict(git=next_git, nr_rays=self.nr_rays, reel=id(reel), rays=rays, begun=begun, done=done)
+        self._prefetched = dict(git=next_git, nr_rays=self.nr_rays, reel=id(reel), rays=rays, begun=begun, done=done, pcg=pcg)
 
     def _hand_written_step_applies(self):
         """The hand-written step is built on the fused compositing kernels (at most 256 samples per ray: foreground
@@ -241,12 +256,13 @@ class ManualTrainer(Trainer):
         side_ctx = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
         with torch.no_grad():
             begun = None
-            if self._prefetch_valid(git) and self._prefetched["reel"] == id(reel):
+            if self._prefetch_valid(git, reel):
                 pf, self._prefetched = self._prefetched, None
                 main.wait_event(pf["done"])
                 (o, d, gt, hit, img_idx, _), begun = pf["rays"], pf["begun"]
             else:
-                self._prefetched = None
+                # (step() has seeded this iteration itself in that case: it asks the same question with the same reel)
+                self._drop_prefetch()
                 o, d, gt, hit, img_idx, _ = self._draw_rays(reel)
             R = o.shape[0]
             cc = self.colorcal

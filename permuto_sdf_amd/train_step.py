@@ -409,8 +409,8 @@ class Trainer:
         # per-rank random streams for rays/jitter, one shared stream for the grid refresh
         self._seed = seed + 1
 
-    def _prefetch_valid(self, git):
-        """True when the first half of iteration `git`'s sampling has already been issued (train_manual.ManualTrainer)"""
+    def _prefetch_valid(self, git, reel=None):
+        """True when the first half of iteration `git`'s sampling (from `reel`) has already been issued (train_manual.ManualTrainer)"""
         return False
 
     def _param_key(self):
@@ -595,7 +595,9 @@ class Trainer:
         n0 = int(hp.nr_iter_sphere_fit) if self.reference_schedule else 0
         in_sphere_init = git < n0
         it = git if in_sphere_init else git - n0                      # iter_nr_for_anneal (permuto_sdf_utils.py:80-88)
-        if not self._prefetch_valid(git):     # (a prefetched step has been seeded, and its rays drawn, by the step before it)
+        if not self._prefetch_valid(git, reel):     # (a prefetched step has been seeded, and its rays drawn, by the step before it)
+            if hasattr(self, "_drop_prefetch"):
+                self._drop_prefetch()             # a prefetch for another iteration / reel: its jitter draws are rolled back
             parallel.seed_generators(parallel.step_seed(self._seed, parallel.rank(), git), self.dev)  # this rank's rays / jitter
         late = (not in_sphere_init) and it >= hp.iter_start_reduce_curv
         for group in self.opt.param_groups:

@@ -140,3 +140,41 @@ def test_single_process_is_a_noop():
     b.reduce([t])
     b.finish()
     assert torch.equal(t, torch.ones(4))
+
+
+def _consolidate_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from permuto_sdf_amd import parallel
+    parallel.init(backend="gloo")
+    n = 4096
+    big, small = torch.nn.Parameter(torch.zeros(n)), torch.nn.Parameter(torch.zeros(8))
+    opt = torch.optim.Adam([big, small], lr=1e-3)
+    lo, hi = parallel.shard_bounds(n, 4)
+    m, v = torch.zeros(n), torch.zeros(n)
+    m[lo:hi] = torch.arange(lo, hi, dtype=torch.float32) + 1.0           # the owner's moments; zero elsewhere (never written)
+    v[lo:hi] = (torch.arange(lo, hi, dtype=torch.float32) + 1.0) ** 2
+    opt.state[big] = {"step": torch.tensor(3.0), "exp_avg": m, "exp_avg_sq": v}
+    opt.state[small] = {"step": torch.tensor(3.0), "exp_avg": torch.full((8,), 0.5), "exp_avg_sq": torch.full((8,), 0.25)}
+    opt._sharded_params = {big}
+    sd = parallel.consolidated_state_dict(opt)
+    ret["m_%d" % rank] = sd["state"][0]["exp_avg"].numpy()
+    ret["v_%d" % rank] = sd["state"][0]["exp_avg_sq"].numpy()
+    ret["small_%d" % rank] = sd["state"][1]["exp_avg"].numpy()
+    ret["live_%d" % rank] = float(opt.state[big]["exp_avg"].abs().sum())   # the live state keeps its sharded form
+    ret["own_%d" % rank] = float(m.abs().sum())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_consolidated_state_dict_gathers_the_sharded_moments():
+    """parallel.consolidated_state_dict: the moments of a sharded parameter summed over the ranks (zero outside a rank's own
+    range, one owner per element) = the full state, on every rank, in a COPY; replicated parameters untouched."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_consolidate_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    full = np.arange(4096, dtype=np.float32) + 1.0
+    for r in range(world):
+        assert np.array_equal(ret["m_%d" % r], full) and np.array_equal(ret["v_%d" % r], full ** 2)
+        assert np.array_equal(ret["small_%d" % r], np.full(8, 0.5, np.float32))
+        assert ret["live_%d" % r] == ret["own_%d" % r]

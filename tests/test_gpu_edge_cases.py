@@ -75,3 +75,28 @@ def test_single_sample_backward_and_double_backward(dev):
     lin = [mod for mod in ref if isinstance(mod, torch.nn.Linear)]
     for a, b in zip(m.layers, lin):
         assert (a.weight.grad.double() - b.weight.grad).abs().max() <= 2e-4 * max(1e-9, float(b.weight.grad.abs().max()))
+
+
+def test_coarse2fine_window_host_evaluation_equals_the_device_formula():
+    """encoding.Coarse2Fine evaluates its 24-float cosine window on the HOST (one upload instead of five launches); the reference
+    (common_utils.py:51-62) and earlier rounds evaluate the same formula on the GPU.  Host libm and the device's cos may differ
+    in the last place: measured here over a sweep of t, bound 1.2e-7 absolute (one ulp of a value in [0.5, 1)), which is the
+    tolerance the bit-parity statements of the reference-step tests carry for the window."""
+    import math
+    import torch
+    from permuto_sdf_amd.encoding import Coarse2Fine
+    dev = torch.device("cuda:0")
+    worst, differing, total = 0.0, 0, 0
+    for L in (16, 24):
+        c2f = Coarse2Fine(L).to(dev)
+        for t in [i / 997.0 for i in range(0, 998, 7)] + [0.3, 1.0, 0.0]:
+            host = c2f(t)
+            alpha = torch.tensor(float(t) * L, dtype=torch.float32, device=dev)
+            x = torch.clamp(alpha - torch.arange(L, dtype=torch.float32, device=dev), 0.0, 1.0)
+            devw = 0.5 * (1.0 + torch.cos(math.pi * x + math.pi))
+            d = (host - devw).abs()
+            worst = max(worst, float(d.max()))
+            differing += int((d > 0).sum())
+            total += L
+    print("Coarse2Fine host vs device: %d of %d window values differ, worst %.2e" % (differing, total, worst))
+    assert worst <= 1.2e-7

@@ -240,3 +240,33 @@ def test_prefetched_sampling_draws_the_same_rays_and_samples(dev):
     for (ra, na, la), (rb, nb, lb) in zip(*runs):
         assert (ra, na) == (rb, nb), (runs[0], runs[1])
         assert abs(la - lb) <= 2e-3 * max(1.0, abs(la)), (la, lb)
+
+
+def test_prefetch_for_another_reel_is_rolled_back(dev):
+    """a step that finds a prefetch drawn from ANOTHER image reel drops it -- and must then be exactly the step a
+    trainer without prefetch takes: torch's generators seeded for its own iteration, the PCG jitter streams back where they were
+    before the dropped prefetch advanced them.  Two reels, switched mid-run: ray counts, sample counts and losses of the runs
+    with and without prefetch agree."""
+    import copy
+    from permuto_sdf_amd.bridge import OccupancyGrid, RaySampler, VolumeRendering
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    from permuto_sdf_amd.train_step import HyperParams, SyntheticReel
+    reels = [SyntheticReel(dev, nr_images=4, height=60, width=80), SyntheticReel(dev, nr_images=3, height=48, width=64)]
+    owners = (OccupancyGrid, RaySampler, VolumeRendering)
+    saved = [copy.deepcopy(c._rng) for c in owners]
+    runs = []
+    for prefetch in (False, True):
+        for c, r in zip(owners, saved):
+            c._rng = copy.deepcopy(r)
+        hp = HyperParams()
+        hp.nr_rays, hp.target_nr_of_samples = 256, 256 * 96
+        tr = ManualTrainer(dev, hp)
+        tr.prefetch_sampling = prefetch
+        rec = []
+        for i in range(12):
+            loss = float(tr.step(reels[(i // 3) % 2]))          # the reel changes every third step
+            rec.append((tr.last["nr_rays"], tr.last["nr_fg_samples"], loss))
+        runs.append(rec)
+    for (ra, na, la), (rb, nb, lb) in zip(*runs):
+        assert (ra, na) == (rb, nb), (runs[0], runs[1])
+        assert abs(la - lb) <= 2e-3 * max(1.0, abs(la)), (la, lb)
