@@ -297,6 +297,13 @@ int psdf_adamw_step_multi(int n_tensors, const int64_t* sizes, float* const* par
 int psdf_adamw_step_blocks(int64_t n_blocks, int block_elems, float* param, float* grad, float* exp_avg, float*
     exp_avg_sq, unsigned char* touched, unsigned char* active, float lr, float beta1, float beta2, float eps, int step,
     float grad_scale, int zero_grad, void* stream);
+/* psdf_adamw_step_blocks for up to 8 tensors in ONE launch: host arrays [n_tensors] of block counts, block sizes, device pointers
+   and per-tensor lr / beta1 / beta2 / eps / step (the lattices of a training step sit in different parameter groups). */
+int psdf_adamw_step_blocks_multi(int n_tensors, const int64_t* n_blocks, const int* block_elems, float* const* params,
+    float* const* grads, float* const* exp_avgs, float* const* exp_avg_sqs, unsigned char* const* touched,
+    unsigned char* const* active, const float* lr, const float* beta1, const float* beta2, const float* eps, const int* step,
+    float grad_scale, int zero_grad, void* stream);
+
 
 /* ---- sampling.hip ---- */
 /* replaces: OccupancyGrid::compute_grid_points / compute_random_sample_of_grid_points, src/OccupancyGrid.cu:88-117,179-208 */

@@ -38,6 +38,7 @@
 // -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize (build.py).
 #include "psdf_common.h"
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -1155,6 +1156,593 @@ __global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
 }
 
 // Sum of the workgroup images, accumulated into the torch-layout gradients (dW_l [out, in], db_l)
+// ====================================================================================== chain / dW wave pairs (round 5, second form)
+// The N-split pair above halves a wave's independent work per layer; this form keeps the layers whole and cuts the WORK LIST
+// instead: a CHAIN wave (forward recompute, activation derivatives, the dH chain, dX: everything on the tile's dependency path)
+// and a dW wave (the 48 operand transposes, the 88 parameter-gradient products, the bias sums: 136 of the 274 MFMAs and a
+// quarter of the VALU work, none of it on the dependency path) share a SIMD (waves w, w + 4).  The hand-over is ONE-WAY: the
+// chain wave appends the operand pieces it has split anyway (dZ3, h2, h3 | dZ2, h1 | dZ1, X) to a ring of 4-KB records, the dW
+// wave consumes them in order; the chain wave never waits for its partner unless the ring (four records) is full.  The dW wave
+// holds all 176 accumulators (+ 80 registers of working set), the chain wave none.
+// What makes it fit 160 KB: the weights are resident ONCE, as row-major fp16 pieces [out][in] (48 KB instead of 93 KB for W and
+// W^T as ready-made operand records); the forward operand of a 16 x 32 tile is still one ds_read_b128 per lane, the TRANSPOSED
+// operand of the dH chain comes out of the same image with two ds_read_b64_tr_b16 (gfx950's transposing LDS read: 16 lanes hand
+// in the addresses of 4 x 16 values, lane i receives column i).  16-byte chunks of a row are XOR-swizzled with bit-reversed row
+// bits so that both access patterns spread over the banks.  LDS: image 49 KB + staging 4 x 8.5 KB + rings 4 x 16 KB = 147 KB.
+namespace cd {
+constexpr int WS = 128;                        // bytes per image row (64 fp16)
+constexpr int W_PIECE = 64 * WS, W_LAYER = NP * W_PIECE, W_BYTES = 3 * W_LAYER;      // 8 KB, 16 KB, 48 KB
+constexpr int TAIL_BYTES = (TAIL_FLOATS * 4 + 15) / 16 * 16;
+constexpr int IMG_BYTES = W_BYTES + TAIL_BYTES;
+constexpr int NREC = 4, REC_BYTES = 4096, RING_BYTES = NREC * REC_BYTES;
+constexpr int SIDE_BYTES = 2 * 64;             // dY of the tile (16 floats), two tiles in flight
+constexpr int NPAIR = 4;
+constexpr int STAGE_FLOATS = 64 * 16 + 64;
+constexpr size_t LDS_BYTES = (size_t)IMG_BYTES + (size_t)NPAIR * 2 * STAGE_FLOATS * 4 + (size_t)NPAIR * (RING_BYTES + SIDE_BYTES) + 64;
+// 16-byte chunk `chunk` (0..7: eight fp16) of image row `row`: the chunk index is XOR-ed with the bit-reversed bits 1..3 of the
+// row, so that (a) the 16 lanes of a forward read (16 consecutive rows, one chunk) and (b) the 16 lanes of a transposing read
+// (4 consecutive rows x 4 chunks) each touch 16 different 16-byte bank groups
+__host__ __device__ inline int swz_key(int row) {
+  const int f = (row >> 1) & 7;
+  return ((f & 1) << 2) | (f & 2) | ((f >> 2) & 1);
+}
+__host__ __device__ inline int wofs(int row, int chunk) { return row * WS + ((chunk ^ swz_key(row)) << 4); }
+}  // namespace cd
+
+// the image of cd: thread = (layer 0..2, row, chunk) splits eight weights into their two pieces; tail threads copy biases etc.
+__global__ void mlp_cd_pack_kernel(int K0, const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
+                                   const float* __restrict__ W3, const float* __restrict__ b0, const float* __restrict__ b1,
+                                   const float* __restrict__ b2, const float* __restrict__ b3, unsigned char* __restrict__ rec,
+                                   uint32_t* __restrict__ absmax) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 3 * 64 * 8) {
+    const int layer = t / 512, row = (t >> 3) & 63, chunk = t & 7;
+    float w[8];
+    float wmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int pos = 8 * chunk + j;
+      if (layer == 0) {
+        w[j] = pos < K0 ? W0[row * K0 + pos] : 0.f;                 // natural order of the inputs
+      } else {
+        const int col = kf(pos >> 5, (pos >> 3) & 3, pos & 7);      // position 32 s + 8 g + j holds feature kf(s, g, j)
+        w[j] = (layer == 1 ? W1 : W2)[row * HID + col];
+      }
+      wmax = __builtin_fmaxf(wmax, __builtin_fabsf(w[j]));
+    }
+    if (wmax >= 65504.f) atomicOr(absmax + 1, 1u);
+    u32x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t h, l;
+      split2(w[2 * i], w[2 * i + 1], h, l);
+      hi[i] = h;
+      lo[i] = l;
+    }
+    unsigned char* base = rec + layer * cd::W_LAYER + cd::wofs(row, chunk);
+    *reinterpret_cast<u32x4*>(base) = hi;
+    *reinterpret_cast<u32x4*>(base + cd::W_PIECE) = lo;
+  } else {
+    const int e = t - 3 * 64 * 8;
+    float* tail = reinterpret_cast<float*>(rec + cd::W_BYTES);
+    if (e < HID) tail[e] = b0[e];
+    else if (e < 2 * HID) tail[e] = b1[e - HID];
+    else if (e < 3 * HID) tail[e] = b2[e - 2 * HID];
+    else if (e < 4 * HID) {
+      tail[e] = W3[e - 3 * HID];
+      if (__builtin_fabsf(W3[e - 3 * HID]) >= 65504.f) atomicOr(absmax + 1, 1u);
+    } else if (e == 4 * HID) tail[e] = b3[0];
+  }
+}
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+// single-producer / single-consumer ring of 4-KB records between the two waves of a pair
+struct Ring {
+  lds_byte* base;               // NREC records
+  lds_flag_t* produced;         // records written so far (chain wave)
+  lds_flag_t* consumed;         // records released so far (dW wave)
+  uint32_t at;                  // this wave's position (records)
+  // chain wave: a free record to write (waits while the ring is full)
+  __device__ __forceinline__ unsigned char* claim() {
+#pragma unroll 1
+    for (int spin = 0; spin < (1 << 24); spin++) {
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)*consumed);
+      if ((int32_t)(at - c) < cd::NREC) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    asm volatile("" ::: "memory");
+    return (unsigned char*)(base + (at & (cd::NREC - 1)) * cd::REC_BYTES);
+  }
+  __device__ __forceinline__ void publish() {
+    asm volatile("" ::: "memory");
+    at++;
+    *produced = at;             // behind the record's stores in the wave's DS queue
+    asm volatile("" ::: "memory");
+  }
+  // dW wave: the next record, once it is there
+  __device__ __forceinline__ lds_byte* acquire() {
+#pragma unroll 1
+    for (int spin = 0; spin < (1 << 24); spin++) {
+      const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)*produced);
+      if ((int32_t)(p - at) > 0) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    asm volatile("" ::: "memory");
+    return base + (at & (cd::NREC - 1)) * cd::REC_BYTES;
+  }
+  __device__ __forceinline__ void release() {
+    asm volatile("" ::: "memory");
+    at++;
+    *consumed = at;             // behind the record's loads in the wave's DS queue
+    asm volatile("" ::: "memory");
+  }
+};
+// Record of operand pieces: [k-step 2][piece 2][entry 64] 16-byte entries.  The chain wave's lane (c = sample, g) holds the
+// eight k-slots = features kf(s, g, 0..7) of sample c; the dW wave needs the transposed view -- lane (f, g') the samples
+// 4 g' .. 4 g' + 3 of feature f -- and gets it straight out of the record with ds_read_b64_tr_b16: the 16 lanes of group g' hand
+// in the addresses of the 16 entries of samples 4 g' + j, lane groups q (8 bytes each: the half u of the entry for tile 2 s + u)
+// and lane f receives k-slot (f & 3) of lane group f >> 2 = feature f of the tile.  No transposing MFMAs, no conversions.
+// Placement (measured: the lane-linear placement cost 1 000 LDS conflict cycles per tile, profiles/r05_pmc_sq_mlp_cd_v1.txt):
+//   entry(c, g) = 16 (c >> 2) + ((4 g + (c & 3)) ^ 4 ((c >> 2) & 1))     the 8 contiguous lanes of a store group (8 samples, one g)
+//                                                                         fall on 8 different 16-byte bank groups
+//   halves swapped in the entries of odd sample blocks                    the two 16-lane groups a transposing read serves together
+//                                                                         (g' = 0, 1 / 2, 3) then read opposite halves: all 64 banks once
+struct RecLane {        // per-lane byte offsets inside a [piece][k-step] plane of a record
+  int w_lo, w_hi;       // chain wave: where the low / high 8 bytes of its entry go
+  int r_u0;             // dW wave: its transposing read of the tile with u = 0 (u = 1: ^ 8)
+};
+__device__ __forceinline__ RecLane rec_lane(int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  RecLane r;
+  const int ent = 16 * (c >> 2) + ((4 * g + (c & 3)) ^ (4 * ((c >> 2) & 1))), sw = (c >> 2) & 1;
+  r.w_lo = ent * 16 + 8 * sw;
+  r.w_hi = ent * 16 + 8 - 8 * sw;
+  // reader: lane i of group g' hands in the entry of (sample 4 g' + (i >> 2), lane group i & 3)
+  const int i = c, gp = g;
+  r.r_u0 = (16 * gp + ((4 * (i & 3) + (i >> 2)) ^ (4 * (gp & 1)))) * 16 + 8 * (gp & 1);
+  return r;
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void put_pieces(unsigned char* rec, const RecLane& rl, int s, const BP& b) {
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const u32x4 v = __builtin_bit_cast(u32x4, b.p[p]);
+    unsigned char* plane = rec + (s * NP + p) * 1024;
+    *reinterpret_cast<u32x2*>(plane + rl.w_lo) = u32x2{v[0], v[1]};
+    *reinterpret_cast<u32x2*>(plane + rl.w_hi) = u32x2{v[2], v[3]};
+  }
+}
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// the four samples 4 g' .. + 3 of feature (lane & 15) of tile `tile`, one piece
+__device__ __forceinline__ f16x4 get_T(lds_byte* rec, const RecLane& rl, int tile, int piece) {
+  const int off = ((tile >> 1) * NP + piece) * 1024 + ((tile & 1) ? (rl.r_u0 ^ 8) : rl.r_u0);
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rec + off));
+  return __builtin_bit_cast(f16x4, v);
+}
+// acc += sum over the lane's four samples of piece value x factor (v_fma_mix_f32: the fp16 source is widened inside the fma)
+__device__ __forceinline__ float mix_sum(float acc, const f16x4& v, const f32x4& w) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) acc = __builtin_fmaf((float)v[j], w[j], acc);
+  return acc;
+}
+
+template <int NT0>
+__global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
+    mlp_bwd_split_f16_cd_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
+                                const u32x4* __restrict__ img, uint32_t* __restrict__ absmax, float* __restrict__ dX,
+                                float* __restrict__ partial) {
+  static_assert(NT0 == 3, "the chain / dW form holds three input tiles (K0 <= 48)");
+  extern __shared__ __align__(16) u32x4 lds[];
+  float sc, isc;
+  const int kscale = dy_scale((uint32_t)__builtin_amdgcn_readfirstlane((int)absmax[0]), sc, isc);
+  for (int i = threadIdx.x; i < cd::IMG_BYTES / 16; i += PAIR_WAVES * 64) lds[i] = img[i];
+  const int lane_k = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wave & 3;
+  const bool is_chain = wave < 4;             // waves w and w + 4 share a SIMD (tools/simd_map.hip)
+  lds_byte* wimg = (lds_byte*)(unsigned char*)lds;
+  const float* tail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(lds) + cd::W_BYTES);
+  unsigned char* dyn = reinterpret_cast<unsigned char*>(lds) + cd::IMG_BYTES;
+  float* stage = reinterpret_cast<float*>(dyn) + pair * 2 * cd::STAGE_FLOATS;
+  unsigned char* ring_mem = dyn + (size_t)cd::NPAIR * 2 * cd::STAGE_FLOATS * 4 + (size_t)pair * (cd::RING_BYTES + cd::SIDE_BYTES);
+  float* side = reinterpret_cast<float*>(ring_mem + cd::RING_BYTES);          // dY of the tile in flight, by tile parity
+  uint32_t* flags = reinterpret_cast<uint32_t*>(dyn + (size_t)cd::NPAIR * 2 * cd::STAGE_FLOATS * 4 +
+                                                (size_t)cd::NPAIR * (cd::RING_BYTES + cd::SIDE_BYTES));
+  if (threadIdx.x < 2 * cd::NPAIR) flags[threadIdx.x] = 0u;
+  Ring ring;
+  ring.base = (lds_byte*)ring_mem;
+  ring.produced = (lds_flag_t*)(flags + 2 * pair);
+  ring.consumed = (lds_flag_t*)(flags + 2 * pair + 1);
+  ring.at = 0u;
+  const int64_t ntiles = (N + 15) / 16;
+  const int64_t tile0 = (int64_t)blockIdx.x * cd::NPAIR + pair, tstride = (int64_t)gridDim.x * cd::NPAIR;
+  constexpr int STAGE_ROWS = 64, stage_floats = cd::STAGE_FLOATS, OFF_DY = STAGE_ROWS * 16;
+  if (is_chain) {
+    // ================================================================= chain wave
+    __builtin_amdgcn_s_setprio(2);
+    for (int i = rows4 * 16 + lane_k; i < STAGE_ROWS * 16; i += 64) {
+      stage[i] = 0.f;
+      stage[stage_floats + i] = 0.f;
+    }
+    const bool wide_dma = (N & 3) == 0 && N >= 4;
+    auto prefetch = [&](int64_t t, float* buf, int lane_k) {
+      const int c = lane_k & 15, g = lane_k >> 4;
+      int64_t nn = t * 16 + c;
+      nn = nn < N ? nn : N - 1;
+      int i0 = 0;
+      if (wide_dma) {
+        int64_t n4 = t * 16 + 4 * (lane_k & 3);
+        n4 = n4 + 3 < N ? n4 : N - 4;
+        const int n16 = rows4 >> 4;
+        for (int j = 0; j < n16; j++) {
+          const int k = 16 * j + (lane_k >> 2);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)(k < K0 ? k : K0 - 1) * N + n4),
+                                           (__attribute__((address_space(3))) void*)(buf + j * 256), 16, 0, 0);
+        }
+        i0 = n16 * 4;
+      }
+      for (int i = i0; i < (rows4 >> 2); i++) {
+        int k = 4 * i + g;
+        k = k < K0 ? k : K0 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)k * N + nn),
+                                         (__attribute__((address_space(3))) void*)(buf + i * 64), 4, 0, 0);
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + nn),
+                                       (__attribute__((address_space(3))) void*)(buf + OFF_DY), 4, 0, 0);
+    };
+    if (tile0 < ntiles) prefetch(tile0, stage, lane_k);
+    __syncthreads();             // image, flag words (the dW waves wait here too)
+    uint32_t out_of_range = 0u;
+    float db4 = 0.f;
+    int cur = 0;
+    for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const float* xb = stage + cur * stage_floats;
+      int lane_l = lane_k;
+      asm volatile("" : "+v"(lane_l));
+      const int lane = lane_l, c = lane & 15, g = lane >> 4;
+      const int64_t n0 = tile * 16, n = n0 + c;
+      const bool live = n < N;
+      const RecLane rl = rec_lane(lane);
+      // ---- addresses into the weight image (see cd::wofs): forward operand of out tile t, k-step s = row 16 t + c, chunk 4 s + g
+      const int fkey = cd::swz_key(c);                                    // (rows 16 t + c: bits 1..3 are those of c)
+      const int f_lane = c * cd::WS + ((g ^ (fkey & 3)) << 4);           // + 16 t rows + 64 (s ^ (fkey >> 2))
+      auto fwd_w = [&](int layer, int t, int s, int p) -> f16x8 {
+        const int off = layer * cd::W_LAYER + p * cd::W_PIECE + 16 * t * cd::WS + f_lane + (((s ^ (fkey >> 2)) & 1) << 6);
+        return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>((const unsigned char*)lds + off));
+      };
+      // transposed operand of in tile t, k-step s (over the layer's OUTPUTS, kf order): rows 32 s + 16 hh + 4 g + (i >> 2),
+      // columns = the 16 inputs of tile t; lane i of a 16-lane group hands in the address of inputs 4 (i & 3) .. + 3 of its row
+      const int i16 = c, q = i16 & 3, trow = 4 * g + (i16 >> 2);
+      const int tkey = cd::swz_key(trow);                                 // (+ 32 s + 16 hh: multiples of 16 do not change the key)
+      auto tr_w = [&](int layer, int t, int s, int p) -> f16x8 {
+        int chunk, half8;
+        if (layer == 0) {                 // inputs in natural order: feature 16 t + 4 q -> chunk 2 t + (q >> 1), half q & 1
+          chunk = 2 * t + (q >> 1);
+          half8 = q & 1;
+        } else {                          // position order: tile t = 2 s' + u, features 16 t + 4 q -> chunk 4 s' + q, half u
+          chunk = 4 * (t >> 1) + q;
+          half8 = t & 1;
+        }
+        const int off = layer * cd::W_LAYER + p * cd::W_PIECE + (32 * s + trow) * cd::WS + ((chunk ^ tkey) << 4) + 8 * half8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(wimg + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(wimg + off + 16 * cd::WS));
+        typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(f16x8, both);
+      };
+      // one chain layer: out[NTILE] += W x in over both k-steps; the operand pieces of each k-step go to per_step
+      auto chain_fwd = [&](int layer, const f32x4 (&in)[NT], f32x4 (&out)[NT], BP (&keep)[2]) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          f16x8 w[NT][NP];
+#pragma unroll
+          for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) w[t][p] = fwd_w(layer, t, s, p);
+          float x[8];
+          step_operand(in, s, x);
+          split8(x, keep[s]);
+          mac16r<NT>(out, keep[s], w);
+        }
+      };
+      // ---------------- forward recompute
+      f32x4 a[NT], g1[NT], b[NT], g2[NT];
+      BP h1p[2], h2p[2];
+      float seen;
+      bias_init<NT>(a, tail, g);
+      {
+        float xs[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+          for (int j = 0; j < 8; j++) xs[s][j] = xb[(32 * s + 8 * g + j) * 16 + c];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          f16x8 w[NT][NP];
+#pragma unroll
+          for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) w[t][p] = fwd_w(0, t, s, p);
+          BP bx;
+          split8(xs[s], bx);
+          mac16r<NT>(a, bx, w);
+        }
+        seen = amax_of8(amax_of8(0.f, xs[0]), xs[1]);
+      }
+      bias_init<NT>(b, tail + HID, g);
+      act_both(a, g1);  // a = h1
+#pragma unroll
+      for (int t = 0; t < NT; t++) seen = amax_of(seen, a[t]);
+      chain_fwd(1, a, b, h1p);
+      bias_init<NT>(a, tail + 2 * HID, g);
+      act_both(b, g2);  // b = h2
+#pragma unroll
+      for (int t = 0; t < NT; t++) seen = amax_of(seen, b[t]);
+      chain_fwd(2, b, a, h2p);
+      f32x4 dz[NT];
+      act_both(a, dz);  // a = h3, dz = gelu'(z3)
+#pragma unroll
+      for (int t = 0; t < NT; t++) seen = amax_of(seen, a[t]);
+      out_of_range |= __builtin_amdgcn_ballot_w64(seen >= RANGE_LIMIT) != 0ull ? 1u : 0u;
+      // ---------------- the tile's dY for the dW wave (16 floats, by tile parity), then record 1: the pieces of h3
+      if (lane < 16) side[cur * 16 + lane] = (n0 + lane < N) ? xb[OFF_DY + lane] : 0.f;
+      {
+        unsigned char* r = ring.claim();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          float x[8];
+          step_operand(a, s, x);
+          BP p;
+          split8(x, p);
+          put_pieces(r, rl, s, p);
+        }
+        ring.publish();
+      }
+      {
+        f32x4 dyT = *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dyT[r] = (n0 + 4 * g + r < N) ? dyT[r] * sc : 0.f;
+        db4 += (dyT[0] + dyT[1]) + (dyT[2] + dyT[3]);
+      }
+      float dy, dy_pow2;
+      dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(tail + 3 * HID + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dz[t][r] *= w4[r] * dy;
+      }
+      // one layer of the dH chain: out[NTO] += W^T x dz over both k-steps; the pieces of dz go out as a record, `other` (the
+      // H-side pieces the dW wave needs with them) as the next one
+      auto chain_bwd = [&](auto ntile_tag, int layer, const f32x4 (&in)[NT], auto& out, const BP (*other)[2]) {
+        constexpr int NTO = decltype(ntile_tag)::value;
+        unsigned char* r = ring.claim();
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          f16x8 w[NTO][NP];
+#pragma unroll
+          for (int t = 0; t < NTO; t++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) w[t][p] = tr_w(layer, t, s, p);
+          float x[8];
+          step_operand(in, s, x);
+          BP pz;
+          split8(x, pz);
+          put_pieces(r, rl, s, pz);
+          mac16r<NTO>(out, pz, w);
+        }
+        ring.publish();
+        if (other) {
+          unsigned char* r2 = ring.claim();
+          put_pieces(r2, rl, 0, (*other)[0]);
+          put_pieces(r2, rl, 1, (*other)[1]);
+          ring.publish();
+        }
+      };
+      // ---------------- layer 3
+      zero_init<NT>(a);
+      chain_bwd(std::integral_constant<int, NT>{}, 2, dz, a, &h2p);
+#pragma unroll
+      for (int t = 0; t < NT; t++) a[t] *= g2[t];   // dZ2^T
+      // ---------------- layer 2
+      if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats, lane);
+      zero_init<NT>(dz);
+      chain_bwd(std::integral_constant<int, NT>{}, 1, a, dz, &h1p);
+#pragma unroll
+      for (int t = 0; t < NT; t++) dz[t] *= g1[t];   // dZ1^T
+      // ---------------- layer 1: the pieces of dZ1, then X in feature-lane order as it lies in the staging buffer
+      f32x4 dx[NT0];
+      zero_init<NT0>(dx);
+      chain_bwd(std::integral_constant<int, NT0>{}, 0, dz, dx, nullptr);
+      {
+        u32x4* r = reinterpret_cast<u32x4*>(ring.claim()) + lane;          // (feature-lane order as staged: lane-linear entries)
+#pragma unroll
+        for (int u = 0; u < NT0; u++) r[u * 64] = *reinterpret_cast<const u32x4*>(xb + (16 * u + c) * 16 + 4 * g);
+        ring.publish();
+      }
+      if (dX && live) {
+        float* p0 = dX + (int64_t)(4 * g) * N + n;
+#pragma unroll
+        for (int t = 0; t < NT0; t++) {
+          if (16 * (t + 1) <= K0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
+          } else if (16 * t < K0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              if (16 * t + 4 * g + r < K0) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (out_of_range && lane_k == 0) atomicOr(absmax + 1, 1u);
+    // ---------------- epilogue (chain wave): db4
+    __syncthreads();             // every pair is done: the weight image is dead
+    float* G = reinterpret_cast<float*>(lds);
+    for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) G[e] = 0.f;
+    __syncthreads();
+    float b4 = db4;
+    b4 += __shfl_xor(b4, 16, 64);
+    b4 += __shfl_xor(b4, 32, 64);
+    for (int w = 0; w < cd::NPAIR; w++) {
+      if (pair == w && lane_k == 0) G[G_B4] += b4;
+      __syncthreads();
+    }
+  } else {
+    // ================================================================= dW wave
+    f32x4 dW1[NT][NT0], dW2[NT][NT], dW3[NT][NT];
+#pragma unroll
+    for (int to = 0; to < NT; to++) {
+#pragma unroll
+      for (int ti = 0; ti < NT; ti++) dW2[to][ti] = dW3[to][ti] = zero4();
+#pragma unroll
+      for (int ti = 0; ti < NT0; ti++) dW1[to][ti] = zero4();
+    }
+    Sum<false> db1[NT], db2[NT], db3[NT], dw4[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      db1[t].clear(); db2[t].clear(); db3[t].clear(); dw4[t].clear();
+    }
+    __syncthreads();             // image, flag words
+    int cur = 0;
+    for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
+      int lane_l = lane_k;
+      asm volatile("" : "+v"(lane_l));
+      const int lane = lane_l, g = lane >> 4;
+      const int64_t n0 = tile * 16;
+      const RecLane rl = rec_lane(lane);
+      // ---- record 1: h3 -> dW4 (needs the tile's dY, written before the record)
+      f32x4 rT;
+      {
+        lds_byte* r = ring.acquire();
+        f32x4 dyT = *reinterpret_cast<const f32x4*>(side + cur * 16 + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const bool in = n0 + 4 * g + q < N;
+          const int ex = (int)(__float_as_uint(dyT[q]) >> 23) & 255;
+          int er = ex + kscale - CHAIN_EXP + H_PRESCALE_EXP;
+          er = er < 1 ? 0 : (er > 254 ? 254 : er);
+          uint32_t bits = (uint32_t)er << 23;
+          bits = ex > CHAIN_EXP ? bits : 0u;
+          bits = ex == 255 ? 0x3F800000u : bits;
+          rT[q] = __uint_as_float(in ? bits : 0u);
+          dyT[q] = in ? dyT[q] * sc : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          dw4[t].v = mix_sum(dw4[t].v, get_T(r, rl, t, 1), dyT);     // smallest first
+          dw4[t].v = mix_sum(dw4[t].v, get_T(r, rl, t, 0), dyT);
+        }
+        ring.release();
+      }
+      // ---- dZ-side operands of a layer (both pieces of the four samples of the lane's feature: one MFMA operand) + bias sums
+      auto dz_side = [&](AT (&A)[NT], Sum<false> (&db)[NT]) {
+        lds_byte* r = ring.acquire();
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const f16x4 hi = get_T(r, rl, t, 0), lo = get_T(r, rl, t, 1);
+          db[t].v = mix_sum(db[t].v, lo, rT);
+          db[t].v = mix_sum(db[t].v, hi, rT);
+          typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+          A[t].t01 = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        ring.release();
+      };
+      // ---- H-side operand of tile t out of a record of pieces: value = high + low (exact), scaled, split again
+      auto h_side = [&](lds_byte* r, int t, BT& B) {
+        const f16x4 hi = get_T(r, rl, t, 0), lo = get_T(r, rl, t, 1);
+        f32x4 h;
+#pragma unroll
+        for (int j = 0; j < 4; j++) h[j] = ((float)hi[j] + (float)lo[j]) * rT[j];
+        split4(h, B);
+      };
+      {
+        AT A[NT];
+        dz_side(A, db3);
+        lds_byte* r = ring.acquire();
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) {
+          BT B;
+          h_side(r, ti, B);
+#pragma unroll
+          for (int to = 0; to < NT; to++) dW3[to][ti] = dw_mac<false>(dW3[to][ti], A[to], B);
+        }
+        ring.release();
+      }
+      {
+        AT A[NT];
+        dz_side(A, db2);
+        lds_byte* r = ring.acquire();
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) {
+          BT B;
+          h_side(r, ti, B);
+#pragma unroll
+          for (int to = 0; to < NT; to++) dW2[to][ti] = dw_mac<false>(dW2[to][ti], A[to], B);
+        }
+        ring.release();
+      }
+      {
+        AT A[NT];
+        dz_side(A, db1);
+        lds_byte* r = ring.acquire();
+#pragma unroll
+        for (int u = 0; u < NT0; u++) {
+          const f32x4 xT = *reinterpret_cast<const f32x4*>((const unsigned char*)(r + (u * 64 + lane) * 16));
+          BT B;
+          split4(xT * rT, B);
+#pragma unroll
+          for (int to = 0; to < NT; to++) dW1[to][u] = dw_mac<false>(dW1[to][u], A[to], B);
+        }
+        ring.release();
+      }
+    }
+    // ---------------- epilogue (dW wave): accumulators -> workgroup image
+    const int lane = lane_k, c = lane & 15, g = lane >> 4;
+    __syncthreads();
+    float* G = reinterpret_cast<float*>(lds);
+    for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) G[e] = 0.f;      // (all eight waves zero the image together)
+    __syncthreads();
+    for (int w = 0; w < cd::NPAIR; w++) {
+      if (pair == w) {
+#pragma unroll
+        for (int to = 0; to < NT; to++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int row = (16 * to + 4 * g + r) * 64;  // [out][in]
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+              G[G_W2 + row + 16 * ti + c] += dW2[to][ti][r];
+              G[G_W3 + row + 16 * ti + c] += dW3[to][ti][r];
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT0; ti++) G[G_W1 + row + 16 * ti + c] += dW1[to][ti][r];
+          }
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          float v1 = db1[t].total(), v2 = db2[t].total(), v3 = db3[t].total(), v4 = dw4[t].total();
+          v1 += __shfl_xor(v1, 16, 64); v2 += __shfl_xor(v2, 16, 64); v3 += __shfl_xor(v3, 16, 64); v4 += __shfl_xor(v4, 16, 64);
+          v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); v3 += __shfl_xor(v3, 32, 64); v4 += __shfl_xor(v4, 32, 64);
+          if (g == 0) {
+            G[G_B1 + 16 * t + c] += v1;
+            G[G_B2 + 16 * t + c] += v2;
+            G[G_B3 + 16 * t + c] += v3;
+            G[G_W4 + 16 * t + c] += v4;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  float* G = reinterpret_cast<float*>(lds);
+  float* dst = partial + (size_t)blockIdx.x * G_TOTAL;
+  for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) dst[e] = G[e];
+}
+
 // guard_drops: the launch has a bf16 launch queued behind it that redoes the batch when the range guard is raised (absmax[1]):
 // the images are then dropped here.  events (host-mapped, may be NULL): count of raised guards, for the one-time warning.
 __global__ void mlp_split_reduce_kernel(const float* __restrict__ partial, const uint32_t* __restrict__ absmax, int nimg, int K0, float* __restrict__ dW0,
@@ -1286,6 +1874,9 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
 #ifndef PSDF_MLP_BWD_F16_PAIR_DEFAULT
 #define PSDF_MLP_BWD_F16_PAIR_DEFAULT 0
 #endif
+#ifndef PSDF_MLP_BWD_F16_CD_DEFAULT
+#define PSDF_MLP_BWD_F16_CD_DEFAULT 0
+#endif
 static int g_f16_form = 0;   // form of the last launch: 1 = one wave per SIMD, 2 = wave pairs
 namespace psdf {
 size_t mlp_backward_split_scratch_bytes(int K0, int64_t N);      // mlp_bwd_split.hip
@@ -1338,8 +1929,10 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
   // every call so that tests and benches can A/B the two in one process
   const char* form = getenv("PSDF_MLP_BWD_F16_FORM");
   const bool pair_form = nt0 == 3 && (form ? form[0] == 'p' : PSDF_MLP_BWD_F16_PAIR_DEFAULT);
+  // "cd" = chain / dW wave pairs (mlp_bwd_split_f16_cd_kernel: its own weight image, cd::IMG_BYTES)
+  const bool cd_form = nt0 == 3 && !pair_form && (form ? form[0] == 'c' : PSDF_MLP_BWD_F16_CD_DEFAULT);
   const size_t pair_lds = img_bytes + (size_t)(PAIR_WAVES / 2) * 2 * (64 * 16 + 64) * 4 + (size_t)(PAIR_WAVES / 2) * XCH_PAIR * 16 + 64;
-  g_f16_form = pair_form ? 2 : 1;
+  g_f16_form = pair_form ? 2 : (cd_form ? 3 : 1);
   int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;   // four tiles in flight per workgroup in either form
   if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave (pair) walks many tiles
   const size_t part_bytes = ((size_t)blocks * G_TOTAL * sizeof(float) + 15) & ~(size_t)15;
@@ -1372,13 +1965,22 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,                  \
                        reinterpret_cast<const u32x4*>(rec), absmax, dX, partial);                                           \
   } while (0)
-  if (nt0 == 3) PACK(3); else PACK(4);
+  if (cd_form)
+    hipLaunchKernelGGL(mlp_cd_pack_kernel, dim3((3 * 64 * 8 + TAIL_FLOATS + 255) / 256), dim3(256), 0, st, K0, weights[0], weights[1],
+                       weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], reinterpret_cast<unsigned char*>(rec), absmax);
+  else if (nt0 == 3) PACK(3); else PACK(4);
   {
     int64_t ab = ((N >> 2) + 1023) / 1024;     // four 16-byte loads per thread, at most 512 workgroups (= 512 atomics)
     ab = ab < 1 ? 1 : (ab > 512 ? 512 : ab);
     hipLaunchKernelGGL(mlp_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, N, dY, absmax);
   }
-  if (pair_form) {
+  if (cd_form) {
+    auto kern = mlp_bwd_split_f16_cd_kernel<3>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PAIR_WAVES * 64), cd::LDS_BYTES, st, N, K0, rows4, X, dY,
+                       reinterpret_cast<const u32x4*>(rec), absmax, dX, partial);
+  } else if (pair_form) {
     auto kern = mlp_bwd_split_f16_pair_kernel<3>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds);
     if (e != hipSuccess) return (int)e;

@@ -79,8 +79,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // AdamW makes them) the result is bit-for-bit what the dense kernel produces, while never-touched blocks are not even
 // read.  The gradient is zeroed in the same pass (the buffer is persistent: no allocation, no separate fill launch).
 // One wave per block, float4 per lane.
-__global__ void __launch_bounds__(PSDF_BLOCK)
-    adamw_blocks_kernel(int64_t n_blocks, int block_elems, float* __restrict__ p, float* __restrict__ g,
+__device__ __forceinline__ void adamw_blocks_body(int64_t n_blocks, int block_elems, float* __restrict__ p, float* __restrict__ g,
                         float* __restrict__ m, float* __restrict__ v, unsigned char* __restrict__ touched,
                         unsigned char* __restrict__ active, float lr, float beta1, float beta2, float eps, float bias_corr1,
                         float bias_corr2_sqrt, float grad_scale, int zero_grad) {
@@ -121,6 +120,28 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
     }
   }
 }
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    adamw_blocks_kernel(int64_t n_blocks, int block_elems, float* __restrict__ p, float* __restrict__ g,
+                        float* __restrict__ m, float* __restrict__ v, unsigned char* __restrict__ touched,
+                        unsigned char* __restrict__ active, float lr, float beta1, float beta2, float eps, float bias_corr1,
+                        float bias_corr2_sqrt, float grad_scale, int zero_grad) {
+  adamw_blocks_body(n_blocks, block_elems, p, g, m, v, touched, active, lr, beta1, beta2, eps, bias_corr1, bias_corr2_sqrt,
+                    grad_scale, zero_grad);
+}
+constexpr int ADAMW_BLOCKS_MAX = 8;
+struct AdamwBlocksMulti {
+  int64_t n_blocks[ADAMW_BLOCKS_MAX];
+  int block_elems[ADAMW_BLOCKS_MAX];
+  float *p[ADAMW_BLOCKS_MAX], *g[ADAMW_BLOCKS_MAX], *m[ADAMW_BLOCKS_MAX], *v[ADAMW_BLOCKS_MAX];
+  unsigned char *touched[ADAMW_BLOCKS_MAX], *active[ADAMW_BLOCKS_MAX];
+  float lr[ADAMW_BLOCKS_MAX], beta1[ADAMW_BLOCKS_MAX], beta2[ADAMW_BLOCKS_MAX], eps[ADAMW_BLOCKS_MAX], bc1[ADAMW_BLOCKS_MAX],
+      bc2[ADAMW_BLOCKS_MAX];
+};
+__global__ void __launch_bounds__(PSDF_BLOCK) adamw_blocks_multi_kernel(AdamwBlocksMulti a, float grad_scale, int zero_grad) {
+  const int t = blockIdx.y;
+  adamw_blocks_body(a.n_blocks[t], a.block_elems[t], a.p[t], a.g[t], a.m[t], a.v[t], a.touched[t], a.active[t], a.lr[t], a.beta1[t],
+                    a.beta2[t], a.eps[t], a.bc1[t], a.bc2[t], grad_scale, zero_grad);
+}
 }  // namespace
 
 extern "C" {
@@ -140,6 +161,43 @@ int psdf_adamw_step_blocks(int64_t n_blocks, int block_elems, float* param, floa
   if (blocks > 8192u) blocks = 8192u;
   hipLaunchKernelGGL(adamw_blocks_kernel, dim3(blocks), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, n_blocks, block_elems,
                      param, grad, exp_avg, exp_avg_sq, touched, active, lr, beta1, beta2, eps, bc1, bc2, grad_scale, zero_grad);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
+// The same update for up to ADAMW_BLOCKS_MAX touched-rows tensors in ONE launch (blockIdx.y = tensor; every tensor with its own
+// learning rate, betas, eps and step count: the lattices of a training step sit in different parameter groups).  A cfg-4 step
+// updates three lattices: three launches of ~42 us each, far from filling the chip (profiles/r04_cfg4_manual_kernel_stats.txt).
+int psdf_adamw_step_blocks_multi(int n_tensors, const int64_t* n_blocks, const int* block_elems, float* const* params,
+                                 float* const* grads, float* const* exp_avgs, float* const* exp_avg_sqs,
+                                 unsigned char* const* touched, unsigned char* const* active, const float* lr,
+                                 const float* beta1, const float* beta2, const float* eps, const int* step, float grad_scale,
+                                 int zero_grad, void* stream) {
+  if (n_tensors <= 0) return PSDF_OK;
+  if (n_tensors > ADAMW_BLOCKS_MAX || !n_blocks || !block_elems || !params || !grads || !exp_avgs || !exp_avg_sqs || !touched ||
+      !active || !lr || !beta1 || !beta2 || !eps || !step)
+    return PSDF_ERR_ARG;
+  AdamwBlocksMulti a;
+  int64_t most = 0;
+  for (int t = 0; t < n_tensors; t++) {
+    if (n_blocks[t] < 0 || !params[t] || !grads[t] || !exp_avgs[t] || !exp_avg_sqs[t] || !touched[t] || !active[t] || step[t] < 1 ||
+        block_elems[t] <= 0 || (block_elems[t] & 3))
+      return PSDF_ERR_ARG;
+    if ((((uintptr_t)params[t] | (uintptr_t)grads[t] | (uintptr_t)exp_avgs[t] | (uintptr_t)exp_avg_sqs[t]) & 15) != 0) return PSDF_ERR_ARG;
+    a.n_blocks[t] = n_blocks[t];
+    a.block_elems[t] = block_elems[t];
+    a.p[t] = params[t]; a.g[t] = grads[t]; a.m[t] = exp_avgs[t]; a.v[t] = exp_avg_sqs[t];
+    a.touched[t] = touched[t]; a.active[t] = active[t];
+    a.lr[t] = lr[t]; a.beta1[t] = beta1[t]; a.beta2[t] = beta2[t]; a.eps[t] = eps[t];
+    a.bc1[t] = 1.f - powf(beta1[t], (float)step[t]);
+    a.bc2[t] = sqrtf(1.f - powf(beta2[t], (float)step[t]));
+    most = n_blocks[t] > most ? n_blocks[t] : most;
+  }
+  if (most == 0) return PSDF_OK;
+  unsigned blocks = psdf_blocks(most, PSDF_BLOCK / 64);
+  if (blocks > 8192u) blocks = 8192u;
+  hipLaunchKernelGGL(adamw_blocks_multi_kernel, dim3(blocks, n_tensors), dim3(PSDF_BLOCK), 0, (hipStream_t)stream, a, grad_scale,
+                     zero_grad);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }

@@ -69,6 +69,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._sharded_params = set()
             self._sharded_params.update(owned.keys())
         self.generation += 1
+        blocks_pending = []
         for group in self.param_groups:
             b1, b2 = group["betas"]
             small = {}   # step count -> [(p, g, m, v)]
@@ -102,10 +103,10 @@ class FusedAdamW(torch.optim.Optimizer):
                             af[blo:bhi].fill_(1)
                             tf[blo:bhi].zero_()
                         else:
-                            L.call("psdf_adamw_step_blocks", L.c_l(bhi - blo), L.c_i(be), L.ptr(pf[lo:hi]), L.ptr(gf[lo:hi]),
-                                   L.ptr(mf[lo:hi]), L.ptr(vf[lo:hi]), L.ptr(tf[blo:bhi]), L.ptr(af[blo:bhi]),
-                                   L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
-                                   L.c_i(st["step"]), L.c_f(float(grad_scale)), L.c_i(1), L.stream())
+                            # collected: ONE launch for all touched-rows tensors of the step (the three lattices of cfg 4 live
+                            # in different parameter groups; three ~42-us launches that do not fill the chip, round 4's trace)
+                            blocks_pending.append((bhi - blo, be, pf[lo:hi], gf[lo:hi], mf[lo:hi], vf[lo:hi], tf[blo:bhi], af[blo:bhi],
+                                                   group["lr"], b1, b2, group["eps"], st["step"]))
                     if p in owned:      # what lies outside: local contributions whose sums live with their owners
                         prev = 0
                         for lo, hi in sorted(ranges) + [(p.numel(), p.numel())]:
@@ -150,3 +151,19 @@ class FusedAdamW(torch.optim.Optimizer):
                     L.call("psdf_adamw_step_multi", L.c_i(n), sizes, *arrs, L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2),
                            L.c_f(group["eps"]), L.c_f(group["weight_decay"]), L.c_i(step), L.c_f(float(grad_scale)),
                            L.stream())
+        for i in range(0, len(blocks_pending), 8):
+            chunk = blocks_pending[i:i + 8]
+            n = len(chunk)
+            if n == 1:
+                c = chunk[0]
+                L.call("psdf_adamw_step_blocks", L.c_l(c[0]), L.c_i(c[1]), L.ptr(c[2]), L.ptr(c[3]), L.ptr(c[4]), L.ptr(c[5]),
+                       L.ptr(c[6]), L.ptr(c[7]), L.c_f(c[8]), L.c_f(c[9]), L.c_f(c[10]), L.c_f(c[11]), L.c_i(c[12]),
+                       L.c_f(float(grad_scale)), L.c_i(1), L.stream())
+                continue
+            nb = (ctypes.c_int64 * n)(*[c[0] for c in chunk])
+            be = (ctypes.c_int * n)(*[c[1] for c in chunk])
+            ptrs = [(ctypes.c_void_p * n)(*[c[k].data_ptr() for c in chunk]) for k in range(2, 8)]
+            fl = [(ctypes.c_float * n)(*[float(c[k]) for c in chunk]) for k in range(8, 12)]
+            steps = (ctypes.c_int * n)(*[int(c[12]) for c in chunk])
+            L.call("psdf_adamw_step_blocks_multi", L.c_i(n), nb, be, *ptrs, *fl, steps, L.c_f(float(grad_scale)), L.c_i(1),
+                   L.stream())

@@ -428,7 +428,7 @@ def test_unfused_widths_raise_unless_opted_in(dev):
                                   # width, the full 64 rows (no zero-padded row in the staging buffer), fewer than 16 rows (no
                                   # 16-byte request at all), a batch smaller than one tile
                                   (52, 262_144), (64, 65_536), (5, 4_096), (36, 8)])
-@pytest.mark.parametrize("form", ["one", "pair"])
+@pytest.mark.parametrize("form", ["one", "pair", "cd"])
 def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypatch):
     """csrc/mlp_bwd_split_f16.hip (two fp16 pieces per fp32 operand, three products; gradient chain evaluated on dY * 2^k with k
     from max|dY|): every gradient against a float64 evaluation, for upstream gradients of ordinary size, tiny (1e-7: every
@@ -469,7 +469,7 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypa
     assert rc == 0, rc
     which = L.lib().psdf_mlp_backward_split_f16_form
     which.restype = ctypes.c_int
-    assert which() == (2 if (form == "pair" and K0 <= 48) else 1)
+    assert which() == ({"pair": 2, "cd": 3}[form] if (form != "one" and K0 <= 48) else 1)
     got = [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
     names = ["dX", "dW1", "db1", "dW2", "db2", "dW3", "db3", "dW4", "db4"]
     errs = {}
@@ -494,7 +494,7 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypa
                arr(dWs), arr(dbs), L.stream()) == -2
 
 
-@pytest.mark.parametrize("form", ["one", "pair"])
+@pytest.mark.parametrize("form", ["one", "pair", "cd"])
 @pytest.mark.parametrize("what", ["inputs", "hidden", "weights"])
 def test_split_f16_backward_range_guard(dev, what, form, monkeypatch):
     """The two-piece fp16 arithmetic holds for |inputs|, |hidden activations| < 2^8 (the H-side operand of the parameter-gradient

@@ -3,7 +3,7 @@
 # the float64 tests under either form, then the kernel time on the BASELINE batch.  Output: gpurun_out/r05/mlp_pair_ab.txt
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; O=$R/gpurun_out/r05; mkdir -p $O
 {
-for form in one pair; do
+for form in ${FORMS:-one pair cd}; do
   echo "== form $form"
   PSDF_MLP_BWD_F16_FORM=$form timeout 600 python -m pytest tests/test_gpu_mlp.py -q -m gpu -k "split_f16_backward" -x 2>&1 | tail -5
   for d in 36-64-64-64-1 20-64-64-64-1; do
