@@ -247,7 +247,7 @@ def main():
         mlp_note = ("fp32-equivalent arithmetic priced against the fp32 matrix peak (157.3 TF): every fp32 operand is two fp16 pieces "
                     "(11 + 11 mantissa bits) and every product three (chains) or four (dW) fp16 MFMA products on "
                     "v_mfma_f32_16x16x32_f16 -- fp32 MFMAs do not overlap with VALU work on gfx950, and gfx950's matrix pipe honours "
-                    "fp16 subnormals (tools/prototypes/mlp_fwd_split_f16.hip); the gradient chain of each sample runs on the mantissa of its dY "
+                    "fp16 subnormals (attic/prototypes/mlp_fwd_split_f16.hip); the gradient chain of each sample runs on the mantissa of its dY "
                     "(exact rescaling), so accuracy does not depend on the size or spread of dY; the forward recomputation and the "
                     "operand transposes on the matrix pipe are extra, uncounted work; the event bracket also holds the three small "
                     "pack / absmax / reduce launches" if f16 else

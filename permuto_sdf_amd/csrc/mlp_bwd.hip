@@ -2,7 +2,7 @@
 // Autograd backward of the reference's torch.nn.Sequential(Linear, GELU, ...) evaluators
 // (permuto_sdf_py/models/models.py:153-161 SDF net, :451-470 background nets) and of the BASELINE 64x3 net.
 //
-// Design (third version; the two earlier ones are kept under tools/rejected/ with their measurements):
+// Design (third version; the two earlier ones are kept under attic/rejected/ with their measurements):
 //   * 16-sample tiles, v_mfma_f32_16x16x4_f32.  Same FLOP/cycle as the 32x32x2 instruction, but the per-wave state of
 //     a tile (activations and their derivatives of three 64-wide layers) is 96 registers instead of 192.
 //   * The weight gradient dW_l = dZ_l^T H_{l-1} is a product whose k dimension is the SAMPLE index, so its MFMA

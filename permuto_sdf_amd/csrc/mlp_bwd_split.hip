@@ -2,7 +2,7 @@
 // fp32 accuracy: every fp32 operand is cut into three bf16 pieces and six of the nine piece products are kept (error
 // 2^-24-ish per product, the level of an fp32 evaluation; same scheme as the forward, csrc/mlp.hip).  Why: fp32 MFMAs and
 // VALU work do not overlap on gfx950 (profiles/r01_mfma_valu_overlap.txt), and the fp32 kernel (mlp_bwd.hip) spends 49 %
-// of its time in them.  Structure (tools/prototypes/mlp_bwd_split_bf16_v3.hip is the standalone prototype with its history):
+// of its time in them.  Structure (attic/prototypes/mlp_bwd_split_bf16_v3.hip is the standalone prototype with its history):
 //   * 16-sample tiles on v_mfma_f32_16x16x32_bf16, one wave per SIMD, dW accumulators persistent in registers (176);
 //   * forward recomputed from X; gelu and gelu' from one exponential and one reciprocal (gelu_rational below);
 //   * the sample<->feature transposes that the dW products need are MFMAs against a 0/1 operand (no LDS, no VALU);

@@ -4,7 +4,7 @@
 // the dW products all four (the fourth rides in an otherwise empty K half).  Against the bf16 scheme: 274 instead of 480 MFMAs
 // per 16-sample tile, operand splitting 5 instead of 9 VALU instructions per pair, a 95-KB instead of a 142-KB weight image
 // (so every input width up to 64 gets double-buffered staging).  What makes it legitimate on gfx950 (measured with
-// tools/prototypes/mlp_fwd_split_f16.hip): the matrix pipe HONOURS fp16 subnormal inputs, so a low piece below 2^-14 keeps an absolute
+// attic/prototypes/mlp_fwd_split_f16.hip): the matrix pipe HONOURS fp16 subnormal inputs, so a low piece below 2^-14 keeps an absolute
 // precision of 2^-24 instead of being flushed.  fp16 has 5 exponent bits, hence two guards:
 //   * the gradient chain of sample n is linear in dY[n], so it is evaluated on the MANTISSA of dY[n] (sign kept, magnitude
 //     scaled into [2^4, 2^5)) and dX[n] is multiplied by 2^(e(n) - 4) at the store (exact): every sample keeps 22 bits RELATIVE TO ITSELF, whatever

@@ -299,7 +299,7 @@ __device__ __forceinline__ void init_bias4(f32x16 (&acc)[T], const float* __rest
 // ---- the same with TWO fp16 pieces per operand (round 3; opt-in, see psdf_mlp_forward_f16): a = a0 + a1, a0 = fp16(a) rounded
 // toward zero (the remainder is exact in fp32), a1 = fp16(a - a0); products a1 b0 + a0 b1 + a0 b0 on v_mfma_f32_32x32x16_f16.
 // Half the MFMAs and about half the splitting work of the three-piece bf16 scheme; gfx950's matrix pipe honours fp16 subnormals
-// (tools/prototypes/mlp_fwd_split_f16.hip), so small low pieces keep an absolute precision of 2^-24; values must stay below 65504.
+// (attic/prototypes/mlp_fwd_split_f16.hip), so small low pieces keep an absolute precision of 2^-24; values must stay below 65504.
 // The image keeps the three-slot record layout (slot 2 unused), so SplitPlan is shared.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8h(const float (&x)[8], f16x8& hi, f16x8& lo) {

@@ -570,7 +570,7 @@ def test_split_f16_backward_range_guard(dev, what, form, monkeypatch):
 @pytest.mark.parametrize("K0,N", [(36, 200_003), (52, 70_000), (20, 4_097), (64, 33)])
 def test_split_f16_forward_against_float64(dev, K0, N):
     """psdf_mlp_forward_f16 (two fp16 pieces per operand, three products; opt-in, the hot path's forward): against float64,
-    bar 4e-6 of the largest output (measured ~1e-6 relative: tools/prototypes/mlp_fwd_split_f16.hip: 2.8e-6 absolute at outputs
+    bar 4e-6 of the largest output (measured ~1e-6 relative: attic/prototypes/mlp_fwd_split_f16.hip: 2.8e-6 absolute at outputs
     up to 2.5); inputs with small channels (encoding-like) included; other nets say -2."""
     import copy
     from permuto_sdf_amd._lib import PsdfError

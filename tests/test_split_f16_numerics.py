@@ -43,7 +43,7 @@ def test_remainder_is_exact_and_pieces_reconstruct_to_22_bits():
     err = np.abs(hi.astype(np.float64) + lo.astype(np.float64) - x) / np.abs(x)
     assert err[ok].max() <= 2.0 ** -22
     # below 2^-3 the low piece is an fp16 SUBNORMAL: absolute precision 2^-25 (half the subnormal spacing), which is what makes
-    # the scheme legitimate on gfx950 only because its matrix pipe honours subnormal inputs (tools/prototypes/mlp_fwd_split_f16.hip)
+    # the scheme legitimate on gfx950 only because its matrix pipe honours subnormal inputs (attic/prototypes/mlp_fwd_split_f16.hip)
     small = np.abs(x) <= 2.0 ** -3
     assert np.abs(hi.astype(np.float64) + lo.astype(np.float64) - x)[small].max() <= 2.0 ** -25
 

@@ -1,5 +1,5 @@
 """Fit and check a cheaper GELU for the MLP kernels (the forward is VALU-issue bound on GELU since it moved to the bf16
-matrix pipe; tools/prototypes/mlp_fwd_split_bf16.hip).  Identity used:
+matrix pipe; attic/prototypes/mlp_fwd_split_bf16.hip).  Identity used:
 
     gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),          Phi(-t) = exp2(P(t)),  t = |x|
 
