@@ -86,10 +86,56 @@ def fuse_lipshitz(ref):
     return ours
 
 
+# ---- round 5: two more pieces of the reference's step behind its own objects --------------------------------------------------
+def _fused_compute_weights(self, ray_samples_packed, sdf, gradients, cos_anneal_ratio, forced_variance=None):
+    """VolumeRenderingNeus.compute_weights (volume_rendering_modules.py:129-172) with the ~30 elementwise launches between
+    `inv_s` and `alpha` (and their ~60 autograd nodes) as ONE differentiable operator (csrc/neus.hip); the deviation network, the
+    transmittance cumprod and the per-ray sum are the module's own sub-modules, untouched"""
+    from .neus import neus_alpha
+    inv_s = self.deviation_network(forced_variance)
+    inv_s = inv_s.clip(1e-6, 1e6)
+    self.last_inv_s = inv_s
+    alpha, one_minus = neus_alpha(sdf, ray_samples_packed.samples_dirs, gradients, ray_samples_packed.samples_dt, inv_s,
+                                  cos_anneal_ratio)
+    transmittance, bg_transmittance = self.cumprod_alpha2transmittance_module(ray_samples_packed, one_minus)
+    weights = (alpha * transmittance).view(-1, 1)
+    weights_sum, _ = self.sum_ray_module(ray_samples_packed, weights)
+    return weights, weights_sum, bg_transmittance, inv_s
+
+
+def _fused_get_sdf_and_gradient(self, points, iter_nr, method="autograd"):
+    """SDF.get_sdf_and_gradient (models.py:199-251), autograd branch: the same differentiated evaluation, but the inner
+    torch.autograd.grad no longer computes -- and throws away -- the lattice and the MLP parameter gradients of the first-order
+    pass (the encoding and the fused MLP are told that only the input gradient is wanted); twice differentiable as before"""
+    if method != "autograd" or not hasattr(self.mlp_sdf, "input_gradient_only") or not hasattr(self.encoding, "positions_gradient_only"):
+        return type(self).get_sdf_and_gradient(self, points, iter_nr, method)
+    with torch.set_grad_enabled(True):
+        points.requires_grad_(True)
+        sdf, geom_feat = self.forward(points, iter_nr)
+        d_output = torch.ones_like(sdf, requires_grad=False, device=sdf.device)
+        with self.encoding.positions_gradient_only(), self.mlp_sdf.input_gradient_only():
+            gradients = torch.autograd.grad(outputs=sdf, inputs=points, grad_outputs=d_output, create_graph=True,
+                                            retain_graph=True, only_inputs=True)[0]
+    return sdf, gradients, geom_feat
+
+
 def fuse_model(model, verbose=False):
-    """swap every direct child that is a Linear/GELU Sequential or a reference-style LipshitzMLP; returns the names swapped"""
+    """swap every direct child that is a Linear/GELU Sequential or a reference-style LipshitzMLP; returns the names swapped.
+    PSDF_FUSE_REFERENCE_STEP=0 keeps the two round-5 additions off (NeuS weights of a `VolumeRenderingNeus` child as one operator,
+    input-gradient-only inner pass of `SDF.get_sdf_and_gradient`)."""
     done = []
+    step_level = os.environ.get("PSDF_FUSE_REFERENCE_STEP", "1") != "0"
+    if step_level and type(model).__name__ == "SDF" and hasattr(model, "get_sdf_and_gradient") and "get_sdf_and_gradient" not in model.__dict__:
+        import types
+        model.__dict__["get_sdf_and_gradient"] = types.MethodType(_fused_get_sdf_and_gradient, model)
+        done.append("get_sdf_and_gradient()")
     for name, child in list(model.named_children()):
+        if step_level and type(child).__name__ == "VolumeRenderingNeus" and hasattr(child, "cumprod_alpha2transmittance_module"):
+            # same object, same Parameters and state_dict keys: only the class it looks its method up in changes
+            child.__class__ = type("FusedVolumeRenderingNeus", (type(child),), {"compute_weights": _fused_compute_weights,
+                                                                               "_reference_class": type(child)})
+            done.append(name + ".compute_weights()")
+            continue
         if isinstance(child, (FusedSequential, M.LipshitzMLP, M.FusedMLP)):
             continue
         if isinstance(child, torch.nn.Sequential) and _is_linear_gelu_stack(child):
@@ -108,8 +154,14 @@ def fuse_model(model, verbose=False):
 def unfuse_model(model):
     """undo fuse_model (same Parameters again): for A/B comparisons of the fused and the torch evaluation of one set of weights"""
     done = []
+    if "get_sdf_and_gradient" in model.__dict__:
+        del model.__dict__["get_sdf_and_gradient"]
+        done.append("get_sdf_and_gradient()")
     for name, child in list(model.named_children()):
-        if isinstance(child, FusedSequential):
+        if hasattr(type(child), "_reference_class"):
+            child.__class__ = type(child)._reference_class
+            done.append(name + ".compute_weights()")
+        elif isinstance(child, FusedSequential):
             setattr(model, name, torch.nn.Sequential(*list(child)))
             done.append(name)
         elif isinstance(child, M.LipshitzMLP) and "_reference_module" in child.__dict__:

@@ -109,8 +109,12 @@ class ManualTrainer(Trainer):
         pf, self._prefetched = self._prefetched, None
         if pf is not None and pf.get("pcg") is not None:
             from .bridge import OccupancyGrid, RaySampler, VolumeRendering
-            for cls, (st, inc) in zip((OccupancyGrid, RaySampler, VolumeRendering), pf["pcg"]):
-                cls._rng.state, cls._rng.inc = st, inc
+            owners = (OccupancyGrid, RaySampler, VolumeRendering)
+            # only where the stream still stands where the prefetch left it: a caller that has set the generators itself since
+            # (tools/reference_step_parity.py copies the reference's states in) keeps what it set
+            for cls, (st, inc), after in zip(owners, pf["pcg"], pf["pcg_after"]):
+                if (cls._rng.state, cls._rng.inc) == after:
+                    cls._rng.state, cls._rng.inc = st, inc
 
     def _launch_prefetch(self, reel, next_git):
         """The march is the largest kernel of the step (0.21 ms) and runs on 12 waves: nothing it needs -- the grid, the image
@@ -143,7 +147,9 @@ class ManualTrainer(Trainer):
             begun = self._samples_begin(rays[0], rays[1], True)
             done = torch.cuda.Event()
             done.record(side)
-        self._prefetched = dict(git=next_git, nr_rays=self.nr_rays, reel=id(reel), rays=rays, begun=begun, done=done, pcg=pcg)
+        pcg_after = [(c._rng.state, c._rng.inc) for c in (OccupancyGrid, RaySampler, VolumeRendering)]
+        self._prefetched = dict(git=next_git, nr_rays=self.nr_rays, reel=id(reel), rays=rays, begun=begun, done=done, pcg=pcg,
+                                pcg_after=pcg_after)
 
     def _hand_written_step_applies(self):
         """The hand-written step is built on the fused compositing kernels (at most 256 samples per ray: foreground

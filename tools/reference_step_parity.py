@@ -154,6 +154,8 @@ def main():
                 p.__init__()
             for _ in range(a.sphere_iters + a.warm_iters):
                 trm.step(reel)
+            if hasattr(trm, "_drop_prefetch"):     # the last step has issued the NEXT step's sampling ahead of time: undo it (the
+                trm._drop_prefetch()               # jitter generators return to their state before it) before they are snapshotted
             n0 = a.sphere_iters
             # ---- snapshot: networks (reference checkpoint layout), grid, ray count, generators
             state = {k: {n: v.detach().clone() for n, v in m.state_dict().items()}
