@@ -97,6 +97,12 @@ def test_round3_kernels_do_not_spill(objdir, tmp_path):
         assert b["vgpr_count"] <= 512 and b["agpr_count"] >= acc, b
         assert b["vgpr_spill_count"] == 0 and b["private_segment_fixed_size"] == 0, b
     assert _one(k, r"mlp_bwd_split_f16_kernelILi3EEEv")["agpr_count"] <= 184
+    # round 5: the N-split wave pair (two waves per SIMD, 88 accumulators per wave, all of them in VGPRs: a kernel with a
+    # 256-register budget that asks for ANY accumulation register gets a fixed 128 + 128 split): fits, nothing in scratch
+    b = _one(k, r"mlp_bwd_split_f16_pair_kernelILi3EEEv")
+    assert b["vgpr_count"] <= 256 and b["agpr_count"] == 0 and b["vgpr_spill_count"] == 0 and b["private_segment_fixed_size"] == 0, b
+    b = _one(k, r"mlp_bwd_split_f16_cd_kernelILi3EEEv")        # chain / dW pair: 256 registers too (its spills: SPILLING below)
+    assert b["vgpr_count"] <= 256 and b["agpr_count"] == 0, b
     k = _kernels(os.path.join(objdir, "mlp_wide.o"), str(tmp_path))
     for pat in (r"mlp_wide_bwd_kernelILi7ELi8ELi8ELi4ELi1E", r"mlp_wide_bwd_kernelILi4ELi4ELi4ELi4ELi5E"):
         b = _one(k, pat)
@@ -126,6 +132,10 @@ SPILLING = {
     r"mlp_dbl_bwd_kernelILi3ELi4ELi4ELi4ELi1ELb1EE": 256, r"mlp_dbl_bwd_kernelILi4ELi4ELi4ELi4ELi1ELb1EE": 320,
     # background colour head 80 -> 64x2 -> 3 with parameter gradients (models.py:463-469): every training step, one register
     r"mlp_bwd_kernelILi5ELi4ELi4ELi0ELi1ELb1ELb1ELb1ELi4E": 8,
+    # round 5, OPT-IN form of the split-fp16 backward (PSDF_MLP_BWD_F16_FORM=cd; the default one-wave kernel and the `pair` form do
+    # not spill): the dW wave of the chain / dW pair holds all 176 accumulators in a 256-register budget; measured slower than the
+    # default either way (profiles/r05_mlp_pair_ab.txt)
+    r"mlp_bwd_split_f16_cd_kernelILi3E": 40,
     # fused encode -> MLP forward of a 32-wide net with 33 outputs (psdf_encode_mlp_forward: the sphere tracer's colour pass)
     r"fused_fwd_kernelILi2ELi2ELi2ELi2ELb0EE": 8,
 }
