@@ -1158,9 +1158,9 @@ int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, c
 // parameter gradients from the workgroup-cooperative kernel (mlp_wide.hip); their single-wave dW instantiations spilled 128 - 253
 // registers and were reachable only while a stream was being captured -- they are not built any more (round 4): such a call
 // returns PSDF_ERR_UNSUPPORTED (tests/test_dispatch_tables.py lists every instantiation that still spills, with its route).
-template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool WITH_DW = true>
-int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
-  constexpr int NW = (T1 <= 2 && T2 <= 2 && T3 <= 2) ? 8 : BW;   // 32-wide nets: two waves per SIMD
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool WITH_DW, int NW_>
+int launch_bwd_nw(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
+  constexpr int NW = NW_;   // waves per workgroup (launch_bwd below picks it)
   const int64_t ntiles = (N + 15) / 16;
   int64_t blocks = (ntiles + NW - 1) / NW;
   if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
@@ -1202,6 +1202,17 @@ int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, floa
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
   }
+}
+// 32-wide nets: two waves per SIMD (8 per workgroup) pay from ~2^17 samples on -- 131.8 against 148.6 us at 262 144 samples --
+// but at a training step's ~49 K samples one wave per SIMD with the whole register file is faster AND does not spill (the
+// 8-wave instantiation of the reference's SDF net parks 24 registers in scratch): 49.7 against 52.9 us, 25.4 against 30.9 us at
+// 1 024 samples (round 5, tools/small_batch_bench.py 52-32-32-32-33).  Wider nets: one wave per SIMD always.
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool WITH_DW = true>
+int launch_bwd(const Plan16& p, int64_t N, const float* X, const float* dY, float* dX, const BwdPtrs& a, hipStream_t st) {
+  if constexpr (T1 <= 2 && T2 <= 2 && T3 <= 2) {
+    if (N >= ((int64_t)1 << 17)) return launch_bwd_nw<TI0, T1, T2, T3, OUT_T, FINAL_DOT, WITH_DW, 8>(p, N, X, dY, dX, a, st);
+  }
+  return launch_bwd_nw<TI0, T1, T2, T3, OUT_T, FINAL_DOT, WITH_DW, BW>(p, N, X, dY, dX, a, st);
 }
 
 }  // namespace

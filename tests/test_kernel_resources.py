@@ -124,8 +124,9 @@ SPILLING = {
     r"mlp_bwd_kernelILi3ELi4ELi4ELi4ELi1ELb1ELb1ELb1ELi4E": 64, r"mlp_bwd_kernelILi3ELi4ELi4ELi4ELi1ELb1ELb0ELb1ELi4E": 64,
     r"mlp_bwd_kernelILi4ELi4ELi4ELi4ELi1ELb1ELb1ELb1ELi4E": 128, r"mlp_bwd_kernelILi4ELi4ELi4ELi4ELi1ELb1ELb0ELb1ELi4E": 64,
     r"mlp_bwd_kernelILi2ELi4ELi4ELi4ELi1ELb1ELb1ELb1ELi4E": 32,
-    # the reference's SDF net 52 -> 32x3 -> 33 with parameter gradients: twice per training step (train_manual.py), two waves
-    # per SIMD at the 256-register limit
+    # the reference's SDF net 52 -> 32x3 -> 33 with parameter gradients, two waves per SIMD at the 256-register limit: batches
+    # of 2^17 samples and more only (round 5: a training step's ~49 K samples run the one-wave-per-SIMD instantiation, which does
+    # not spill and is faster there -- launch_bwd in csrc/mlp_bwd.hip)
     r"mlp_bwd_kernelILi4ELi2ELi2ELi2ELi3ELb0ELb1ELb1ELi8E": 24, r"mlp_bwd_kernelILi4ELi2ELi2ELi2ELi3ELb0ELb0ELb1ELi8E": 8,
     # double backward of the BASELINE net (psdf_mlp_double_backward; the reference's own net is 32 wide and does not spill):
     # fp32-MFMA form, one wave per SIMD -- DESIGN.md "Next": the workgroup-cooperative split form
