@@ -215,6 +215,16 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
 
 // The same evaluator on the bf16 matrix pipe with split fp32 operands (mlp_device.h, "split-bf16 operand path").
 // CH: k-steps of layer 0 whose loads are issued together (= all of them when the input has <= 64 features).
+// activation of the split forwards: packed arithmetic for the two-piece fp16 form (VALU-count bound), one element per
+// instruction for the three-piece bf16 form (see apply_gelu_scalar / apply_gelu_packed in mlp_device.h)
+#if !defined(PSDF_FWD_F16_GELU_PACKED)
+#define PSDF_FWD_F16_GELU_PACKED 1
+#endif
+#define GELU_SPLIT(T_, H_)                                           \
+  do {                                                               \
+    if constexpr (F16 && PSDF_FWD_F16_GELU_PACKED) apply_gelu_packed<T_>(H_); \
+    else apply_gelu_scalar<T_>(H_);                                  \
+  } while (0)
 template <int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, int CH, bool F16 = false>
 __global__ void __launch_bounds__(PSDF_BLOCK, 2)
     mlp_fwd_split_kernel(MlpPlan p, SplitPlan sp, int64_t N, const float* __restrict__ X,
@@ -270,17 +280,17 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
         split_mac<T1, F16>(h1, xs[i], simg + sp.w_rec[0] + s * 192, ns0, lane);
       }
     }
-    apply_gelu_scalar<T1>(h1);
+    GELU_SPLIT(T1, h1);
     f32x16 h2[T2];
     init_bias4<T2>(h2, tail + sp.b_off[1], h);
     split_chain<T1, T2, F16>(h1, h2, simg + sp.w_rec[1], lane);
-    apply_gelu_scalar<T2>(h2);
+    GELU_SPLIT(T2, h2);
     constexpr int TL = (T3 > 0) ? T3 : T2;
     f32x16 hl[TL];
     if constexpr (T3 > 0) {
       init_bias4<T3>(hl, tail + sp.b_off[2], h);
       split_chain<T2, T3, F16>(h2, hl, simg + sp.w_rec[2], lane);
-      apply_gelu_scalar<T3>(hl);
+      GELU_SPLIT(T3, hl);
     } else {
 #pragma unroll
       for (int t = 0; t < T2; t++) hl[t] = h2[t];

@@ -167,6 +167,13 @@ __device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __b
 __device__ __forceinline__ f32x2 sp2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ f32x2 lo2(const f32x4& v) { return __builtin_shufflevector(v, v, 0, 1); }
 __device__ __forceinline__ f32x2 hi2(const f32x4& v) { return __builtin_shufflevector(v, v, 2, 3); }
+// elementwise products of register quadruples as TWO packed multiplies (the file is built without the SLP vectoriser, which is
+// what would otherwise pair the four scalar multiplies of `a * b`): 117 -> ~60 multiply instructions per tile
+__device__ __forceinline__ f32x4 mul4(const f32x4& a, const f32x4& b) {
+  const f32x2 l = lo2(a) * lo2(b), h = hi2(a) * hi2(b);
+  return f32x4{l.x, l.y, h.x, h.y};
+}
+__device__ __forceinline__ f32x4 mul4s(const f32x4& a, float s) { return mul4(a, f32x4{s, s, s, s}); }
 // running sum of products over the samples of a lane.  PAIR: two partial sums (samples 4 g + {0, 1} and 4 g + {2, 3}: register
 // pairs as an MFMA leaves them, so the packed multiply-adds need no moves -- the scalar form cost 86 v_mov per tile), added in the
 // epilogue; the widest instantiation (K0 > 48) has no registers for the second half and keeps one sum
@@ -231,8 +238,18 @@ __device__ __forceinline__ void gelu_rational4(f32x2 za, f32x2 zb, f32x2& ha, f3
   const f32x2 ea = (za * za) * sp2(-0.72134752044448170368f), eb = (zb * zb) * sp2(-0.72134752044448170368f);
   const f32x2 Ea = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
   const f32x2 Eb = {__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
+#if !defined(PSDF_F16_GELU_ABS_MOD)
+#define PSDF_F16_GELU_ABS_MOD 1
+#endif
+#if PSDF_F16_GELU_ABS_MOD
+  // 1 + p |z|: two scalar fmas whose |.| is a source modifier (no instruction), instead of two v_and + one packed fma -- the
+  // results only feed v_rcp_f32, which is scalar anyway; same fused arithmetic, bit-identical
+  const f32x2 da = {__builtin_fmaf(__builtin_fabsf(za.x), 0.39f, 1.0f), __builtin_fmaf(__builtin_fabsf(za.y), 0.39f, 1.0f)};
+  const f32x2 db = {__builtin_fmaf(__builtin_fabsf(zb.x), 0.39f, 1.0f), __builtin_fmaf(__builtin_fabsf(zb.y), 0.39f, 1.0f)};
+#else
   const f32x2 da = pk_fma2(f32x2{fabsf(za.x), fabsf(za.y)}, sp2(0.39f), sp2(1.0f));
   const f32x2 db = pk_fma2(f32x2{fabsf(zb.x), fabsf(zb.y)}, sp2(0.39f), sp2(1.0f));
+#endif
   const f32x2 ta = {__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
   const f32x2 tb = {__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
   f32x2 qa = sp2(5.384693295e-02f), qb = sp2(5.384693295e-02f);
@@ -240,9 +257,20 @@ __device__ __forceinline__ void gelu_rational4(f32x2 za, f32x2 zb, f32x2& ha, f3
   HORNER(-2.582434118e-01f) HORNER(3.751679361e-01f) HORNER(-1.663514599e-02f) HORNER(1.944366544e-01f) HORNER(1.514270604e-01f)
 #undef HORNER
   const f32x2 la = (qa * ta) * Ea, lb = (qb * tb) * Eb;
+#if !defined(PSDF_F16_GELU_COPYSIGN)
+#define PSDF_F16_GELU_COPYSIGN 1
+#endif
+#if PSDF_F16_GELU_COPYSIGN
+  // cdf = 1/2 + sign(z) (1/2 - Phi(-|z|)): one v_bfi_b32 per value instead of a compare and a select (1/2 - l >= 0 always);
+  // differs from `z < 0 ? l : 1 - l` by at most one rounding of the sum (6e-8)
+  const f32x2 ma = sp2(0.5f) - la, mb = sp2(0.5f) - lb;
+  const f32x2 ca = f32x2{__builtin_copysignf(ma.x, za.x), __builtin_copysignf(ma.y, za.y)} + sp2(0.5f);
+  const f32x2 cb = f32x2{__builtin_copysignf(mb.x, zb.x), __builtin_copysignf(mb.y, zb.y)} + sp2(0.5f);
+#else
   const f32x2 oa = sp2(1.0f) - la, ob = sp2(1.0f) - lb;
   const f32x2 ca = {za.x < 0.f ? la.x : oa.x, za.y < 0.f ? la.y : oa.y};
   const f32x2 cb = {zb.x < 0.f ? lb.x : ob.x, zb.y < 0.f ? lb.y : ob.y};
+#endif
   ha = za * ca;
   hb = zb * cb;
   ga = pk_fma2(za, Ea * sp2(0.3989422804014327f), ca);
@@ -319,7 +347,7 @@ __device__ __forceinline__ void layer_bwd(const f32x4 (&dz)[NT], f32x4 (&dh)[NTO
 #pragma unroll
   for (int ti = 0; ti < NTI; ti++) {
     BT B;
-    split4(hT[ti] * rT, B);      // H of sample 4 g + r carries that sample's dY magnitude (see the header)
+    split4(mul4(hT[ti], rT), B);      // H of sample 4 g + r carries that sample's dY magnitude (see the header)
 #pragma unroll
     for (int to = 0; to < NT; to++) dW[to][ti] = dw_mac(dW[to][ti], A[to], B);
   }
@@ -551,7 +579,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
         const int ex = (int)(__float_as_uint(dyT[r]) >> 23) & 255;
         int er = ex + kscale - CHAIN_EXP + H_PRESCALE_EXP;  // dZ of the chain = true dZ * 2^(CHAIN_EXP - e(n)); + the H pre-scale
         er = er < 1 ? 0 : (er > 254 ? 254 : er);            // below 2^-126 after scaling: the contribution is dropped
-        rT[r] = (in && ex > CHAIN_EXP && ex != 255) ? __uint_as_float((uint32_t)er << 23) : ((in && ex == 255) ? 1.f : 0.f);
+        uint32_t bits = (uint32_t)er << 23;                 // (selects, not branches: the nested conditional compiled to four
+        bits = ex > CHAIN_EXP ? bits : 0u;                  //  exec-masked blocks per tile)
+        bits = ex == 255 ? 0x3F800000u : bits;
+        rT[r] = __uint_as_float(in ? bits : 0u);
         dyT[r] = in ? dyT[r] * sc : 0.f;
       }
       db4 += (dyT[0] + dyT[1]) + (dyT[2] + dyT[3]);
@@ -572,22 +603,19 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     float dy, dy_pow2;
     dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) dz[t][r] *= w4[t][r] * dy;
-    }
+    for (int t = 0; t < NT; t++) dz[t] = mul4(dz[t], mul4s(w4[t], dy));
     // ---------------- layer 3
     zero_init<NT>(a);
     layer_bwd<NT, NT, PAIR>(dz, a, lds + OFF_T2, lane, id, h2T, dW3, db3, rT);  // a = dH2^T
 #pragma unroll
-    for (int t = 0; t < NT; t++) a[t] *= GLDS ? gl[(NT + t) * 64] : g2[t];   // dZ2^T
+    for (int t = 0; t < NT; t++) a[t] = mul4(a[t], GLDS ? gl[(NT + t) * 64] : g2[t]);   // dZ2^T
     // ---------------- layer 2 (the prefetch goes out here: late enough that the early part of the tile does not wait on
     // it, early enough for an HBM round trip before the next tile)
     if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats);
     zero_init<NT>(dz);
     layer_bwd<NT, NT, PAIR>(a, dz, lds + OFF_T1, lane, id, h1T, dW2, db2, rT);  // dz = dH1^T
 #pragma unroll
-    for (int t = 0; t < NT; t++) dz[t] *= GLDS ? gl[t * 64] : g1[t];         // dZ1^T
+    for (int t = 0; t < NT; t++) dz[t] = mul4(dz[t], GLDS ? gl[t * 64] : g1[t]);         // dZ1^T
     // ---------------- layer 1: H = X in feature-lane order, straight from the staged rows
     f32x4 xT[NT0], dx[NT0];
 #pragma unroll
