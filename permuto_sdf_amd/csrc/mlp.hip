@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
   extern __shared__ __align__(16) float lds[];
   for (int i = threadIdx.x; i < p.total; i += PSDF_BLOCK) lds[i] = packed[i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the tile loop is uniform)
   const int h = lane >> 5, sl = lane & 31;
   const int K0 = p.dims[0];
   const int OUT = p.dims[p.n_layers];
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, 2)
   }
   __syncthreads();
   const float* tail = reinterpret_cast<const float*>(simg + sp.tail_rec);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the tile loop is uniform)
   const int h = lane >> 5, sl = lane & 31;
   const int K0 = p.dims[0];
   const int OUT = p.dims[p.n_layers];

@@ -405,8 +405,12 @@ __device__ __forceinline__ void dy_parts(float dy, float& mant, float& pow2) {
   const uint32_t b = __float_as_uint(dy);
   const int ex = (int)(b >> 23) & 255;
   const bool special = ex == 255, zero = ex <= CHAIN_EXP;
-  mant = zero ? 0.f : (special ? dy : __uint_as_float((b & 0x807FFFFFu) | ((uint32_t)(127 + CHAIN_EXP) << 23)));
-  pow2 = zero ? 0.f : (special ? 1.f : __uint_as_float((uint32_t)(ex - CHAIN_EXP) << 23));
+  // selects on the bit patterns (the nested conditional on floats compiled to an exec-masked block per tile)
+  uint32_t m = (b & 0x807FFFFFu) | ((uint32_t)(127 + CHAIN_EXP) << 23), p = (uint32_t)(ex - CHAIN_EXP) << 23;
+  m = special ? b : m;
+  p = special ? 0x3F800000u : p;
+  mant = __uint_as_float(zero ? 0u : m);
+  pow2 = __uint_as_float(zero ? 0u : p);
 }
 
 // X [K0, N], dY [1, N], dX [K0, N] (optional) feature-major; img = the LDS image (mlp_split_pack_kernel); partial
@@ -433,7 +437,9 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   for (int i = threadIdx.x; i < NREC; i += NWAVES * 64) lds[i] = img[i];
   __syncthreads();
   const float* tail = reinterpret_cast<const float*>(lds + OFF_F32);
-  const int lane_k = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a scalar: tile numbers, loop bounds and the prefetch condition are then uniform to the compiler -- the
+  //  prefetch block was exec-masked with vector compares before)
+  const int lane_k = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const f16x8 id[2] = {ident_op(0, lane_k), ident_op(1, lane_k)};
   f32x4 dW1[NT][NT0], dW2[NT][NT], dW3[NT][NT];
 #pragma unroll
@@ -601,7 +607,10 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
     }
     // the chain of sample n runs on the mantissa of its dY (magnitude in [2^4, 2^5)); dX is multiplied by 2^(e(n) - 4) at the store
     float dy, dy_pow2;
-    dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
+    {
+      const float dy_read = xb[OFF_DY + c];         // (read first, then select: `live ? read : 0` became an exec-masked load)
+      dy_parts(live ? dy_read : 0.f, dy, dy_pow2);
+    }
 #pragma unroll
     for (int t = 0; t < NT; t++) dz[t] = mul4(dz[t], mul4s(w4[t], dy));
     // ---------------- layer 3
