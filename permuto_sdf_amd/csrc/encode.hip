@@ -153,27 +153,30 @@ template <int F>
 __device__ __forceinline__ bool combine_runs16(uint32_t key, bool valid, float (&v)[F]) {
   constexpr int ROW_SHR = 0x110, ROW_SHL = 0x100;
   const int k = valid ? (int)key : -1 - (int)psdf::lane_id();  // invalid lanes never match a neighbour
-  const int kprev = __builtin_amdgcn_update_dpp(-1000, k, ROW_SHR | 1, 0xf, 0xf, false);
-  const int head = (kprev != k) ? 1 : 0;  // first lane of a row: kprev = -1000 -> head
-  int f = head;
+  // Every cross-lane move uses bound_ctrl: a lane that would read across the edge of its 16-lane row receives 0 from the
+  // instruction itself (otherwise the compiler preloads each destination with a v_mov: 10 per contribution).  The flag is
+  // therefore kept INVERTED -- j = 1: "joined to the run of the lane before" -- so that the 0 shifted in means "a run starts
+  // here".  (The first lane of a row may read j = 1 against the shifted-in key 0; everything it then adds is a shifted-in 0.)
+  const int kprev = __builtin_amdgcn_update_dpp(0, k, ROW_SHR | 1, 0xf, 0xf, true);
+  const int joined = (kprev == k) ? 1 : 0;
+  int j = joined;
 #define PSDF_SCAN_STEP(D)                                                                                        \
   {                                                                                                              \
-    const int f2 = __builtin_amdgcn_update_dpp(1, f, ROW_SHR | D, 0xf, 0xf, false);                              \
+    const int j2 = __builtin_amdgcn_update_dpp(0, j, ROW_SHR | D, 0xf, 0xf, true);                               \
     float v2[F];                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < F; i++) v2[i] =                                                        \
-        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), ROW_SHR | D, 0xf, 0xf, false));      \
-    if (!f) {                                                                                                    \
-      _Pragma("unroll") for (int i = 0; i < F; i++) v[i] = v[i] + v2[i];                                         \
-      f = f2;                                                                                                    \
-    }                                                                                                            \
+        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), ROW_SHR | D, 0xf, 0xf, true));       \
+    _Pragma("unroll") for (int i = 0; i < F; i++) v[i] = j ? v[i] + v2[i] : v[i];                                \
+    j = j & j2;                                                                                                  \
   }
   PSDF_SCAN_STEP(1)
   PSDF_SCAN_STEP(2)
   PSDF_SCAN_STEP(4)
   PSDF_SCAN_STEP(8)
 #undef PSDF_SCAN_STEP
-  const int next_head = __builtin_amdgcn_update_dpp(1, head, ROW_SHL | 1, 0xf, 0xf, false);  // last lane of a row: 1
-  return valid && next_head != 0;
+  // the lane after: joined to this one (0 shifted in past the end of the row: a run ends with its row)
+  const int next_joined = __builtin_amdgcn_update_dpp(0, joined, ROW_SHL | 1, 0xf, 0xf, true);
+  return valid && next_joined == 0;
 }
 
 // TOTAL = slots x F.  8192 (48 KiB for F = 2) where the cache is all there is between the contributions and global float
