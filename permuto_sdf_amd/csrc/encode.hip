@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // switches the cache off for the rest of its walk (vote after its first tile: share of contributions that hit an
 // entry which already existed).
 constexpr uint32_t SC_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t Q_NONE = 0xFFFFFFFFu;   // "no contribution" in a thread's list of rows (rows are < capacity <= 2^31)
 #if !defined(PSDF_ENC_QSPT)
 #define PSDF_ENC_QSPT 2
 #endif
@@ -150,24 +151,26 @@ __device__ __forceinline__ void lds_add_pair(float* p, float a, float b, int& ho
 // that what reaches LDS has a multiplicity of at most 4 per wave -- within reach of the retries of lds_add_pair.
 // Returns true on the lanes that own a (partial) run sum.
 template <int F>
-__device__ __forceinline__ bool combine_runs16(uint32_t key, bool valid, float (&v)[F]) {
+__device__ __forceinline__ bool combine_runs16(uint32_t key, float (&v)[F]) {
   constexpr int ROW_SHR = 0x110, ROW_SHL = 0x100;
-  const int k = valid ? (int)key : -1 - (int)psdf::lane_id();  // invalid lanes never match a neighbour
+  // key Q_NONE: a lane without a contribution (v = 0).  Such lanes may join each other -- they add zeros and never own a run.
+  const int k = (int)key;
   // Every cross-lane move uses bound_ctrl: a lane that would read across the edge of its 16-lane row receives 0 from the
   // instruction itself (otherwise the compiler preloads each destination with a v_mov: 10 per contribution).  The flag is
   // therefore kept INVERTED -- j = 1: "joined to the run of the lane before" -- so that the 0 shifted in means "a run starts
   // here".  (The first lane of a row may read j = 1 against the shifted-in key 0; everything it then adds is a shifted-in 0.)
   const int kprev = __builtin_amdgcn_update_dpp(0, k, ROW_SHR | 1, 0xf, 0xf, true);
-  const int joined = (kprev == k) ? 1 : 0;
-  int j = joined;
+  const float joined = (kprev == k) ? 1.0f : 0.0f;
+  // The flag is a float 1.0 / 0.0 and the conditional add is ONE fused multiply-add per feature whose shifted operand comes
+  // through DPP (v_fmac_f32_dpp: v = shifted(v) * j + v; exact -- a product by 1 or 0 -- instead of v_add_dpp + v_cmp + v_cndmask),
+  // the flag update one v_mul_f32_dpp: 3 instructions per step for F = 2, was 7.  (A non-finite contribution now also spoils the
+  // lanes of its row that are NOT in its run, 0 x inf; such a step is lost either way.)
+  float j = joined;
 #define PSDF_SCAN_STEP(D)                                                                                        \
   {                                                                                                              \
-    const int j2 = __builtin_amdgcn_update_dpp(0, j, ROW_SHR | D, 0xf, 0xf, true);                               \
-    float v2[F];                                                                                                 \
-    _Pragma("unroll") for (int i = 0; i < F; i++) v2[i] =                                                        \
-        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), ROW_SHR | D, 0xf, 0xf, true));       \
-    _Pragma("unroll") for (int i = 0; i < F; i++) v[i] = j ? v[i] + v2[i] : v[i];                                \
-    j = j & j2;                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < F; i++) v[i] = __builtin_fmaf(                                         \
+        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), ROW_SHR | D, 0xf, 0xf, true)), j, v[i]); \
+    j = j * __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(j), ROW_SHR | D, 0xf, 0xf, true));      \
   }
   PSDF_SCAN_STEP(1)
   PSDF_SCAN_STEP(2)
@@ -175,8 +178,8 @@ __device__ __forceinline__ bool combine_runs16(uint32_t key, bool valid, float (
   PSDF_SCAN_STEP(8)
 #undef PSDF_SCAN_STEP
   // the lane after: joined to this one (0 shifted in past the end of the row: a run ends with its row)
-  const int next_joined = __builtin_amdgcn_update_dpp(0, joined, ROW_SHL | 1, 0xf, 0xf, true);
-  return valid && next_joined == 0;
+  const int next_joined = __builtin_amdgcn_update_dpp(0, __float_as_int(joined), ROW_SHL | 1, 0xf, 0xf, true);
+  return key != Q_NONE && next_joined == 0;
 }
 
 // TOTAL = slots x F.  8192 (48 KiB for F = 2) where the cache is all there is between the contributions and global float
@@ -264,39 +267,63 @@ struct Queues {
   int cap, np, shift;  // rows per partition = 1 << shift
 };
 constexpr int Q_MAX_PARTS = 64;
+constexpr int Q_LDS_INTS = 4 * Q_MAX_PARTS + 4;   // q_cnt, q_base, q_off (+1), q_gd; 3 vote words
 
 // Workgroup-collective append of up to NC contributions per thread to the level's partition queues.
 // Slots are reserved with an LDS counter per partition and ONE global atomic per (call, partition).
+// Addressing (round 5: the binning kernel is VALU bound, profiles/r05_pmc_sq_encode_bwd.txt, and the 64-bit entry offset
+// ((level * np + part) * cap + idx) took 12 vector instructions per contribution): the level's slice of the queues is a
+// wave-uniform base pointer; the entry offset inside it is 32 bits (queue_plan refuses plans whose level slice exceeds 2^32
+// bytes) and comes out of LDS ready made -- next to a partition's reserved tail (q_base[part], for the "queue full" test) sits
+// part * cap + tail (q_aux[part], 64 ints further: one ds_read2_b32 fetches both) -- so that a contribution needs two adds.
+struct LevelQueues {
+  char* rows;   // Q.rows + level * np * cap                [np, cap] uint16
+  char* vals;   // Q.vals + level * np * cap * F            [np, cap, F] float
+  uint32_t mask;   // rows per partition - 1
+};
+template <int F>
+__device__ __forceinline__ LevelQueues level_queues(const Queues& Q, int level) {
+  const int64_t e = (int64_t)level * Q.np * Q.cap;
+  return LevelQueues{reinterpret_cast<char*>(Q.rows + e), reinterpret_cast<char*>(Q.vals + e * F), (1u << Q.shift) - 1u};
+}
+template <int F>
+__device__ __forceinline__ void queue_store(const LevelQueues& LQ, uint32_t o, uint32_t row, const float* v) {
+  *reinterpret_cast<uint16_t*>(LQ.rows + (o * 2u)) = (uint16_t)(row & LQ.mask);
+  if (F == 2) {
+    *reinterpret_cast<float2*>(LQ.vals + (o * 8u)) = make_float2(v[0], v[F - 1]);
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; f++) *reinterpret_cast<float*>(LQ.vals + (o * (uint32_t)(F * 4) + (uint32_t)(f * 4))) = v[f];
+  }
+}
+
 template <int NC, int F>
-__device__ __forceinline__ void queue_push(const Queues& Q, int level, int* q_cnt, int* q_base, const bool (&pending)[NC],
+__device__ __forceinline__ void queue_push(const Queues& Q, int level, int* q_cnt, int* q_base,
                                            const uint32_t (&crow)[NC], const float (&cval)[NC][F],
                                            float* __restrict__ table_grad) {
+  int* q_aux = q_base + Q_MAX_PARTS;
+  const LevelQueues LQ = level_queues<F>(Q, level);
   if (threadIdx.x < Q.np) q_cnt[threadIdx.x] = 0;
   __syncthreads();
   int slot[NC];
 #pragma unroll
   for (int r = 0; r < NC; r++)
-    if (pending[r]) slot[r] = atomicAdd(&q_cnt[crow[r] >> Q.shift], 1);
+    if (crow[r] != Q_NONE) slot[r] = atomicAdd(&q_cnt[crow[r] >> Q.shift], 1);
   __syncthreads();
   if (threadIdx.x < Q.np) {
     const int c = q_cnt[threadIdx.x];
-    q_base[threadIdx.x] = c ? atomicAdd(&Q.tails[level * Q.np + threadIdx.x], c) : 0;
+    const int base = c ? atomicAdd(&Q.tails[level * Q.np + threadIdx.x], c) : 0;
+    q_base[threadIdx.x] = base;
+    q_aux[threadIdx.x] = (int)threadIdx.x * Q.cap + base;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < NC; r++) {
-    if (!pending[r]) continue;
+    if (crow[r] == Q_NONE) continue;
     const int part = crow[r] >> Q.shift;
     const int idx = q_base[part] + slot[r];
     if (idx < Q.cap) {
-      const int64_t o = ((int64_t)level * Q.np + part) * Q.cap + idx;
-      Q.rows[o] = (uint16_t)(crow[r] - ((uint32_t)part << Q.shift));
-      if (F == 2) {
-        *reinterpret_cast<float2*>(Q.vals + o * 2) = make_float2(cval[r][0], cval[r][F - 1]);
-      } else {
-#pragma unroll
-        for (int f = 0; f < F; f++) Q.vals[o * F + f] = cval[r][f];
-      }
+      queue_store<F>(LQ, (uint32_t)(q_aux[part] + slot[r]), crow[r], cval[r]);
     } else {  // queue full: exact fallback
 #pragma unroll
       for (int f = 0; f < F; f++) atomicAdd(table_grad + (int64_t)crow[r] * F + f, cval[r][f]);
@@ -311,17 +338,18 @@ __device__ __forceinline__ void queue_push(const Queues& Q, int level, int* q_cn
 // inside the group comes from the same LDS counter that reserves the queue segment), then written out linearly, so a
 // wave writes 64 consecutive queue entries.
 template <int NC>
-__device__ __forceinline__ void queue_push_staged(const Queues& Q, int level, int* q_cnt, int* q_base, int* q_off,
-                                                  float* stage, const bool (&pending)[NC], const uint32_t (&crow)[NC],
+__device__ __forceinline__ void queue_push_staged(const Queues& Q, int level, int* q_cnt, int* q_base, int* q_off, int* q_gd,
+                                                  float* stage, const uint32_t (&crow)[NC],
                                                   const float (&cval)[NC][2], float* __restrict__ table_grad) {
   uint32_t* st_row = reinterpret_cast<uint32_t*>(stage);                 // [NC * PSDF_BLOCK]
   float2* st_val = reinterpret_cast<float2*>(stage + NC * PSDF_BLOCK);   // [NC * PSDF_BLOCK]
+  const LevelQueues LQ = level_queues<2>(Q, level);
   if (threadIdx.x < Q.np) q_cnt[threadIdx.x] = 0;
   __syncthreads();
   int slot[NC];
 #pragma unroll
   for (int r = 0; r < NC; r++)
-    if (pending[r]) slot[r] = atomicAdd(&q_cnt[crow[r] >> Q.shift], 1);
+    if (crow[r] != Q_NONE) slot[r] = atomicAdd(&q_cnt[crow[r] >> Q.shift], 1);
   __syncthreads();
   if (threadIdx.x < 64) {   // the first wave: segment offsets by a wave scan (np <= 64).  A serial walk over the counters by
     // thread p (p LDS reads in a dependent chain, up to 31 of them, inside a barrier-separated phase) cost 4.5 % of the pair.
@@ -329,15 +357,22 @@ __device__ __forceinline__ void queue_push_staged(const Queues& Q, int level, in
     const int c = lane < Q.np ? q_cnt[lane] : 0;
     const int incl = psdf::wave_incl_scan_add_i(c);
     if (lane < Q.np) {
-      q_base[lane] = c ? atomicAdd(&Q.tails[level * Q.np + lane], c) : 0;
-      q_off[lane] = incl - c;
+      // staged entry i of partition p goes to queue slot tail_p + (i - off_p): what the write-out loop needs per entry is
+      // i + (tail_p - off_p) for the "queue full" test and i + (p * cap + tail_p - off_p) as the offset in the level's slice
+      // (q_gd: written here, behind two barriers of this call, and read by the write-out loop of this call only -- so the
+      // next call may start while slower waves are still in that loop, no barrier at the end)
+      const int base = c ? atomicAdd(&Q.tails[level * Q.np + lane], c) : 0;
+      const int off = incl - c;
+      q_off[lane] = off;
+      q_base[lane] = base - off;
+      q_gd[lane] = lane * Q.cap + base - off;
       if (lane == Q.np - 1) q_off[Q.np] = incl;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < NC; r++)
-    if (pending[r]) {
+    if (crow[r] != Q_NONE) {
       const int i = q_off[crow[r] >> Q.shift] + slot[r];
       st_row[i] = crow[r];
       st_val[i] = make_float2(cval[r][0], cval[r][1]);
@@ -348,11 +383,10 @@ __device__ __forceinline__ void queue_push_staged(const Queues& Q, int level, in
     const uint32_t row = st_row[i];
     const float2 v = st_val[i];
     const int part = row >> Q.shift;
-    const int idx = q_base[part] + (i - q_off[part]);
+    const int idx = i + q_base[part];
     if (idx < Q.cap) {
-      const int64_t o = ((int64_t)level * Q.np + part) * Q.cap + idx;
-      Q.rows[o] = (uint16_t)(row - ((uint32_t)part << Q.shift));
-      *reinterpret_cast<float2*>(Q.vals + o * 2) = v;
+      const float vv[2] = {v.x, v.y};
+      queue_store<2>(LQ, (uint32_t)(i + q_gd[part]), row, vv);
     } else {  // queue full: exact fallback
       atomicAdd(table_grad + (int64_t)row * 2, v.x);
       atomicAdd(table_grad + (int64_t)row * 2 + 1, v.y);
@@ -367,15 +401,14 @@ __device__ __forceinline__ void cache_drain_to_queue(SC& sc, const Queues& Q, in
                                                      int* q_base, float* __restrict__ table_grad) {
   for (int base = 0; base < SC::SC_SLOTS; base += PSDF_BLOCK) {
     const int i = base + threadIdx.x;
-    bool pending[1];
     uint32_t crow[1];
     float cval[1][F];
     const uint32_t tag = sc.tags[i];
-    pending[0] = tag != SC_EMPTY;
-    crow[0] = pending[0] ? tag : 0u;
+    static_assert(SC_EMPTY == Q_NONE, "an empty slot is 'no contribution'");
+    crow[0] = tag;
 #pragma unroll
     for (int f = 0; f < F; f++) cval[0][f] = sc.sums[i * F + f];
-    queue_push<1, F>(Q, level, q_cnt, q_base, pending, crow, cval, table_grad);
+    queue_push<1, F>(Q, level, q_cnt, q_base, crow, cval, table_grad);
     sc.tags[i] = SC_EMPTY;
   }
   __syncthreads();
@@ -488,10 +521,13 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
   }
   using SCache = ScatterCache<F, QUEUE ? 4096 : 8192>;
   SCache sc;
-  if (LATTICE) sc.init(lds);
   int* q_cnt = reinterpret_cast<int*>(lds + SCache::bytes() / 4);  // [Q_MAX_PARTS]
   int* q_base = q_cnt + Q_MAX_PARTS;                                          // [Q_MAX_PARTS]
   int* q_off = q_base + Q_MAX_PARTS;                                          // [Q_MAX_PARTS + 1]
+  int* q_gd = q_off + Q_MAX_PARTS + 1;                                        // [Q_MAX_PARTS]
+  int* q_vote = q_gd + Q_MAX_PARTS;                                           // [3]
+  if (QUEUE && threadIdx.x < 3) q_vote[threadIdx.x] = 0;   // (a barrier follows in sc.init)
+  if (LATTICE) sc.init(lds);
   bool use_cache = LATTICE;
   int hot = 0;  // lds_add_pair: >0 while this thread's adds are contended (go straight to the float atomic)
   int hits = 0, tries = 0, iter = 0;
@@ -511,11 +547,9 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
   for (int64_t tile = bx; tile < ntiles_w; tile += gx, iter++) {
     uint32_t crow[NC];
     float cval[NC][F];
-    bool pending[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-      pending[c] = false;
-      crow[c] = 0u;
+      crow[c] = Q_NONE;   // until the thread's point fills it in; again after the combine where another lane / the cache took it
 #pragma unroll
       for (int f = 0; f < F; f++) cval[c][f] = 0.f;
     }
@@ -587,7 +621,6 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
 #pragma unroll
               for (int f = 0; f < F; f++) cval[c][f] = cval[c][f] + g2[f] * bw2;
             }
-            pending[c] = true;  // provisional: resolved after the run combine below (outside this divergent branch)
           }
           if (POS) {
 #pragma unroll
@@ -632,7 +665,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
         // (also where neighbouring samples do not share rows -- the finest levels: a per-workgroup vote that skips the combine
         // when the first tile merged < 1/16 of its contributions was measured in round 4 and made the pair SLOWER, 0.798 ->
         // 0.835 ms on the bench step, profiles/r04_bench_combine_vote_ab.txt: the scan is cheaper than the vote's bookkeeping)
-        const bool own = combine_runs16<F>(crow[c], pending[c], cval[c]);
+        const bool own = combine_runs16<F>(crow[c], cval[c]);
         bool absorbed = false;
         if (own && use_cache) {
           const int rc = sc.add(crow[c], cval[c], hot);
@@ -640,31 +673,44 @@ __global__ void __launch_bounds__(PSDF_BLOCK, QUEUE ? ((P <= 3 && F == 2) ? PSDF
           hits += (rc == 2);
           tries++;
         }
-        pending[c] = own && !absorbed;
+        if (!own || absorbed) crow[c] = Q_NONE;
       }
     }
     if (LATTICE) {
       if (QUEUE) {
         // everything the cache did not absorb goes to the queues (also while the cache is on: rays are spatially
         // coherent, so a mid level can re-use entries AND overflow the 4096 slots)
-        bool any = false;
+        uint32_t all = Q_NONE;   // all ones: the AND of the rows is Q_NONE iff every one of them is
 #pragma unroll
-        for (int c = 0; c < NC; c++) any |= pending[c];
-        if (__syncthreads_or(any)) {
+        for (int c = 0; c < NC; c++) all &= crow[c];
+        const bool any = all != Q_NONE;
+        // Does any thread of the workgroup hold something for the queues?  With the cache off: yes, no vote.  Otherwise one
+        // barrier (__syncthreads_or takes three): a wave that has something sets word iter % 3, everybody reads it behind the
+        // barrier; the word of the NEXT super-tile is cleared in front of that barrier -- its last readers (super-tile iter - 2)
+        // have arrived at the barrier of iter - 1 by then.
+        bool go = !use_cache && iter > 0;
+        if (!go) {
+          const int vw = iter % 3;
+          if (threadIdx.x == 0) q_vote[vw == 2 ? 0 : vw + 1] = 0;
+          if (__builtin_amdgcn_ballot_w64(any) != 0ull && psdf::lane_id() == 0) q_vote[vw] = 1;
+          __syncthreads();
+          go = q_vote[vw] != 0;
+        }
+        if (go) {
           // cache off (and drained): its LDS is the staging area of the coalesced hand-off
           if constexpr (F == 2 && NC * PSDF_BLOCK * 3 * 4 <= SCache::SC_SLOTS * (1 + F) * 4) {
             if (!use_cache && iter > 0)
-              queue_push_staged<NC>(Q, level, q_cnt, q_base, q_off, lds, pending, crow, cval, grad_lattice + tbase);
+              queue_push_staged<NC>(Q, level, q_cnt, q_base, q_off, q_gd, lds, crow, cval, grad_lattice + tbase);
             else
-              queue_push<NC, F>(Q, level, q_cnt, q_base, pending, crow, cval, grad_lattice + tbase);
+              queue_push<NC, F>(Q, level, q_cnt, q_base, crow, cval, grad_lattice + tbase);
           } else {
-            queue_push<NC, F>(Q, level, q_cnt, q_base, pending, crow, cval, grad_lattice + tbase);
+            queue_push<NC, F>(Q, level, q_cnt, q_base, crow, cval, grad_lattice + tbase);
           }
         }
       } else {
 #pragma unroll
         for (int c = 0; c < NC; c++)
-          if (pending[c]) {
+          if (crow[c] != Q_NONE) {
 #pragma unroll
             for (int f = 0; f < F; f++) atomicAdd(grad_lattice + tbase + (int64_t)crow[c] * F + f, cval[c][f]);
           }
@@ -1151,6 +1197,8 @@ static bool queue_plan(int pos_dim, int nr_feat, int64_t N, int nr_levels, int c
   const int64_t contrib = (int64_t)(pos_dim + 1) * N;
   const int64_t cap = (contrib / np) + (contrib / np) / 4 + 4096;
   if (cap > 0x7fffffff) return false;
+  // the kernels address a level's slice of the queues with 32-bit byte offsets (queue_store)
+  if ((int64_t)np * cap * (nr_feat * 4 > 2 ? nr_feat * 4 : 2) > 0xffffffffll) return false;
   Q.cap = (int)cap;
   Q.np = np;
   Q.shift = shift;
@@ -1377,7 +1425,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
   }
 #define BWD(P_, F_, A_, B_, Q_)                                                                                  \
   hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, A_, B_, Q_>), grid, dim3(PSDF_BLOCK),                             \
-                     ((A_) ? ScatterCache<F_, ((Q_) ? 4096 : 8192)>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int) : 0), st, N, \
+                     ((A_) ? ScatterCache<F_, ((Q_) ? 4096 : 8192)>::bytes() + Q_LDS_INTS * sizeof(int) : 0), st, N, \
                      nr_levels,                                                                                    \
                      (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, points_scaling,        \
                      grad_sliced, grad_lattice, grad_positions, Q)
@@ -1388,7 +1436,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
 // (Those figures are from the 3-workgroups-per-CU state of the kernel; 5 fit now -- 80 per level at 16 levels -- by the same rule.)
 #define BWD_PLAN(P_, F_)                                                                                          \
   hipLaunchKernelGGL((encode_bwd_kernel<P_, F_, true, false, true>), dim3(plan.first[nr_levels]), dim3(PSDF_BLOCK), \
-                     (ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int)), st, N, nr_levels,    \
+                     (ScatterCache<F_, 4096>::bytes() + Q_LDS_INTS * sizeof(int)), st, N, nr_levels,    \
                      (uint32_t)capacity, psdf::enc_conv_state(), positions, lattice, scale_factor, shifts, window, \
                      points_scaling, grad_sliced, grad_lattice, (float*)nullptr, Q, (const float*)nullptr,          \
                      (float*)nullptr, 0, (const float*)nullptr, plan)
@@ -1398,7 +1446,7 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     bool balanced = false;                                                                                       \
     if (use_queue) {                                                                                             \
       int per_cu = 0;                                                                                            \
-      const size_t shm = ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                  \
+      const size_t shm = ScatterCache<F_, 4096>::bytes() + Q_LDS_INTS * sizeof(int);                  \
       const hipError_t eo =                                                                                      \
           (grad_positions && pos_fused) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(                                        \
                                &per_cu, encode_bwd_kernel<P_, F_, true, true, true>, PSDF_BLOCK, shm)            \
@@ -1551,7 +1599,7 @@ int psdf_encode_double_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_l
 #define DBLQ(P_, F_)                                                                                                     \
   do {                                                                                                                   \
     auto kern = encode_bwd_kernel<P_, F_, true, false, true, true>;                                                      \
-    const size_t shm = ScatterCache<F_, 4096>::bytes() + (3 * Q_MAX_PARTS + 1) * sizeof(int);                            \
+    const size_t shm = ScatterCache<F_, 4096>::bytes() + Q_LDS_INTS * sizeof(int);                            \
     int per_cu = 0;                                                                                                      \
     int64_t gx = 128;                                                                                                    \
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PSDF_BLOCK, shm) == hipSuccess && per_cu > 0)        \

@@ -103,13 +103,18 @@ __device__ __forceinline__ float wave_incl_scan_add(float v) {
   }
   return v;
 }
+// Integer inclusive scan over the wave on the DPP path: four shifted adds inside each 16-lane row (0 shifted in at the row's
+// edge: bound_ctrl), then the last lane of row 0 / 2 added to row 1 / 3 (row_bcast:15, rows 1 and 3 enabled) and lane 31 to rows
+// 2 and 3 (row_bcast:31).  Six VALU instructions; the __shfl_up form was six ds_bpermute round trips in a dependent chain plus
+// a lane compare and a select each (and six 64-bit lane masks: SGPR spills in the encode binning kernel).  Integer adds: the
+// result is the same whatever the order.
 __device__ __forceinline__ int wave_incl_scan_add_i(int v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int t = __shfl_up(v, o, 64);
-    if (l >= o) v += t;
-  }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
 // inclusive product scan
