@@ -46,20 +46,23 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
   const double inv = 1.0 / (P + 1);
   const float invf = 1.0f / (P + 1);
   int sum = 0;
+  float remf[P + 1];
 #pragma unroll
   for (int i = 0; i <= P; i++) {
     float v = POW2 ? E[i] * invf : (float)((double)E[i] * inv);
     float up = ceilf(v) * (float)(P + 1);
     float down = floorf(v) * (float)(P + 1);
-    s.rem0[i] = ((up - E[i]) < (E[i] - down)) ? (int)up : (int)down;
+    remf[i] = ((up - E[i]) < (E[i] - down)) ? up : down;   // integer valued: (float)(int)remf == remf, one convert instead of two
+    s.rem0[i] = (int)remf[i];
     sum += s.rem0[i];
   }
-  sum /= (P + 1);
+  // the remainders add up to a multiple of P+1 (the elevated coordinates add up to 0): for a power of two an arithmetic shift
+  sum = POW2 ? (sum >> __builtin_ctz(P + 1)) : (sum / (P + 1));
 
   float d[P + 1];
 #pragma unroll
   for (int i = 0; i <= P; i++) {
-    d[i] = E[i] - (float)s.rem0[i];
+    d[i] = E[i] - remf[i];
     s.rank[i] = 0;
   }
   // tie rule (encode_conventions.h): a wave-uniform value, so ONE scalar branch picks the comparison for all pairs
@@ -89,7 +92,9 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
 #pragma unroll
   for (int i = 0; i <= P; i++) {   // wrap into 0..P; as selects: written as if / else-if the compiler emits a divergent branch per i
     const int r = s.rank[i] + sum;
-    const int adj = (r < 0) ? (P + 1) : ((r > P) ? -(P + 1) : 0);
+    // P + 1 a power of two: the wrap by +-(P+1) is the two's-complement remainder (r lies in [-(P+1), 2P+1]) -- add, and, sub
+    // instead of two compares and two selects, and the compiler now KNOWS 0 <= rank <= P (vertex_rows drops its r = 0 terms)
+    const int adj = POW2 ? ((r & P) - r) : ((r < 0) ? (P + 1) : ((r > P) ? -(P + 1) : 0));
     s.rank[i] = r + adj;
     s.rem0[i] += adj;
   }
@@ -108,9 +113,11 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
     for (int r = 0; r <= P; r++)
       if (s.rank[i] == r) ds[r] = delta;
   }
-  s.bary[0] = 0.f + ds[P];
+  // (the oracle accumulates into zero-initialised slots, 0 + ds: that differs from ds only in the sign of a zero, which no
+  // consumer sees -- a barycentric coordinate is a factor of products that are added to sums)
+  s.bary[0] = ds[P];
 #pragma unroll
-  for (int k = 1; k <= P; k++) s.bary[k] = (0.f + ds[P - k]) - ds[P + 1 - k];
+  for (int k = 1; k <= P; k++) s.bary[k] = ds[P - k] - ds[P + 1 - k];
   s.bary[P + 1] = 0.f - ds[0];
   s.bary[0] = (float)((double)s.bary[0] + (1.0 + (double)s.bary[P + 1]));
 }
@@ -138,13 +145,23 @@ __device__ __forceinline__ void vertex_rows(const Simplex<P>& s, uint32_t capaci
     h0 += (uint32_t)s.rem0[i];
     h0 *= hash_c;
   }
+  // sum_i [rank_i > P - r] t_i with t_i = (P+1) c^(P-i): the ranks are a permutation, so gather T_k = t_i of the coordinate of
+  // rank k (the same rank_i == k compares as the barycentric gather of compute_simplex: the compiler shares them) and run the
+  // sum up from k = P: vertex r subtracts T_P + .. + T_(P+1-r).
+  uint32_t T[P + 1];
 #pragma unroll
-  for (int r = 0; r <= P; r++) {
-    uint32_t h = h0 + (uint32_t)r * geom;
+  for (int k = 1; k <= P; k++) {
+    T[k] = 0u;
 #pragma unroll
     for (int i = 0; i < P; i++)
-      if (s.rank[i] > P - r) h -= (uint32_t)(P + 1) * pw[P - i];
-    rows[r] = h;
+      if (s.rank[i] == k) T[k] = (uint32_t)(P + 1) * pw[P - i];
+  }
+  rows[0] = h0;
+  uint32_t S = 0u;
+#pragma unroll
+  for (int r = 1; r <= P; r++) {
+    S += T[P + 1 - r];
+    rows[r] = h0 + ((uint32_t)r * geom - S);
   }
   if ((capacity & (capacity - 1u)) == 0u) {
 #pragma unroll
