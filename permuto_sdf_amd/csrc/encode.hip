@@ -33,11 +33,14 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   // levels for ALL points so that a table is fetched into one L2 instead of eight: 0.358 -> 0.631 ms at 2 M points, 16 levels
   // (profiles/r04_enc_ab.jsonl).  Eight XCDs streaming eight different tables each touch every position and write every
   // output row with 1/8 of the chip; the level-at-a-time sweep below keeps all 256 CUs on one 2-MiB table.)
-  const int64_t tile = blockIdx.x;
   const int level = blockIdx.y;
+  const int64_t ntiles = (N + PSDF_BLOCK - 1) / PSDF_BLOCK;
+  // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its level (gridDim.x = the number of tiles unless the
+  // launcher caps it: then the level's constants are fetched once per workgroup instead of once per tile)
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
-  if (n >= N) return;
-  if (skip && skip[n]) return;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
+  if (n >= N) continue;
+  if (skip && skip[n]) continue;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
   float pos[P];
   load_pos<P>(positions, n, pos);
   if (level >= L) {  // pseudo-levels carrying the scaled input point (zero padded)
@@ -52,14 +55,14 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
       // channel L*F + d; d >= P exists only in the zero-padded pseudo-level layout (encode_conventions.h)
       if (d < P || pad_points) sliced[((int64_t)level * F + f) * N + n] = v;
     }
-    return;
+    continue;
   }
   const float w = window[level];
   if (w == 0.f) {  // a level the coarse-to-fine window keeps closed (workgroup-uniform): its channels are 0 * (finite rows) = 0,
                    // no simplex, no gathers, nothing to mark (its backward contributes nothing either)
 #pragma unroll
     for (int f = 0; f < F; f++) sliced[((int64_t)level * F + f) * N + n] = 0.f;
-    return;
+    continue;
   }
   Simplex<P> s;
   compute_simplex<P>(pos, shifts + level * P, scale_factor + level * P, s, conv.tie_later);
@@ -97,6 +100,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
 #pragma unroll
   for (int f = 0; f < F; f++) sliced[((int64_t)level * F + f) * N + n] = acc[f];
+  }
 }
 
 
@@ -1127,6 +1131,7 @@ int psdf_encode_set_conventions(uint32_t hash_multiplier, int rank_tie_raises_la
   return PSDF_OK;
 }
 
+static int device_cus();
 static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
                                const float* lattice, const float* scale_factor, const float* shifts, const float* window,
                                int concat_points, float points_scaling, const unsigned char* skip, float* sliced,
@@ -1137,6 +1142,12 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);
+  // one resident round of workgroups per level (8 per CU) that walk the tiles, instead of one workgroup per tile: the level's
+  // constants are fetched once per workgroup.  Round 5, 2 M points x 16 levels, forward bracket of the bench step: 0.650 ms
+  // uncapped, 0.646 with 1024, 0.636 with 2048 or 4096 (profiles/r05_mlp_pair_ab.txt).  PSDF_ENC_FWD_WGS=0: one tile each.
+  static const int fwd_env = getenv("PSDF_ENC_FWD_WGS") ? atoi(getenv("PSDF_ENC_FWD_WGS")) : -1;
+  const int fwd_wgs = fwd_env >= 0 ? fwd_env : device_cus() * 8;
+  if (fwd_wgs > 0 && (int)grid.x > fwd_wgs) grid.x = fwd_wgs;
 #define FWD(P_, F_)                                                                                            \
   hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, psdf::enc_conv_state(), \
                      positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced,  \
