@@ -80,23 +80,24 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   float fv[P + 1][F];
 #pragma unroll
   for (int r = 0; r <= P; r++) {
+    // 32-bit byte offset from the level's table (a wave-uniform base): one shift per gather instead of a 64-bit shift-add
+    // (a level of the table is below 4 GiB: checked by the launcher)
+    const char* tb = reinterpret_cast<const char*>(table);
     if (F == 2) {
-      float2 t = *reinterpret_cast<const float2*>(table + (int64_t)row[r] * 2);
+      float2 t = *reinterpret_cast<const float2*>(tb + (row[r] * 8u));
       fv[r][0] = t.x;
       fv[r][F - 1] = t.y;
     } else {
 #pragma unroll
-      for (int f = 0; f < F; f++) fv[r][f] = table[(int64_t)row[r] * F + f];
+      for (int f = 0; f < F; f++) fv[r][f] = *reinterpret_cast<const float*>(tb + (row[r] * (uint32_t)(F * 4) + (uint32_t)(f * 4)));
     }
   }
   float acc[F];
 #pragma unroll
-  for (int f = 0; f < F; f++) acc[f] = 0.f;
-#pragma unroll
   for (int r = 0; r <= P; r++) {
     const float bw = s.bary[r] * w;
 #pragma unroll
-    for (int f = 0; f < F; f++) acc[f] = acc[f] + fv[r][f] * bw;
+    for (int f = 0; f < F; f++) acc[f] = r == 0 ? fv[r][f] * bw : acc[f] + fv[r][f] * bw;   // (0 + x: the sign of a zero only)
   }
 #pragma unroll
   for (int f = 0; f < F; f++) sliced[((int64_t)level * F + f) * N + n] = acc[f];
@@ -1139,6 +1140,7 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   if (N == 0) return PSDF_OK;
   if (N < 0 || nr_levels <= 0 || capacity <= 0 || !positions || !lattice || !sliced || !concat_ok(concat_points))
     return PSDF_ERR_ARG;
+  if ((int64_t)capacity * nr_feat * 4 > 0xffffffffll) return PSDF_ERR_UNSUPPORTED;   // the kernel's 32-bit offsets inside a level
   hipStream_t st = (hipStream_t)stream;
   const int Lt = nr_levels + extra_levels(pos_dim, nr_feat, concat_points);
   dim3 grid(psdf_blocks(N, PSDF_BLOCK), Lt);

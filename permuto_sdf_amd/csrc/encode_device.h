@@ -50,9 +50,20 @@ __device__ __forceinline__ void compute_simplex(const float* __restrict__ pos, c
 #pragma unroll
   for (int i = 0; i <= P; i++) {
     float v = POW2 ? E[i] * invf : (float)((double)E[i] * inv);
-    float up = ceilf(v) * (float)(P + 1);
     float down = floorf(v) * (float)(P + 1);
-    remf[i] = ((up - E[i]) < (E[i] - down)) ? up : down;   // integer valued: (float)(int)remf == remf, one convert instead of two
+    if (POW2) {
+      // The nearer of the two multiples of P+1 around E, the lower one on a tie: E > down + (P+1)/2 -- the midpoint is exact, no
+      // rounded differences to compare.  Same answer as the reference's (up - E) < (E - down) on every float (those differences
+      // are exact or round monotonically towards the midpoint; tests/test_dpp_scan_emulation.py sweeps the neighbourhoods of all
+      // multiples of 1/2 and 5e7 random values): floor, two packed products / sums, a compare, a select -- was ceil, floor, two
+      // products, two differences, a compare, a select.
+      const float mid = down + 0.5f * (float)(P + 1), up = down + (float)(P + 1);
+      remf[i] = (E[i] > mid) ? up : down;
+    } else {
+      float up = ceilf(v) * (float)(P + 1);
+      remf[i] = ((up - E[i]) < (E[i] - down)) ? up : down;
+    }
+    // (integer valued: (float)(int)remf == remf, one convert instead of two)
     s.rem0[i] = (int)remf[i];
     sum += s.rem0[i];
   }

@@ -156,3 +156,39 @@ def test_vertex_rows_from_per_rank_terms():
             S = (S + T[P + 1 - r]) % M
             rows.append((h0 + (r * geom - S)) % M)
         assert rows == ref
+
+
+def test_nearest_remainder_rule_equals_the_reference_rule_on_floats():
+    """compute_simplex, P + 1 = 4: rem = (E > down + 2) ? down + 4 : down against the reference's (up - E) < (E - down) ? up : down
+    with up = 4 ceil(E / 4), down = 4 floor(E / 4), all in float32 -- swept over +-2000 ulps around every multiple of 1/2 up to
+    +-300 (the ties and their neighbours), the denormals, every float of a few unit intervals, and random values of all scales."""
+    f32 = np.float32
+
+    def ref(E):
+        v = (E * f32(0.25)).astype(f32)
+        up, down = (np.ceil(v) * f32(4)).astype(f32), (np.floor(v) * f32(4)).astype(f32)
+        return np.where((up - E).astype(f32) < (E - down).astype(f32), up, down).astype(f32)
+
+    def new(E):
+        down = (np.floor((E * f32(0.25)).astype(f32)) * f32(4)).astype(f32)
+        return np.where(E > (down + f32(2)).astype(f32), (down + f32(4)).astype(f32), down).astype(f32)
+
+    def check(E):
+        E = E.astype(f32)
+        E = E[np.isfinite(E)]
+        assert np.array_equal(ref(E), new(E))
+
+    rng = np.random.default_rng(8)
+    offs = np.arange(-2000, 2001)
+    for b0 in np.arange(-600, 601) * 0.5:
+        bits = np.array([b0], f32).view(np.int32)[0]
+        check((bits + offs).astype(np.int32).view(f32))
+    check(np.arange(-3000, 3001).astype(np.int32).view(f32))                       # +-denormals and the smallest normals
+    check((np.arange(0, 3000) | 0x80000000).astype(np.uint32).view(f32))
+    for lo, hi in [(1.5, 2.5), (5.5, 6.5), (2.0 ** 20 + 1.5, 2.0 ** 20 + 2.5), (2.0 ** 24 - 8, 2.0 ** 24 + 64)]:
+        lb, hb = np.array([lo, hi], f32).view(np.int32)
+        arr = np.arange(lb, hb + 1, dtype=np.int32).view(f32)
+        check(arr)
+        check(-arr)
+    for scale in [1e-30, 1e-10, 1e-3, 1, 10, 1e3, 1e5, 1e6, 3e7, 1e9]:
+        check(rng.standard_normal(1_000_000) * scale)
