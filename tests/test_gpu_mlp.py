@@ -567,11 +567,13 @@ def test_split_f16_backward_range_guard(dev, what, form, monkeypatch):
         assert int(events()) == mid and max(errs.values()) <= 2e-5, errs
 
 
-@pytest.mark.parametrize("K0,N", [(36, 200_003), (52, 70_000), (20, 4_097), (64, 33)])
+@pytest.mark.parametrize("K0,N", [(36, 200_003), (52, 70_000), (20, 4_097), (64, 33), (44, 9_001), (27, 4_099), (41, 777)])
 def test_split_f16_forward_against_float64(dev, K0, N):
     """psdf_mlp_forward_f16 (two fp16 pieces per operand, three products; opt-in, the hot path's forward): against float64,
     bar 4e-6 of the largest output (measured ~1e-6 relative: attic/prototypes/mlp_fwd_split_f16.hip: 2.8e-6 absolute at outputs
-    up to 2.5); inputs with small channels (encoding-like) included; other nets say -2."""
+    up to 2.5); inputs with small channels (encoding-like) included; other nets say -2.  K0 = 44, 27, 41: a last k-step with 12,
+    11 and 9 real rows -- rows of BOTH halves of the wave, of the lower half only, and none (the three branches of the partial
+    k-step of mlp_fwd_split_kernel); 36 / 52 / 20: four real rows (lower half only)."""
     import copy
     from permuto_sdf_amd._lib import PsdfError
     from permuto_sdf_amd.mlp import f16_forward_supported, mlp_forward_raw, pack_params

@@ -22,7 +22,9 @@ if [ -z "$SHORT" ]; then
 bash tools/pmc_hbm_traffic.sh r05 > $O/pmc_hbm.log 2>&1
 bash tools/pmc_sq.sh mlp_bwd_split_f16_kernel r05_mlpbwdf16 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_sq_mlp_bwd_f16.log 2>&1
 bash tools/pmc_sq.sh "encode_bwd_kernel" r05_encbwd -- python $R/bench.py --steps 12 --warmup 10 --no-cpu-baseline --no-extra > $O/pmc_sq_encode_bwd.log 2>&1
+bash tools/pmc_sq.sh "encode_fwd_kernel" r05_encfwd -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_sq_encode_fwd.log 2>&1
+bash tools/pmc_sq.sh "mlp_fwd_split_kernel" r05_mlpfwd -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/pmc_sq_mlp_fwd.log 2>&1
 python tools/cfg2_matrix.py > $O/cfg2_matrix.jsonl 2> $O/cfg2_matrix.err
-rm -rf $R/gpurun_out/pmc_hbm_r05/FETCH_SIZE $R/gpurun_out/pmc_hbm_r05/WRITE_SIZE $R/gpurun_out/pmc_sq_r05_mlpbwdf16/pass* $R/gpurun_out/pmc_sq_r05_encbwd/pass*
+rm -rf $R/gpurun_out/pmc_hbm_r05/FETCH_SIZE $R/gpurun_out/pmc_hbm_r05/WRITE_SIZE $R/gpurun_out/pmc_sq_r05_mlpbwdf16/pass* $R/gpurun_out/pmc_sq_r05_encbwd/pass* $R/gpurun_out/pmc_sq_r05_encfwd/pass* $R/gpurun_out/pmc_sq_r05_mlpfwd/pass*
 fi
 tail -c 1200 $O/bench_final.json; echo; head -12 $O/bench_kernel_stats.txt | cut -c1-175; head -8 $O/cfg4_manual_kernel_stats.txt | cut -c1-175
