@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / tensor sharing fail with hipIpcGetMemHandle otherwise); the
+# launcher's environment normally carries it -- set here, before the HIP runtime starts, in case it does not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 

@@ -13,6 +13,8 @@ hotpath.backward can be checked for races without a second device.
 """
 import os
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (see bench.py); only effective before the HIP runtime starts
+
 import torch
 import torch.distributed as dist
 
