@@ -248,3 +248,21 @@ def test_morton_order_is_a_locality_preserving_permutation():
     assert float(step_sorted) < 0.15 * float(step_unsorted)
     p2 = torch.rand(1000, 2)
     assert sorted(morton_order(p2).tolist()) == list(range(1000))
+
+
+def test_binned_backward_plan_refuses_what_its_32_bit_offsets_cannot_address(lib):
+    """psdf_encode_backward_workspace_bytes (host only): 0 = "no binned plan, the plain path runs".  The binning and reduce kernels
+    address a level's slice of the queues with 32-bit byte offsets (csrc/encode.hip: queue_store), so the plan must refuse batches
+    whose level slice would exceed 4 GiB -- and keep the bench batch, the training batch and a 64 M-point batch."""
+    import ctypes
+    fn = lib.psdf_encode_backward_workspace_bytes
+    fn.restype = ctypes.c_int64
+
+    def ws(N, L_=16, cap=1 << 18, P=3, F=2):
+        return int(fn(ctypes.c_int(P), ctypes.c_int(F), ctypes.c_int64(N), ctypes.c_int(L_), ctypes.c_int(cap)))
+
+    assert ws(1 << 10) == 0                         # below the plan's minimum batch
+    small, bench, big = ws(49_152, L_=24), ws(1 << 21), ws(1 << 26)
+    assert 0 < small < bench < big
+    assert bench >= (1 << 21) * 4 * 16 * 10          # room for every contribution: u16 row + two floats each
+    assert ws(1 << 28) == 0                          # 2^30 contributions per level: 10 GiB of queue values per level slice
