@@ -36,7 +36,9 @@ extern "C" {
 int64_t psdf_encode_convention(int which);
 int psdf_encode_set_conventions(uint32_t hash_multiplier, int rank_tie_raises_later);
 
-/* replaces: permutohedral_encoding CUDA op `forward_gpu` (un-vendored; call sites permuto_sdf_py/models/models.py:186,370,500,542) */
+/* replaces: permutohedral_encoding CUDA op `forward_gpu` (un-vendored; call sites permuto_sdf_py/models/models.py:186,370,500,542)
+   -2 (unsupported) when one level of the table exceeds 4 GiB (capacity * nr_feat * 4 bytes: the kernel gathers with 32-bit
+   offsets from the level's base; the reference's tables are 2 MiB per level) */
 int psdf_encode_forward(int pos_dim, int nr_feat, int64_t N, int nr_levels, int capacity, const float* positions,
     const float* lattice, const float* scale_factor, const float* shifts, const float* window, int concat_points,
     float points_scaling, float* sliced, void* stream);

@@ -47,6 +47,11 @@ def test_argument_errors_and_empty_inputs_without_gpu(lib):
     assert lib.psdf_mlp_packed_size(4, (ctypes.c_int * 5)(36, 64, 64, 64, 1)) > 0
     assert lib.psdf_adamw_step(ctypes.c_int64(8), None, None, None, None, ctypes.c_float(1e-3), ctypes.c_float(.9),
                                ctypes.c_float(.99), ctypes.c_float(1e-15), ctypes.c_float(0), 1, ctypes.c_float(1), None) == -1
+    # a level of the table above 4 GiB: the forward's 32-bit gather offsets cannot address it -> "unsupported", before any launch
+    # (the pointers only have to be non-null for the argument check that precedes it)
+    dummy = ctypes.c_void_p(4096)
+    assert lib.psdf_encode_forward(3, 4, ctypes.c_int64(1), 4, 1 << 30, dummy, dummy, dummy, dummy, dummy, 0, ctypes.c_float(1),
+                                   dummy, None) == -2
 
 
 def _packed_floats(dims):
