@@ -22,7 +22,7 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ forward
-template <int P, int F>
+template <int P, int F, bool PLAIN = false>   // PLAIN: no skip mask, no touched-block map (their arguments are ignored)
 __global__ void __launch_bounds__(PSDF_BLOCK)
     encode_fwd_kernel(int64_t N, int L, uint32_t capacity, EncConv conv, const float* __restrict__ positions,
                       const float* __restrict__ lattice, const float* __restrict__ scale_factor,
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int64_t n = tile * PSDF_BLOCK + threadIdx.x;
   if (n >= N) continue;
-  if (skip && skip[n]) continue;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
+  if (!PLAIN && skip && skip[n]) continue;  // masked point (fixed-shape callers, e.g. converged rays): its columns stay untouched
   float pos[P];
   load_pos<P>(positions, n, pos);
   if (level >= L) {  // pseudo-levels carrying the scaled input point (zero padded)
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   // Training forward: remember which blocks of table rows this batch reads.  Every lattice-gradient contribution of the
   // backward / double backward at these positions lands on exactly these rows, so the optimiser can skip blocks whose
   // gradient and moments are still exactly zero (optim.hip: adamw_blocks_kernel) -- a superset is all it needs.
-  if (touched) {
+  if (!PLAIN && touched) {
 #pragma unroll
     for (int r = 0; r <= P; r++) touched[(int64_t)level * blocks_per_level + (row[r] >> touch_shift)] = 1;
   }
@@ -1150,10 +1150,16 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   static const int fwd_env = getenv("PSDF_ENC_FWD_WGS") ? atoi(getenv("PSDF_ENC_FWD_WGS")) : -1;
   const int fwd_wgs = fwd_env >= 0 ? fwd_env : device_cus() * 8;
   if (fwd_wgs > 0 && (int)grid.x > fwd_wgs) grid.x = fwd_wgs;
-#define FWD(P_, F_)                                                                                            \
-  hipLaunchKernelGGL((encode_fwd_kernel<P_, F_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, psdf::enc_conv_state(), \
+#define FWD_(P_, F_, PL_)                                                                                      \
+  hipLaunchKernelGGL((encode_fwd_kernel<P_, F_, PL_>), grid, dim3(PSDF_BLOCK), 0, st, N, nr_levels, (uint32_t)capacity, psdf::enc_conv_state(), \
                      positions, lattice, scale_factor, shifts, window, points_scaling, pad_points(concat_points), skip, sliced,  \
                      touched, touch_shift, (capacity + (1 << touch_shift) - 1) >> touch_shift)
+  // (without a mask and a touched-block map the kernel needs fewer scalar registers: 8 instead of 7 waves per SIMD)
+#define FWD(P_, F_)                          \
+  do {                                       \
+    if (!skip && !touched) FWD_(P_, F_, true); \
+    else FWD_(P_, F_, false);                \
+  } while (0)
   if (pos_dim == 3 && nr_feat == 2)
     FWD(3, 2);
   else if (pos_dim == 4 && nr_feat == 2)
@@ -1165,6 +1171,7 @@ static int encode_forward_impl(int pos_dim, int nr_feat, int64_t N, int nr_level
   else
     return PSDF_ERR_UNSUPPORTED;
 #undef FWD
+#undef FWD_
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
