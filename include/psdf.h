@@ -149,9 +149,8 @@ int psdf_mlp_backward_split(int n_layers, const int* dims, int64_t N, const floa
    here by default (PSDF_MLP_BWD_SPLIT=bf16 selects psdf_mlp_backward_split instead). */
 int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
     const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
-/* which form of the split-fp16 kernel the last psdf_mlp_backward_split_f16 launched: 1 = one wave per SIMD
-   (mlp_bwd_split_f16_kernel, the default), 2 = wave pairs (mlp_bwd_split_f16_pair_kernel, PSDF_MLP_BWD_F16_FORM=pair, K0 <= 48);
-   0 = none yet.  Debug query for tests and benches (host only). */
+/* 1 once psdf_mlp_backward_split_f16 has launched mlp_bwd_split_f16_kernel (one wave per SIMD: the only form built since round 6;
+   the two two-waves-per-SIMD forms of round 5 were slower and live in attic/rejected/), 0 = none yet.  Debug query (host only). */
 int psdf_mlp_backward_split_f16_form(void);
 /* range guard of the split-fp16 backward: inputs / hidden activations of magnitude >= 255 or weights >= 65504 leave the range
    of its two-piece arithmetic; such a batch is redone on the device by the three-piece bf16 kernel (K0 <= 52; no host

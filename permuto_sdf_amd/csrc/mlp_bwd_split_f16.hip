@@ -1,6 +1,6 @@
 // Backward of the 64x3 -> 1 SDF net on the fp16 MATRIX PIPE with TWO pieces per fp32 operand (round 3; the sibling of
-// mlp_bwd_split.hip, which uses three bf16 pieces and six products).  a = a0 + a1, a0 = fp16(a) rounded toward zero (so that
-// a - a0 is exact in fp32), a1 = fp16(a - a0): 11 + 11 mantissa bits; chains keep a0 b0 + a0 b1 + a1 b0 (error ~2^-22 |a b|),
+// mlp_bwd_split.hip, which uses three bf16 pieces and six products).  a = a0 + a1, a0 = fp16(a) rounded to nearest (a - a0
+// is exact in fp32), a1 = fp16(a - a0): 11 + 1 (sign of a1) + 11 mantissa bits; chains keep a0 b0 + a0 b1 + a1 b0 (error ~2^-22 |a b|),
 // the dW products all four (the fourth rides in an otherwise empty K half).  Against the bf16 scheme: 274 instead of 480 MFMAs
 // per 16-sample tile, operand splitting 5 instead of 9 VALU instructions per pair, a 95-KB instead of a 142-KB weight image
 // (so every input width up to 64 gets double-buffered staging).  What makes it legitimate on gfx950 (measured with
@@ -24,7 +24,7 @@
 //     their MFMA pair: the compiler then emits the AGPR form itself and still sees the MFMAs for its hazard bookkeeping) -- left
 //     alone, a changing subset was parked in AGPRs and copied to VGPRs and back around every use (100 - 230 v_accvgpr moves
 //     per tile, depending on the build);
-//   * an operand is split with v_cvt_pkrtz + v_fma_mixlo/hi_f16 (3 instead of 5 instructions per pair, see split2);
+//   * an operand is split with v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16 (3 instead of 5 instructions per pair, see split2);
 //   * weight records are requested one k-step ahead of the MFMAs that need them, biases and final weights ahead of the
 //     activation blocks (38 -> 15 s_waitcnt per tile);
 //   * two GELU pairs are evaluated side by side (a dependent v_pk_fma_f32 needs a wait state: 117 -> 32 s_nop per tile);
@@ -77,8 +77,12 @@ struct BP {  // the two fp16 pieces of one 8-element operand: p[0] = high, p[1] 
   f16x8 p[NP];
 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// two fp32 -> {high pieces, low pieces}, each a packed pair (element 0 in the low half).  v_cvt_pkrtz rounds toward zero, so
-// the remainder v - high is exact in fp32 (24 - 11 = 13 significant bits); the low piece keeps its top 11.
+// two fp32 -> {high pieces, low pieces}, each a packed pair (element 0 in the low half).  The high piece is fp16(x) rounded to
+// NEAREST (v_cvt_pk_f16_f32, new on gfx950; rounds 3-5 truncated with v_cvt_pkrtz): |x - high| <= 2^-11 of x's binade and a
+// multiple of its fp32 ulp, so the remainder is exact in fp32 and has at most 12 significant bits; the low piece keeps 11 of
+// them: x - (high + low) is 0 for three operands in four and 2^-23 of the binade otherwise (truncation left up to 2^-22 and a
+// ONE-SIDED error that grows with the depth of a dot product instead of its square root), and |low| <= 2^-11 |x| makes the
+// dropped low x low product <= 2^-22 of the largest and ~2^-25 of a typical product.  Same three instructions per pair.
 // `one` is 1.0f the optimiser cannot see through (an empty asm on a scalar register): fma(x, one, -high) must reach instruction
 // selection as an fma with an fp16 source and an fp16 result, which is v_fma_mixlo_f16 / v_fma_mixhi_f16 -- x * 1 - high formed
 // exactly and rounded once to fp16 (nearest even; subnormal results kept: the kernel runs with fp16 denormals on) -- ONE
@@ -91,7 +95,7 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
   typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
   float one = 1.0f;
   asm("" : "+s"(one));
-  const auto h2 = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  const h2_t h2 = __builtin_convertvector(f32x2{x0, x1}, h2_t);   // v_cvt_pk_f16_f32 (round to nearest even)
   h2_t l;
   l[0] = (_Float16)__builtin_fmaf(x0, one, -(float)h2[0]);
   l[1] = (_Float16)__builtin_fmaf(x1, one, -(float)h2[1]);
@@ -697,1089 +701,6 @@ __global__ void __launch_bounds__(NWAVES * 64, 1)
   for (int e = threadIdx.x; e < G_TOTAL; e += NWAVES * 64) dst[e] = G[e];
 }
 
-// ====================================================================================== wave-pair form (round 5)
-// The kernel above needs the whole register file of a SIMD for ONE wave (176 dW accumulators), and one in-order wave overlaps
-// nothing: its VALU issue (7 200 cycles per tile), its MFMAs (4 400) and its waits (2 600) simply add up.  Here the NET is cut in
-// two instead of the work list: the two waves of a PAIR own the output-neuron tiles {0, 1} and {2, 3} of every layer -- of the
-// forward recompute, of the dH chain, of the activation derivatives, of the bias sums -- and half of every dW (88 accumulators
-// each: dW3 / dW2 by input-neuron tiles, dW1 by output-neuron tiles), so that a wave fits 256 registers and TWO waves share a SIMD.
-// What a wave lacks for a 64-deep product is its partner's k-step (two tiles = one 32-deep MFMA step): every chain layer
-// hands its operand pieces over through a 2-KB LDS slot (lane-linear 16-byte records: the partner's lane needs exactly what the
-// same lane of the owner holds), five hand-overs per tile (h1, h2, dZ3, dZ2, dZ1), two alternating slots per pair, one flag word
-// per wave (a post counter; LDS executes a wave's DS instructions in order, so the data are in place when the counter is).  The
-// dZ-side dW operands of the partner's tiles are transposed again locally from the pieces that arrive anyway (4 MFMAs per layer:
-// cheaper than a sixth and seventh hand-over); layer 0 splits all of X on both waves (24 instructions).  Partners sit on
-// DIFFERENT SIMDs (waves 2p, 2p+1); the two waves of one SIMD belong to different pairs and drift freely against each other,
-// which is where the VALU of one meets the MFMAs and the waits of the other.  The staged inputs (one double buffer per pair) are
-// requested half by each wave; the "dZ1" post of a tile doubles as "my share of the next tile's inputs has landed".
-// LDS: image 93 KB + 4 x 8.5 KB staging + 4 x 8 KB slots = 159.1 KB (three input tiles only: K0 <= 48).
-constexpr int PAIR_WAVES = 8;
-// weight records of a chain layer: requested right before their MFMAs (W_LATE) or a step ahead (W_EARLY: + 16 registers)
-#ifdef PSDF_PAIR_WPF
-#define W_EARLY(x) x
-#define W_LATE(x)
-#else
-#define W_EARLY(x)
-#define W_LATE(x) x
-#endif
-#ifndef PSDF_PAIR_SUM_PAIR
-#define PSDF_PAIR_SUM_PAIR false
-#endif
-constexpr int XCH_SLOT = 2 * NP * 64, XCH_PAIR = 2 * XCH_SLOT;     // records: [slot 2][half 2][piece 2][lane 64]
-
-template <int NTILE>
-__device__ __forceinline__ void act_both_n(f32x4 (&acc)[NTILE], f32x4 (&gp)[NTILE]) {
-#pragma unroll
-  for (int t = 0; t < NTILE; t++) {
-    f32x2 ha, hb, ga, gb;
-    gelu_rational4(f32x2{acc[t][0], acc[t][1]}, f32x2{acc[t][2], acc[t][3]}, ha, hb, ga, gb);
-    acc[t] = f32x4{ha.x, ha.y, hb.x, hb.y};
-    gp[t] = f32x4{ga.x, ga.y, gb.x, gb.y};
-  }
-}
-// the wave's own k-step: its two tiles in the k order of step_operand
-__device__ __forceinline__ void own_operand(const f32x4 (&act)[2], float (&x)[8]) {
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    x[j] = act[0][j];
-    x[4 + j] = act[1][j];
-  }
-}
-// dZ-side dW operand of a tile whose bias sum belongs to the partner
-__device__ __forceinline__ void transpose_pieces_nosum(const BP& b, f16x8 id, AT& out) {
-  uint32_t q[NP][2];
-#pragma unroll
-  for (int p = 0; p < NP; p++) {
-    const f32x4 o = MFMA16(b.p[p], id, zero4());
-    q[p][0] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o[0], o[1]));
-    q[p][1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(o[2], o[3]));
-  }
-  out.t01 = halves(q[0][0], q[0][1], q[1][0], q[1][1]);
-}
-typedef __attribute__((address_space(3))) volatile uint32_t lds_flag_t;
-struct Link {
-  u32x4* mine;                  // slot 0, this wave's half, this lane
-  int their_delta;              // the partner's half of a slot, relative to `mine` (records)
-  lds_flag_t* my_flag;          // (explicit LDS pointers: a volatile access through a generic pointer stays a flat_ instruction)
-  lds_flag_t* their_flag;
-  uint32_t seq;                 // posts so far (both waves of a pair post in the same order)
-  int slot;
-  __device__ __forceinline__ void post(const BP& b) {
-    u32x4* d = mine + slot * XCH_SLOT;
-    d[0] = __builtin_bit_cast(u32x4, b.p[0]);
-    d[64] = __builtin_bit_cast(u32x4, b.p[1]);
-    asm volatile("" ::: "memory");
-    seq++;
-    *my_flag = seq;             // behind the records in the wave's DS queue
-    asm volatile("" ::: "memory");
-  }
-  __device__ __forceinline__ void take(BP& b) {
-    // (bounded: a partner that never posts -- a bug -- must end in wrong numbers that a test sees, not in a hung device)
-#pragma unroll 1
-    for (int spin = 0; spin < (1 << 24); spin++) {
-      const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)*their_flag);
-      if ((int32_t)(v - seq) >= 0) break;
-#ifndef PSDF_PAIR_NOSLEEP
-      __builtin_amdgcn_s_sleep(1);
-#endif
-    }
-    asm volatile("" ::: "memory");
-    const u32x4* s = mine + their_delta + slot * XCH_SLOT;
-    b.p[0] = __builtin_bit_cast(f16x8, s[0]);
-    b.p[1] = __builtin_bit_cast(f16x8, s[64]);
-    slot ^= 1;
-  }
-};
-// One chain layer of a pair is three steps: post_own (split the own two tiles, hand the pieces to the partner), mac_step with the
-// own pieces, take + mac_step with the partner's.  Everything that does not feed the NEXT post (transposes of the partner's
-// pieces, the dW products of the layer, the dW4 sums) is issued AFTER that post: a wave is then 25 - 40 MFMAs away from its next
-// take when it posts, and a partner that runs a few hundred cycles behind costs nothing (the first build took straight after its
-// own step and waited 1 000 cycles per hand-over, profiles/r05_mlp_pair_ab.txt).
-__device__ __forceinline__ void post_own(const f32x4 (&in)[2], BP& b, Link& lk) {
-  float x[8];
-  own_operand(in, x);
-  split8(x, b);
-  lk.post(b);
-  __builtin_amdgcn_sched_barrier(0);
-}
-// out += W[tiles][one k-step] x pieces; w = records of the wave's first output tile, that k-step, this lane
-template <int NTILE>
-__device__ __forceinline__ void mac_step(f32x4 (&out)[NTILE], const BP& b, const u32x4* __restrict__ w) {
-  f16x8 a[NTILE][NP];
-  load_w<NTILE>(a, w);
-  mac16r<NTILE>(out, b, a);
-}
-
-template <int NT0>
-__global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
-    mlp_bwd_split_f16_pair_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
-                                  const u32x4* __restrict__ img, uint32_t* __restrict__ absmax, float* __restrict__ dX,
-                                  float* __restrict__ partial) {
-  static_assert(NT0 == 3, "the pair form holds three input tiles (K0 <= 48)");
-  extern __shared__ __align__(16) u32x4 lds[];
-  uint32_t out_of_range = 0u;   // range guard (uniform; see the one-wave kernel)
-  float sc, isc;
-  const int kscale = dy_scale((uint32_t)__builtin_amdgcn_readfirstlane((int)absmax[0]), sc, isc);   // (uniform: scalar registers)
-  constexpr size_t IMG_ALIGNED = img_aligned(NT0);
-  constexpr int OFF_F32 = off_f32(NT0);
-  constexpr int NREC = (int)(IMG_ALIGNED / 16);
-  for (int i = threadIdx.x; i < NREC; i += PAIR_WAVES * 64) lds[i] = img[i];
-  const float* tail = reinterpret_cast<const float*>(lds + OFF_F32);
-  const int lane_k = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wave >> 1, half = wave & 1;
-  const f16x8 id[2] = {ident_op(0, lane_k), ident_op(1, lane_k)};
-  // dW3 / dW2 [dZ tile: own 0, own 1, partner's 0, partner's 1][own H tile]; dW1 [own dZ tile][X tile]
-  f32x4 dW3[NT][2], dW2[NT][2], dW1[2][NT0];
-#pragma unroll
-  for (int to = 0; to < NT; to++)
-#pragma unroll
-    for (int ti = 0; ti < 2; ti++) dW2[to][ti] = dW3[to][ti] = zero4();
-#pragma unroll
-  for (int to = 0; to < 2; to++)
-#pragma unroll
-    for (int ti = 0; ti < NT0; ti++) dW1[to][ti] = zero4();
-  Sum<PSDF_PAIR_SUM_PAIR> db1[2], db2[2], db3[2], dw4[2];
-#pragma unroll
-  for (int t = 0; t < 2; t++) {
-    db1[t].clear(); db2[t].clear(); db3[t].clear(); dw4[t].clear();
-  }
-  float db4 = 0.f;
-  const int64_t ntiles = (N + 15) / 16;
-  constexpr int STAGE_ROWS = 64, stage_floats = STAGE_ROWS * 16 + 64, OFF_DY = STAGE_ROWS * 16;
-  constexpr int NPAIR = PAIR_WAVES / 2;
-  char* dyn = reinterpret_cast<char*>(lds) + IMG_ALIGNED;
-  float* stage = reinterpret_cast<float*>(dyn) + pair * 2 * stage_floats;
-  u32x4* xch = reinterpret_cast<u32x4*>(dyn + (size_t)NPAIR * 2 * stage_floats * 4) + pair * XCH_PAIR;
-  uint32_t* flags = reinterpret_cast<uint32_t*>(dyn + (size_t)NPAIR * 2 * stage_floats * 4 + (size_t)NPAIR * XCH_PAIR * 16);
-  if (threadIdx.x < PAIR_WAVES) flags[threadIdx.x] = 0u;
-  for (int i = rows4 * 16 + lane_k + 64 * half; i < STAGE_ROWS * 16; i += 128) {
-    stage[i] = 0.f;
-    stage[stage_floats + i] = 0.f;
-  }
-  const bool wide_dma = (N & 3) == 0 && N >= 4;
-  // the requests of a tile are dealt out to the two waves alternately; dY goes with the second
-  auto prefetch = [&](int64_t t, float* buf, int lane_k) {    // (the lane is passed in: hoisted lane arithmetic ends up in scratch)
-    const int c = lane_k & 15, g = lane_k >> 4;
-    int64_t nn = t * 16 + c;
-    nn = nn < N ? nn : N - 1;
-    int i0 = 0;
-    if (wide_dma) {
-      int64_t n4 = t * 16 + 4 * (lane_k & 3);
-      n4 = n4 + 3 < N ? n4 : N - 4;
-      const int n16 = rows4 >> 4;
-      for (int j = half; j < n16; j += 2) {
-        const int k = 16 * j + (lane_k >> 2);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)(k < K0 ? k : K0 - 1) * N + n4),
-                                         (__attribute__((address_space(3))) void*)(buf + j * 256), 16, 0, 0);
-      }
-      i0 = n16 * 4;
-    }
-    for (int i = i0 + half; i < (rows4 >> 2); i += 2) {
-      int k = 4 * i + g;
-      k = k < K0 ? k : K0 - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)k * N + nn),
-                                       (__attribute__((address_space(3))) void*)(buf + i * 64), 4, 0, 0);
-    }
-    if (half)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + nn),
-                                       (__attribute__((address_space(3))) void*)(buf + OFF_DY), 4, 0, 0);
-  };
-  const int64_t tile0 = (int64_t)blockIdx.x * NPAIR + pair, tstride = (int64_t)gridDim.x * NPAIR;
-  if (tile0 < ntiles) prefetch(tile0, stage, lane_k);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();               // image, zero rows, flag words, the first tile's inputs
-  Link lk;
-  lk.mine = xch + half * (NP * 64) + lane_k;
-  lk.their_delta = half ? -(NP * 64) : (NP * 64);
-  lk.my_flag = (lds_flag_t*)(flags + wave);
-  lk.their_flag = (lds_flag_t*)(flags + (wave ^ 1));
-  lk.seq = 0u;
-  lk.slot = 0;
-  const int tile_rec = 2 * NP * 64;          // records per tile of a layer image
-  int cur = 0;
-  for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
-    const float* xb = stage + cur * stage_floats;
-    int lane_l = lane_k;
-    asm volatile("" : "+v"(lane_l));
-    const int lane = lane_l, c = lane & 15, g = lane >> 4;
-    const int64_t n0 = tile * 16, n = n0 + c;
-    const bool live = n < N;
-    const int own0 = 2 * half;               // the wave's first tile of every hidden layer
-    // ---------------- forward recompute of the own tiles
-    f32x4 a[2], g1[2], b[2], g2[2], h1T[2], h2T[2];
-    float seen;
-    const int own_step = half * (NP * 64), oth_step = (half ^ 1) * (NP * 64);
-    bias_init<2>(a, tail + 16 * own0, g);
-    {
-      f16x8 w00[2][NP], w01[2][NP];
-      const u32x4* w0 = lds + OFF_W0 + own0 * tile_rec + lane;
-      load_w<2>(w00, w0);
-      float xs[2][8];
-#pragma unroll
-      for (int s = 0; s < 2; s++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) xs[s][j] = xb[(32 * s + 8 * g + j) * 16 + c];
-      __builtin_amdgcn_sched_barrier(0);
-      BP bx;
-      split8(xs[0], bx);
-      load_w<2>(w01, w0 + NP * 64);
-      __builtin_amdgcn_sched_barrier(0);
-      mac16r<2>(a, bx, w00);
-      split8(xs[1], bx);
-      mac16r<2>(a, bx, w01);
-      seen = half ? 0.f : amax_of8(amax_of8(0.f, xs[0]), xs[1]);     // (both waves read the same inputs)
-    }
-    // per-sample factors of the tile (samples 4 g + r): rT = 2^(e(n) + kscale) of what H / dZ carry into the parameter
-    // gradients, dyT = dY 2^kscale for dW4 / db4; branch-free
-    f32x4 rT, dyT = *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const bool in = n0 + 4 * g + r < N;
-      const int ex = (int)(__float_as_uint(dyT[r]) >> 23) & 255;
-      int er = ex + kscale - CHAIN_EXP + H_PRESCALE_EXP;
-      er = er < 1 ? 0 : (er > 254 ? 254 : er);
-      uint32_t bits = (uint32_t)er << 23;
-      bits = ex > CHAIN_EXP ? bits : 0u;
-      bits = ex == 255 ? 0x3F800000u : bits;
-      rT[r] = __uint_as_float(in ? bits : 0u);
-      dyT[r] = in ? dyT[r] * sc : 0.f;
-    }
-    float dy, dy_pow2;
-    dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
-    bias_init<2>(b, tail + HID + 16 * own0, g);
-    act_both_n<2>(a, g1);  // a = h1 (own tiles)
-    seen = amax_of(amax_of(seen, a[0]), a[1]);
-    {
-      BP po, pp;
-      const u32x4* w = lds + OFF_W1 + own0 * tile_rec + lane;
-      f16x8 wo[2][NP], wp[2][NP];
-      W_EARLY(load_w<2>(wo, w + own_step));
-      post_own(a, po, lk);
-      W_EARLY(load_w<2>(wp, w + oth_step));
-      W_LATE(load_w<2>(wo, w + own_step));
-      mac16r<2>(b, po, wo);
-      h1T[0] = transpose_f32(po, id[0]);
-      h1T[1] = transpose_f32(po, id[1]);
-      W_LATE(load_w<2>(wp, w + oth_step));
-      lk.take(pp);
-#ifndef PSDF_PAIR_LATE_PREFETCH
-      // the partner has posted h1 of THIS tile, so it is done reading the other staging buffer: the next tile's inputs are
-      // requested here, most of a tile ahead of the s_waitcnt that covers them (an HBM round trip under load is longer than a layer)
-      if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats, lane);
-#endif
-      mac16r<2>(b, pp, wp);
-    }
-    bias_init<2>(a, tail + 2 * HID + 16 * own0, g);
-    act_both_n<2>(b, g2);  // b = h2
-    seen = amax_of(amax_of(seen, b[0]), b[1]);
-    {
-      BP po, pp;
-      const u32x4* w = lds + OFF_W2 + own0 * tile_rec + lane;
-      f16x8 wo[2][NP], wp[2][NP];
-      W_EARLY(load_w<2>(wo, w + own_step));
-      post_own(b, po, lk);
-      W_EARLY(load_w<2>(wp, w + oth_step));
-      W_LATE(load_w<2>(wo, w + own_step));
-      mac16r<2>(a, po, wo);
-      h2T[0] = transpose_f32(po, id[0]);
-      h2T[1] = transpose_f32(po, id[1]);
-      W_LATE(load_w<2>(wp, w + oth_step));
-      lk.take(pp);
-      mac16r<2>(a, pp, wp);
-    }
-    f32x4 dz[2];
-    act_both_n<2>(a, dz);  // a = h3, dz = gelu'(z3)
-    seen = amax_of(amax_of(seen, a[0]), a[1]);
-    out_of_range |= __builtin_amdgcn_ballot_w64(seen >= RANGE_LIMIT) != 0ull ? 1u : 0u;
-    // ---------------- output layer: dZ3 = w4 dy gelu'(z3) on the mantissa of dY (dX is multiplied by 2^(e(n) - 4) at the store)
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(tail + 3 * HID + 16 * (own0 + t) + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; r++) dz[t][r] *= w4[r] * dy;
-    }
-    // ---------------- layer 3
-    AT Ao[2], Ap[2];
-    BP pp3;
-    {
-      BP po;
-      const u32x4* w = lds + OFF_T2 + own0 * tile_rec + lane;
-      f16x8 wo[2][NP], wp[2][NP];
-      W_EARLY(load_w<2>(wo, w + own_step));
-      post_own(dz, po, lk);
-      // (behind the post) dW4 = sum dy h3 on the own tiles, db4 on the first wave of the pair
-      if (half == 0) db4 += (dyT[0] + dyT[1]) + (dyT[2] + dyT[3]);
-      {
-        float x[8];
-        own_operand(a, x);
-        BP p;
-        split8(x, p);
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const f32x4 h3T = transpose_f32(p, id[u]);
-          dw4[u].add(h3T, dyT);
-        }
-      }
-      zero_init<2>(a);
-      W_EARLY(load_w<2>(wp, w + oth_step));
-      W_LATE(load_w<2>(wo, w + own_step));
-      mac16r<2>(a, po, wo);
-      transpose_pieces(po, id[0], Ao[0], db3[0], rT);
-      transpose_pieces(po, id[1], Ao[1], db3[1], rT);
-      W_LATE(load_w<2>(wp, w + oth_step));
-      lk.take(pp3);
-      mac16r<2>(a, pp3, wp);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; t++) a[t] *= g2[t];   // dZ2 (own tiles)
-    // ---------------- layer 2
-    BP pp2;
-    {
-      BP po;
-      const u32x4* w = lds + OFF_T1 + own0 * tile_rec + lane;
-      f16x8 wo[2][NP], wp[2][NP];
-      W_EARLY(load_w<2>(wo, w + own_step));
-      post_own(a, po, lk);
-#ifdef PSDF_PAIR_LATE_PREFETCH
-      if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats, lane);
-#endif
-      // (behind the post) the rest of layer 3: the partner's dZ3 tiles transposed, dW3 += dZ3^T (H2 of the own tiles)
-      transpose_pieces_nosum(pp3, id[0], Ap[0]);
-      transpose_pieces_nosum(pp3, id[1], Ap[1]);
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++) {
-        BT B;
-        split4(h2T[ti] * rT, B);
-        dW3[0][ti] = dw_mac<false>(dW3[0][ti], Ao[0], B);
-        dW3[1][ti] = dw_mac<false>(dW3[1][ti], Ao[1], B);
-        dW3[2][ti] = dw_mac<false>(dW3[2][ti], Ap[0], B);
-        dW3[3][ti] = dw_mac<false>(dW3[3][ti], Ap[1], B);
-      }
-      zero_init<2>(dz);
-      W_EARLY(load_w<2>(wp, w + oth_step));
-      W_LATE(load_w<2>(wo, w + own_step));
-      mac16r<2>(dz, po, wo);
-      transpose_pieces(po, id[0], Ao[0], db2[0], rT);
-      transpose_pieces(po, id[1], Ao[1], db2[1], rT);
-      W_LATE(load_w<2>(wp, w + oth_step));
-      lk.take(pp2);
-      mac16r<2>(dz, pp2, wp);
-    }
-#pragma unroll
-    for (int t = 0; t < 2; t++) dz[t] *= g1[t];   // dZ1 (own tiles)
-    // ---------------- layer 1: dW1 rows of the own dZ1 tiles against all of X; dX tiles {0, 1} on the first wave, {2} on the second
-    {
-      BP po, pp;
-      // this wave's requests for the next tile must have landed before its post says so (see the header)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      post_own(dz, po, lk);
-      // (behind the post) the rest of layer 2
-      transpose_pieces_nosum(pp2, id[0], Ap[0]);
-      transpose_pieces_nosum(pp2, id[1], Ap[1]);
-#pragma unroll
-      for (int ti = 0; ti < 2; ti++) {
-        BT B;
-        split4(h1T[ti] * rT, B);
-        dW2[0][ti] = dw_mac<false>(dW2[0][ti], Ao[0], B);
-        dW2[1][ti] = dw_mac<false>(dW2[1][ti], Ao[1], B);
-        dW2[2][ti] = dw_mac<false>(dW2[2][ti], Ap[0], B);
-        dW2[3][ti] = dw_mac<false>(dW2[3][ti], Ap[1], B);
-      }
-      transpose_pieces(po, id[0], Ao[0], db1[0], rT);
-      transpose_pieces(po, id[1], Ao[1], db1[1], rT);
-#pragma unroll
-      for (int u = 0; u < NT0; u++) {
-        const f32x4 xT = *reinterpret_cast<const f32x4*>(xb + (16 * u + c) * 16 + 4 * g);
-        BT B;
-        split4(xT * rT, B);
-        dW1[0][u] = dw_mac<false>(dW1[0][u], Ao[0], B);
-        dW1[1][u] = dw_mac<false>(dW1[1][u], Ao[1], B);
-      }
-      float* p0 = dX + (int64_t)(4 * g) * N + n;
-      if (half == 0) {
-        f32x4 dx[2];
-        zero_init<2>(dx);
-        const u32x4* w = lds + OFF_T0 + lane;
-        mac_step<2>(dx, po, w + own_step);
-        lk.take(pp);
-        mac_step<2>(dx, pp, w + oth_step);
-        if (dX && live) {
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            if (16 * (t + 1) <= K0) {
-#pragma unroll
-              for (int r = 0; r < 4; r++) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
-            } else if (16 * t < K0) {
-#pragma unroll
-              for (int r = 0; r < 4; r++)
-                if (16 * t + 4 * g + r < K0) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
-            }
-          }
-        }
-      } else {
-        f32x4 dx[1];
-        zero_init<1>(dx);
-        const u32x4* w = lds + OFF_T0 + 2 * tile_rec + lane;
-        mac_step<1>(dx, po, w + own_step);
-        lk.take(pp);
-        mac_step<1>(dx, pp, w + oth_step);
-        if (dX && live) {
-          if (48 <= K0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) p0[(int64_t)(32 + r) * N] = dx[0][r] * dy_pow2;
-          } else if (32 < K0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-              if (32 + 4 * g + r < K0) p0[(int64_t)(32 + r) * N] = dx[0][r] * dy_pow2;
-          }
-        }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (out_of_range && lane_k == 0) atomicOr(absmax + 1, 1u);
-  // ---------------- wave accumulators -> workgroup image -> this workgroup's slot.  The two waves of a pair own disjoint parts
-  // of the image: one round per pair
-  const int lane = lane_k, c = lane & 15, g = lane >> 4;
-  __syncthreads();
-  float* G = reinterpret_cast<float*>(lds);
-  for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) G[e] = 0.f;
-  __syncthreads();
-  for (int w = 0; w < NPAIR; w++) {
-    if (pair == w) {
-#pragma unroll
-      for (int q = 0; q < NT; q++) {
-        const int to = q < 2 ? 2 * half + q : 2 * (half ^ 1) + (q - 2);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = (16 * to + 4 * g + r) * 64;  // [out][in]
-#pragma unroll
-          for (int t = 0; t < 2; t++) {
-            G[G_W2 + row + 16 * (2 * half + t) + c] += dW2[q][t][r];
-            G[G_W3 + row + 16 * (2 * half + t) + c] += dW3[q][t][r];
-          }
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = (16 * (2 * half + t) + 4 * g + r) * 64;
-#pragma unroll
-          for (int ti = 0; ti < NT0; ti++) G[G_W1 + row + 16 * ti + c] += dW1[t][ti][r];
-        }
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        float v1 = db1[t].total(), v2 = db2[t].total(), v3 = db3[t].total(), v4 = dw4[t].total();
-        v1 += __shfl_xor(v1, 16, 64); v2 += __shfl_xor(v2, 16, 64); v3 += __shfl_xor(v3, 16, 64); v4 += __shfl_xor(v4, 16, 64);
-        v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); v3 += __shfl_xor(v3, 32, 64); v4 += __shfl_xor(v4, 32, 64);
-        if (g == 0) {
-          const int f = 16 * (2 * half + t) + c;
-          G[G_B1 + f] += v1;
-          G[G_B2 + f] += v2;
-          G[G_B3 + f] += v3;
-          G[G_W4 + f] += v4;
-        }
-      }
-      float b4 = db4;
-      b4 += __shfl_xor(b4, 16, 64);
-      b4 += __shfl_xor(b4, 32, 64);
-      if (lane == 0 && half == 0) G[G_B4] += b4;
-    }
-    __syncthreads();
-  }
-  float* dst = partial + (size_t)blockIdx.x * G_TOTAL;
-  for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) dst[e] = G[e];
-}
-
-// Sum of the workgroup images, accumulated into the torch-layout gradients (dW_l [out, in], db_l)
-// ====================================================================================== chain / dW wave pairs (round 5, second form)
-// The N-split pair above halves a wave's independent work per layer; this form keeps the layers whole and cuts the WORK LIST
-// instead: a CHAIN wave (forward recompute, activation derivatives, the dH chain, dX: everything on the tile's dependency path)
-// and a dW wave (the 48 operand transposes, the 88 parameter-gradient products, the bias sums: 136 of the 274 MFMAs and a
-// quarter of the VALU work, none of it on the dependency path) share a SIMD (waves w, w + 4).  The hand-over is ONE-WAY: the
-// chain wave appends the operand pieces it has split anyway (dZ3, h2, h3 | dZ2, h1 | dZ1, X) to a ring of 4-KB records, the dW
-// wave consumes them in order; the chain wave never waits for its partner unless the ring (four records) is full.  The dW wave
-// holds all 176 accumulators (+ 80 registers of working set), the chain wave none.
-// What makes it fit 160 KB: the weights are resident ONCE, as row-major fp16 pieces [out][in] (48 KB instead of 93 KB for W and
-// W^T as ready-made operand records); the forward operand of a 16 x 32 tile is still one ds_read_b128 per lane, the TRANSPOSED
-// operand of the dH chain comes out of the same image with two ds_read_b64_tr_b16 (gfx950's transposing LDS read: 16 lanes hand
-// in the addresses of 4 x 16 values, lane i receives column i).  16-byte chunks of a row are XOR-swizzled with bit-reversed row
-// bits so that both access patterns spread over the banks.  LDS: image 49 KB + staging 4 x 8.5 KB + rings 4 x 16 KB = 147 KB.
-namespace cd {
-constexpr int WS = 128;                        // bytes per image row (64 fp16)
-constexpr int W_PIECE = 64 * WS, W_LAYER = NP * W_PIECE, W_BYTES = 3 * W_LAYER;      // 8 KB, 16 KB, 48 KB
-constexpr int TAIL_BYTES = (TAIL_FLOATS * 4 + 15) / 16 * 16;
-constexpr int IMG_BYTES = W_BYTES + TAIL_BYTES;
-constexpr int NREC = 4, REC_BYTES = 4096, RING_BYTES = NREC * REC_BYTES;
-constexpr int SIDE_BYTES = 2 * 64;             // dY of the tile (16 floats), two tiles in flight
-constexpr int NPAIR = 4;
-constexpr int STAGE_FLOATS = 64 * 16 + 64;
-constexpr size_t LDS_BYTES = (size_t)IMG_BYTES + (size_t)NPAIR * 2 * STAGE_FLOATS * 4 + (size_t)NPAIR * (RING_BYTES + SIDE_BYTES) + 64;
-// 16-byte chunk `chunk` (0..7: eight fp16) of image row `row`: the chunk index is XOR-ed with the bit-reversed bits 1..3 of the
-// row, so that (a) the 16 lanes of a forward read (16 consecutive rows, one chunk) and (b) the 16 lanes of a transposing read
-// (4 consecutive rows x 4 chunks) each touch 16 different 16-byte bank groups
-__host__ __device__ inline int swz_key(int row) {
-  const int f = (row >> 1) & 7;
-  return ((f & 1) << 2) | (f & 2) | ((f >> 2) & 1);
-}
-__host__ __device__ inline int wofs(int row, int chunk) { return row * WS + ((chunk ^ swz_key(row)) << 4); }
-}  // namespace cd
-
-// the image of cd: thread = (layer 0..2, row, chunk) splits eight weights into their two pieces; tail threads copy biases etc.
-__global__ void mlp_cd_pack_kernel(int K0, const float* __restrict__ W0, const float* __restrict__ W1, const float* __restrict__ W2,
-                                   const float* __restrict__ W3, const float* __restrict__ b0, const float* __restrict__ b1,
-                                   const float* __restrict__ b2, const float* __restrict__ b3, unsigned char* __restrict__ rec,
-                                   uint32_t* __restrict__ absmax) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < 3 * 64 * 8) {
-    const int layer = t / 512, row = (t >> 3) & 63, chunk = t & 7;
-    float w[8];
-    float wmax = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int pos = 8 * chunk + j;
-      if (layer == 0) {
-        w[j] = pos < K0 ? W0[row * K0 + pos] : 0.f;                 // natural order of the inputs
-      } else {
-        const int col = kf(pos >> 5, (pos >> 3) & 3, pos & 7);      // position 32 s + 8 g + j holds feature kf(s, g, j)
-        w[j] = (layer == 1 ? W1 : W2)[row * HID + col];
-      }
-      wmax = __builtin_fmaxf(wmax, __builtin_fabsf(w[j]));
-    }
-    if (wmax >= 65504.f) atomicOr(absmax + 1, 1u);
-    u32x4 hi, lo;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      uint32_t h, l;
-      split2(w[2 * i], w[2 * i + 1], h, l);
-      hi[i] = h;
-      lo[i] = l;
-    }
-    unsigned char* base = rec + layer * cd::W_LAYER + cd::wofs(row, chunk);
-    *reinterpret_cast<u32x4*>(base) = hi;
-    *reinterpret_cast<u32x4*>(base + cd::W_PIECE) = lo;
-  } else {
-    const int e = t - 3 * 64 * 8;
-    float* tail = reinterpret_cast<float*>(rec + cd::W_BYTES);
-    if (e < HID) tail[e] = b0[e];
-    else if (e < 2 * HID) tail[e] = b1[e - HID];
-    else if (e < 3 * HID) tail[e] = b2[e - 2 * HID];
-    else if (e < 4 * HID) {
-      tail[e] = W3[e - 3 * HID];
-      if (__builtin_fabsf(W3[e - 3 * HID]) >= 65504.f) atomicOr(absmax + 1, 1u);
-    } else if (e == 4 * HID) tail[e] = b3[0];
-  }
-}
-
-typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef __attribute__((address_space(3))) unsigned char lds_byte;
-
-// single-producer / single-consumer ring of 4-KB records between the two waves of a pair
-struct Ring {
-  lds_byte* base;               // NREC records
-  lds_flag_t* produced;         // records written so far (chain wave)
-  lds_flag_t* consumed;         // records released so far (dW wave)
-  uint32_t at;                  // this wave's position (records)
-  // chain wave: a free record to write (waits while the ring is full)
-  __device__ __forceinline__ unsigned char* claim() {
-#pragma unroll 1
-    for (int spin = 0; spin < (1 << 24); spin++) {
-      const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)*consumed);
-      if ((int32_t)(at - c) < cd::NREC) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
-    asm volatile("" ::: "memory");
-    return (unsigned char*)(base + (at & (cd::NREC - 1)) * cd::REC_BYTES);
-  }
-  __device__ __forceinline__ void publish() {
-    asm volatile("" ::: "memory");
-    at++;
-    *produced = at;             // behind the record's stores in the wave's DS queue
-    asm volatile("" ::: "memory");
-  }
-  // dW wave: the next record, once it is there
-  __device__ __forceinline__ lds_byte* acquire() {
-#pragma unroll 1
-    for (int spin = 0; spin < (1 << 24); spin++) {
-      const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)*produced);
-      if ((int32_t)(p - at) > 0) break;
-      __builtin_amdgcn_s_sleep(4);
-    }
-    asm volatile("" ::: "memory");
-    return base + (at & (cd::NREC - 1)) * cd::REC_BYTES;
-  }
-  __device__ __forceinline__ void release() {
-    asm volatile("" ::: "memory");
-    at++;
-    *consumed = at;             // behind the record's loads in the wave's DS queue
-    asm volatile("" ::: "memory");
-  }
-};
-// Record of operand pieces: [k-step 2][piece 2][entry 64] 16-byte entries.  The chain wave's lane (c = sample, g) holds the
-// eight k-slots = features kf(s, g, 0..7) of sample c; the dW wave needs the transposed view -- lane (f, g') the samples
-// 4 g' .. 4 g' + 3 of feature f -- and gets it straight out of the record with ds_read_b64_tr_b16: the 16 lanes of group g' hand
-// in the addresses of the 16 entries of samples 4 g' + j, lane groups q (8 bytes each: the half u of the entry for tile 2 s + u)
-// and lane f receives k-slot (f & 3) of lane group f >> 2 = feature f of the tile.  No transposing MFMAs, no conversions.
-// Placement (measured: the lane-linear placement cost 1 000 LDS conflict cycles per tile, profiles/r05_pmc_sq_mlp_cd_v1.txt):
-//   entry(c, g) = 16 (c >> 2) + ((4 g + (c & 3)) ^ 4 ((c >> 2) & 1))     the 8 contiguous lanes of a store group (8 samples, one g)
-//                                                                         fall on 8 different 16-byte bank groups
-//   halves swapped in the entries of odd sample blocks                    the two 16-lane groups a transposing read serves together
-//                                                                         (g' = 0, 1 / 2, 3) then read opposite halves: all 64 banks once
-struct RecLane {        // per-lane byte offsets inside a [piece][k-step] plane of a record
-  int w_lo, w_hi;       // chain wave: where the low / high 8 bytes of its entry go
-  int r_u0;             // dW wave: its transposing read of the tile with u = 0 (u = 1: ^ 8)
-};
-__device__ __forceinline__ RecLane rec_lane(int lane) {
-  const int c = lane & 15, g = lane >> 4;
-  RecLane r;
-  const int ent = 16 * (c >> 2) + ((4 * g + (c & 3)) ^ (4 * ((c >> 2) & 1))), sw = (c >> 2) & 1;
-  r.w_lo = ent * 16 + 8 * sw;
-  r.w_hi = ent * 16 + 8 - 8 * sw;
-  // reader: lane i of group g' hands in the entry of (sample 4 g' + (i >> 2), lane group i & 3)
-  const int i = c, gp = g;
-  r.r_u0 = (16 * gp + ((4 * (i & 3) + (i >> 2)) ^ (4 * (gp & 1)))) * 16 + 8 * (gp & 1);
-  return r;
-}
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void put_pieces(unsigned char* rec, const RecLane& rl, int s, const BP& b) {
-#pragma unroll
-  for (int p = 0; p < NP; p++) {
-    const u32x4 v = __builtin_bit_cast(u32x4, b.p[p]);
-    unsigned char* plane = rec + (s * NP + p) * 1024;
-    *reinterpret_cast<u32x2*>(plane + rl.w_lo) = u32x2{v[0], v[1]};
-    *reinterpret_cast<u32x2*>(plane + rl.w_hi) = u32x2{v[2], v[3]};
-  }
-}
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-// the four samples 4 g' .. + 3 of feature (lane & 15) of tile `tile`, one piece
-__device__ __forceinline__ f16x4 get_T(lds_byte* rec, const RecLane& rl, int tile, int piece) {
-  const int off = ((tile >> 1) * NP + piece) * 1024 + ((tile & 1) ? (rl.r_u0 ^ 8) : rl.r_u0);
-  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rec + off));
-  return __builtin_bit_cast(f16x4, v);
-}
-// acc += sum over the lane's four samples of piece value x factor (v_fma_mix_f32: the fp16 source is widened inside the fma)
-__device__ __forceinline__ float mix_sum(float acc, const f16x4& v, const f32x4& w) {
-#pragma unroll
-  for (int j = 0; j < 4; j++) acc = __builtin_fmaf((float)v[j], w[j], acc);
-  return acc;
-}
-
-template <int NT0>
-__global__ void __launch_bounds__(PAIR_WAVES * 64, 2)
-    mlp_bwd_split_f16_cd_kernel(int64_t N, int K0, int rows4, const float* __restrict__ X, const float* __restrict__ dY,
-                                const u32x4* __restrict__ img, uint32_t* __restrict__ absmax, float* __restrict__ dX,
-                                float* __restrict__ partial) {
-  static_assert(NT0 == 3, "the chain / dW form holds three input tiles (K0 <= 48)");
-  extern __shared__ __align__(16) u32x4 lds[];
-  float sc, isc;
-  const int kscale = dy_scale((uint32_t)__builtin_amdgcn_readfirstlane((int)absmax[0]), sc, isc);
-  for (int i = threadIdx.x; i < cd::IMG_BYTES / 16; i += PAIR_WAVES * 64) lds[i] = img[i];
-  const int lane_k = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), pair = wave & 3;
-  const bool is_chain = wave < 4;             // waves w and w + 4 share a SIMD (tools/simd_map.hip)
-  lds_byte* wimg = (lds_byte*)(unsigned char*)lds;
-  const float* tail = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(lds) + cd::W_BYTES);
-  unsigned char* dyn = reinterpret_cast<unsigned char*>(lds) + cd::IMG_BYTES;
-  float* stage = reinterpret_cast<float*>(dyn) + pair * 2 * cd::STAGE_FLOATS;
-  unsigned char* ring_mem = dyn + (size_t)cd::NPAIR * 2 * cd::STAGE_FLOATS * 4 + (size_t)pair * (cd::RING_BYTES + cd::SIDE_BYTES);
-  float* side = reinterpret_cast<float*>(ring_mem + cd::RING_BYTES);          // dY of the tile in flight, by tile parity
-  uint32_t* flags = reinterpret_cast<uint32_t*>(dyn + (size_t)cd::NPAIR * 2 * cd::STAGE_FLOATS * 4 +
-                                                (size_t)cd::NPAIR * (cd::RING_BYTES + cd::SIDE_BYTES));
-  if (threadIdx.x < 2 * cd::NPAIR) flags[threadIdx.x] = 0u;
-  Ring ring;
-  ring.base = (lds_byte*)ring_mem;
-  ring.produced = (lds_flag_t*)(flags + 2 * pair);
-  ring.consumed = (lds_flag_t*)(flags + 2 * pair + 1);
-  ring.at = 0u;
-  const int64_t ntiles = (N + 15) / 16;
-  const int64_t tile0 = (int64_t)blockIdx.x * cd::NPAIR + pair, tstride = (int64_t)gridDim.x * cd::NPAIR;
-  constexpr int STAGE_ROWS = 64, stage_floats = cd::STAGE_FLOATS, OFF_DY = STAGE_ROWS * 16;
-  if (is_chain) {
-    // ================================================================= chain wave
-    __builtin_amdgcn_s_setprio(2);
-    for (int i = rows4 * 16 + lane_k; i < STAGE_ROWS * 16; i += 64) {
-      stage[i] = 0.f;
-      stage[stage_floats + i] = 0.f;
-    }
-    const bool wide_dma = (N & 3) == 0 && N >= 4;
-    auto prefetch = [&](int64_t t, float* buf, int lane_k) {
-      const int c = lane_k & 15, g = lane_k >> 4;
-      int64_t nn = t * 16 + c;
-      nn = nn < N ? nn : N - 1;
-      int i0 = 0;
-      if (wide_dma) {
-        int64_t n4 = t * 16 + 4 * (lane_k & 3);
-        n4 = n4 + 3 < N ? n4 : N - 4;
-        const int n16 = rows4 >> 4;
-        for (int j = 0; j < n16; j++) {
-          const int k = 16 * j + (lane_k >> 2);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)(k < K0 ? k : K0 - 1) * N + n4),
-                                           (__attribute__((address_space(3))) void*)(buf + j * 256), 16, 0, 0);
-        }
-        i0 = n16 * 4;
-      }
-      for (int i = i0; i < (rows4 >> 2); i++) {
-        int k = 4 * i + g;
-        k = k < K0 ? k : K0 - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)k * N + nn),
-                                         (__attribute__((address_space(3))) void*)(buf + i * 64), 4, 0, 0);
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dY + nn),
-                                       (__attribute__((address_space(3))) void*)(buf + OFF_DY), 4, 0, 0);
-    };
-    if (tile0 < ntiles) prefetch(tile0, stage, lane_k);
-    __syncthreads();             // image, flag words (the dW waves wait here too)
-    uint32_t out_of_range = 0u;
-    float db4 = 0.f;
-    int cur = 0;
-    for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const float* xb = stage + cur * stage_floats;
-      int lane_l = lane_k;
-      asm volatile("" : "+v"(lane_l));
-      const int lane = lane_l, c = lane & 15, g = lane >> 4;
-      const int64_t n0 = tile * 16, n = n0 + c;
-      const bool live = n < N;
-      const RecLane rl = rec_lane(lane);
-      // ---- addresses into the weight image (see cd::wofs): forward operand of out tile t, k-step s = row 16 t + c, chunk 4 s + g
-      const int fkey = cd::swz_key(c);                                    // (rows 16 t + c: bits 1..3 are those of c)
-      const int f_lane = c * cd::WS + ((g ^ (fkey & 3)) << 4);           // + 16 t rows + 64 (s ^ (fkey >> 2))
-      auto fwd_w = [&](int layer, int t, int s, int p) -> f16x8 {
-        const int off = layer * cd::W_LAYER + p * cd::W_PIECE + 16 * t * cd::WS + f_lane + (((s ^ (fkey >> 2)) & 1) << 6);
-        return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>((const unsigned char*)lds + off));
-      };
-      // transposed operand of in tile t, k-step s (over the layer's OUTPUTS, kf order): rows 32 s + 16 hh + 4 g + (i >> 2),
-      // columns = the 16 inputs of tile t; lane i of a 16-lane group hands in the address of inputs 4 (i & 3) .. + 3 of its row
-      const int i16 = c, q = i16 & 3, trow = 4 * g + (i16 >> 2);
-      const int tkey = cd::swz_key(trow);                                 // (+ 32 s + 16 hh: multiples of 16 do not change the key)
-      auto tr_w = [&](int layer, int t, int s, int p) -> f16x8 {
-        int chunk, half8;
-        if (layer == 0) {                 // inputs in natural order: feature 16 t + 4 q -> chunk 2 t + (q >> 1), half q & 1
-          chunk = 2 * t + (q >> 1);
-          half8 = q & 1;
-        } else {                          // position order: tile t = 2 s' + u, features 16 t + 4 q -> chunk 4 s' + q, half u
-          chunk = 4 * (t >> 1) + q;
-          half8 = t & 1;
-        }
-        const int off = layer * cd::W_LAYER + p * cd::W_PIECE + (32 * s + trow) * cd::WS + ((chunk ^ tkey) << 4) + 8 * half8;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(wimg + off));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(wimg + off + 16 * cd::WS));
-        typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
-        const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(f16x8, both);
-      };
-      // one chain layer: out[NTILE] += W x in over both k-steps; the operand pieces of each k-step go to per_step
-      auto chain_fwd = [&](int layer, const f32x4 (&in)[NT], f32x4 (&out)[NT], BP (&keep)[2]) {
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-          f16x8 w[NT][NP];
-#pragma unroll
-          for (int t = 0; t < NT; t++)
-#pragma unroll
-            for (int p = 0; p < NP; p++) w[t][p] = fwd_w(layer, t, s, p);
-          float x[8];
-          step_operand(in, s, x);
-          split8(x, keep[s]);
-          mac16r<NT>(out, keep[s], w);
-        }
-      };
-      // ---------------- forward recompute
-      f32x4 a[NT], g1[NT], b[NT], g2[NT];
-      BP h1p[2], h2p[2];
-      float seen;
-      bias_init<NT>(a, tail, g);
-      {
-        float xs[2][8];
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-#pragma unroll
-          for (int j = 0; j < 8; j++) xs[s][j] = xb[(32 * s + 8 * g + j) * 16 + c];
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-          f16x8 w[NT][NP];
-#pragma unroll
-          for (int t = 0; t < NT; t++)
-#pragma unroll
-            for (int p = 0; p < NP; p++) w[t][p] = fwd_w(0, t, s, p);
-          BP bx;
-          split8(xs[s], bx);
-          mac16r<NT>(a, bx, w);
-        }
-        seen = amax_of8(amax_of8(0.f, xs[0]), xs[1]);
-      }
-      bias_init<NT>(b, tail + HID, g);
-      act_both(a, g1);  // a = h1
-#pragma unroll
-      for (int t = 0; t < NT; t++) seen = amax_of(seen, a[t]);
-      chain_fwd(1, a, b, h1p);
-      bias_init<NT>(a, tail + 2 * HID, g);
-      act_both(b, g2);  // b = h2
-#pragma unroll
-      for (int t = 0; t < NT; t++) seen = amax_of(seen, b[t]);
-      chain_fwd(2, b, a, h2p);
-      f32x4 dz[NT];
-      act_both(a, dz);  // a = h3, dz = gelu'(z3)
-#pragma unroll
-      for (int t = 0; t < NT; t++) seen = amax_of(seen, a[t]);
-      out_of_range |= __builtin_amdgcn_ballot_w64(seen >= RANGE_LIMIT) != 0ull ? 1u : 0u;
-      // ---------------- the tile's dY for the dW wave (16 floats, by tile parity), then record 1: the pieces of h3
-      if (lane < 16) side[cur * 16 + lane] = (n0 + lane < N) ? xb[OFF_DY + lane] : 0.f;
-      {
-        unsigned char* r = ring.claim();
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-          float x[8];
-          step_operand(a, s, x);
-          BP p;
-          split8(x, p);
-          put_pieces(r, rl, s, p);
-        }
-        ring.publish();
-      }
-      {
-        f32x4 dyT = *reinterpret_cast<const f32x4*>(xb + OFF_DY + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; r++) dyT[r] = (n0 + 4 * g + r < N) ? dyT[r] * sc : 0.f;
-        db4 += (dyT[0] + dyT[1]) + (dyT[2] + dyT[3]);
-      }
-      float dy, dy_pow2;
-      dy_parts(live ? xb[OFF_DY + c] : 0.f, dy, dy_pow2);
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(tail + 3 * HID + 16 * t + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; r++) dz[t][r] *= w4[r] * dy;
-      }
-      // one layer of the dH chain: out[NTO] += W^T x dz over both k-steps; the pieces of dz go out as a record, `other` (the
-      // H-side pieces the dW wave needs with them) as the next one
-      auto chain_bwd = [&](auto ntile_tag, int layer, const f32x4 (&in)[NT], auto& out, const BP (*other)[2]) {
-        constexpr int NTO = decltype(ntile_tag)::value;
-        unsigned char* r = ring.claim();
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-          f16x8 w[NTO][NP];
-#pragma unroll
-          for (int t = 0; t < NTO; t++)
-#pragma unroll
-            for (int p = 0; p < NP; p++) w[t][p] = tr_w(layer, t, s, p);
-          float x[8];
-          step_operand(in, s, x);
-          BP pz;
-          split8(x, pz);
-          put_pieces(r, rl, s, pz);
-          mac16r<NTO>(out, pz, w);
-        }
-        ring.publish();
-        if (other) {
-          unsigned char* r2 = ring.claim();
-          put_pieces(r2, rl, 0, (*other)[0]);
-          put_pieces(r2, rl, 1, (*other)[1]);
-          ring.publish();
-        }
-      };
-      // ---------------- layer 3
-      zero_init<NT>(a);
-      chain_bwd(std::integral_constant<int, NT>{}, 2, dz, a, &h2p);
-#pragma unroll
-      for (int t = 0; t < NT; t++) a[t] *= g2[t];   // dZ2^T
-      // ---------------- layer 2
-      if (tile + tstride < ntiles) prefetch(tile + tstride, stage + (cur ^ 1) * stage_floats, lane);
-      zero_init<NT>(dz);
-      chain_bwd(std::integral_constant<int, NT>{}, 1, a, dz, &h1p);
-#pragma unroll
-      for (int t = 0; t < NT; t++) dz[t] *= g1[t];   // dZ1^T
-      // ---------------- layer 1: the pieces of dZ1, then X in feature-lane order as it lies in the staging buffer
-      f32x4 dx[NT0];
-      zero_init<NT0>(dx);
-      chain_bwd(std::integral_constant<int, NT0>{}, 0, dz, dx, nullptr);
-      {
-        u32x4* r = reinterpret_cast<u32x4*>(ring.claim()) + lane;          // (feature-lane order as staged: lane-linear entries)
-#pragma unroll
-        for (int u = 0; u < NT0; u++) r[u * 64] = *reinterpret_cast<const u32x4*>(xb + (16 * u + c) * 16 + 4 * g);
-        ring.publish();
-      }
-      if (dX && live) {
-        float* p0 = dX + (int64_t)(4 * g) * N + n;
-#pragma unroll
-        for (int t = 0; t < NT0; t++) {
-          if (16 * (t + 1) <= K0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
-          } else if (16 * t < K0) {
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-              if (16 * t + 4 * g + r < K0) p0[(int64_t)(16 * t + r) * N] = dx[t][r] * dy_pow2;
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (out_of_range && lane_k == 0) atomicOr(absmax + 1, 1u);
-    // ---------------- epilogue (chain wave): db4
-    __syncthreads();             // every pair is done: the weight image is dead
-    float* G = reinterpret_cast<float*>(lds);
-    for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) G[e] = 0.f;
-    __syncthreads();
-    float b4 = db4;
-    b4 += __shfl_xor(b4, 16, 64);
-    b4 += __shfl_xor(b4, 32, 64);
-    for (int w = 0; w < cd::NPAIR; w++) {
-      if (pair == w && lane_k == 0) G[G_B4] += b4;
-      __syncthreads();
-    }
-  } else {
-    // ================================================================= dW wave
-    f32x4 dW1[NT][NT0], dW2[NT][NT], dW3[NT][NT];
-#pragma unroll
-    for (int to = 0; to < NT; to++) {
-#pragma unroll
-      for (int ti = 0; ti < NT; ti++) dW2[to][ti] = dW3[to][ti] = zero4();
-#pragma unroll
-      for (int ti = 0; ti < NT0; ti++) dW1[to][ti] = zero4();
-    }
-    Sum<false> db1[NT], db2[NT], db3[NT], dw4[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      db1[t].clear(); db2[t].clear(); db3[t].clear(); dw4[t].clear();
-    }
-    __syncthreads();             // image, flag words
-    int cur = 0;
-    for (int64_t tile = tile0; tile < ntiles; tile += tstride, cur ^= 1) {
-      int lane_l = lane_k;
-      asm volatile("" : "+v"(lane_l));
-      const int lane = lane_l, g = lane >> 4;
-      const int64_t n0 = tile * 16;
-      const RecLane rl = rec_lane(lane);
-      // ---- record 1: h3 -> dW4 (needs the tile's dY, written before the record)
-      f32x4 rT;
-      {
-        lds_byte* r = ring.acquire();
-        f32x4 dyT = *reinterpret_cast<const f32x4*>(side + cur * 16 + 4 * g);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const bool in = n0 + 4 * g + q < N;
-          const int ex = (int)(__float_as_uint(dyT[q]) >> 23) & 255;
-          int er = ex + kscale - CHAIN_EXP + H_PRESCALE_EXP;
-          er = er < 1 ? 0 : (er > 254 ? 254 : er);
-          uint32_t bits = (uint32_t)er << 23;
-          bits = ex > CHAIN_EXP ? bits : 0u;
-          bits = ex == 255 ? 0x3F800000u : bits;
-          rT[q] = __uint_as_float(in ? bits : 0u);
-          dyT[q] = in ? dyT[q] * sc : 0.f;
-        }
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-          dw4[t].v = mix_sum(dw4[t].v, get_T(r, rl, t, 1), dyT);     // smallest first
-          dw4[t].v = mix_sum(dw4[t].v, get_T(r, rl, t, 0), dyT);
-        }
-        ring.release();
-      }
-      // ---- dZ-side operands of a layer (both pieces of the four samples of the lane's feature: one MFMA operand) + bias sums
-      auto dz_side = [&](AT (&A)[NT], Sum<false> (&db)[NT]) {
-        lds_byte* r = ring.acquire();
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-          const f16x4 hi = get_T(r, rl, t, 0), lo = get_T(r, rl, t, 1);
-          db[t].v = mix_sum(db[t].v, lo, rT);
-          db[t].v = mix_sum(db[t].v, hi, rT);
-          typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-          A[t].t01 = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        ring.release();
-      };
-      // ---- H-side operand of tile t out of a record of pieces: value = high + low (exact), scaled, split again
-      auto h_side = [&](lds_byte* r, int t, BT& B) {
-        const f16x4 hi = get_T(r, rl, t, 0), lo = get_T(r, rl, t, 1);
-        f32x4 h;
-#pragma unroll
-        for (int j = 0; j < 4; j++) h[j] = ((float)hi[j] + (float)lo[j]) * rT[j];
-        split4(h, B);
-      };
-      {
-        AT A[NT];
-        dz_side(A, db3);
-        lds_byte* r = ring.acquire();
-#pragma unroll
-        for (int ti = 0; ti < NT; ti++) {
-          BT B;
-          h_side(r, ti, B);
-#pragma unroll
-          for (int to = 0; to < NT; to++) dW3[to][ti] = dw_mac<false>(dW3[to][ti], A[to], B);
-        }
-        ring.release();
-      }
-      {
-        AT A[NT];
-        dz_side(A, db2);
-        lds_byte* r = ring.acquire();
-#pragma unroll
-        for (int ti = 0; ti < NT; ti++) {
-          BT B;
-          h_side(r, ti, B);
-#pragma unroll
-          for (int to = 0; to < NT; to++) dW2[to][ti] = dw_mac<false>(dW2[to][ti], A[to], B);
-        }
-        ring.release();
-      }
-      {
-        AT A[NT];
-        dz_side(A, db1);
-        lds_byte* r = ring.acquire();
-#pragma unroll
-        for (int u = 0; u < NT0; u++) {
-          const f32x4 xT = *reinterpret_cast<const f32x4*>((const unsigned char*)(r + (u * 64 + lane) * 16));
-          BT B;
-          split4(xT * rT, B);
-#pragma unroll
-          for (int to = 0; to < NT; to++) dW1[to][u] = dw_mac<false>(dW1[to][u], A[to], B);
-        }
-        ring.release();
-      }
-    }
-    // ---------------- epilogue (dW wave): accumulators -> workgroup image
-    const int lane = lane_k, c = lane & 15, g = lane >> 4;
-    __syncthreads();
-    float* G = reinterpret_cast<float*>(lds);
-    for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) G[e] = 0.f;      // (all eight waves zero the image together)
-    __syncthreads();
-    for (int w = 0; w < cd::NPAIR; w++) {
-      if (pair == w) {
-#pragma unroll
-        for (int to = 0; to < NT; to++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int row = (16 * to + 4 * g + r) * 64;  // [out][in]
-#pragma unroll
-            for (int ti = 0; ti < NT; ti++) {
-              G[G_W2 + row + 16 * ti + c] += dW2[to][ti][r];
-              G[G_W3 + row + 16 * ti + c] += dW3[to][ti][r];
-            }
-#pragma unroll
-            for (int ti = 0; ti < NT0; ti++) G[G_W1 + row + 16 * ti + c] += dW1[to][ti][r];
-          }
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-          float v1 = db1[t].total(), v2 = db2[t].total(), v3 = db3[t].total(), v4 = dw4[t].total();
-          v1 += __shfl_xor(v1, 16, 64); v2 += __shfl_xor(v2, 16, 64); v3 += __shfl_xor(v3, 16, 64); v4 += __shfl_xor(v4, 16, 64);
-          v1 += __shfl_xor(v1, 32, 64); v2 += __shfl_xor(v2, 32, 64); v3 += __shfl_xor(v3, 32, 64); v4 += __shfl_xor(v4, 32, 64);
-          if (g == 0) {
-            G[G_B1 + 16 * t + c] += v1;
-            G[G_B2 + 16 * t + c] += v2;
-            G[G_B3 + 16 * t + c] += v3;
-            G[G_W4 + 16 * t + c] += v4;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  float* G = reinterpret_cast<float*>(lds);
-  float* dst = partial + (size_t)blockIdx.x * G_TOTAL;
-  for (int e = threadIdx.x; e < G_TOTAL; e += PAIR_WAVES * 64) dst[e] = G[e];
-}
-
 // guard_drops: the launch has a bf16 launch queued behind it that redoes the batch when the range guard is raised (absmax[1]):
 // the images are then dropped here.  events (host-mapped, may be NULL): count of raised guards, for the one-time warning.
 __global__ void mlp_split_reduce_kernel(const float* __restrict__ partial, const uint32_t* __restrict__ absmax, int nimg, int K0, float* __restrict__ dW0,
@@ -1908,13 +829,7 @@ __global__ void mlp_split_pack_kernel(int K0, const float* __restrict__ W0, cons
 
 }  // namespace
 
-#ifndef PSDF_MLP_BWD_F16_PAIR_DEFAULT
-#define PSDF_MLP_BWD_F16_PAIR_DEFAULT 0
-#endif
-#ifndef PSDF_MLP_BWD_F16_CD_DEFAULT
-#define PSDF_MLP_BWD_F16_CD_DEFAULT 0
-#endif
-static int g_f16_form = 0;   // form of the last launch: 1 = one wave per SIMD, 2 = wave pairs
+static int g_f16_form = 0;   // 1 once a split-fp16 backward has been launched (the wave-pair forms 2 / 3 of round 5 live in attic/rejected/)
 namespace psdf {
 size_t mlp_backward_split_scratch_bytes(int K0, int64_t N);      // mlp_bwd_split.hip
 int mlp_backward_split_impl(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
@@ -1938,7 +853,7 @@ static volatile uint32_t* range_events() {
 
 extern "C" {
 
-// 0 = no split-fp16 backward yet, 1 = the last one ran mlp_bwd_split_f16_kernel, 2 = mlp_bwd_split_f16_pair_kernel
+// 0 = no split-fp16 backward yet, 1 = the last one ran mlp_bwd_split_f16_kernel (the only form built since round 6)
 int psdf_mlp_backward_split_f16_form(void) { return g_f16_form; }
 
 // Same contract as psdf_mlp_backward (include/psdf.h) for dims = {K0 <= 64, 64, 64, 64, 1} with dW / db requested; returns
@@ -1962,16 +877,9 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int64_t ntiles = (N + 15) / 16;
-  // PSDF_MLP_BWD_F16_FORM: "pair" = the wave-pair kernel (two waves per SIMD, K0 <= 48), "one" = one wave per SIMD; read at
-  // every call so that tests and benches can A/B the two in one process
-  const char* form = getenv("PSDF_MLP_BWD_F16_FORM");
-  const bool pair_form = nt0 == 3 && (form ? form[0] == 'p' : PSDF_MLP_BWD_F16_PAIR_DEFAULT);
-  // "cd" = chain / dW wave pairs (mlp_bwd_split_f16_cd_kernel: its own weight image, cd::IMG_BYTES)
-  const bool cd_form = nt0 == 3 && !pair_form && (form ? form[0] == 'c' : PSDF_MLP_BWD_F16_CD_DEFAULT);
-  const size_t pair_lds = img_bytes + (size_t)(PAIR_WAVES / 2) * 2 * (64 * 16 + 64) * 4 + (size_t)(PAIR_WAVES / 2) * XCH_PAIR * 16 + 64;
-  g_f16_form = pair_form ? 2 : (cd_form ? 3 : 1);
-  int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;   // four tiles in flight per workgroup in either form
-  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave (pair) walks many tiles
+  g_f16_form = 1;
+  int64_t blocks = (ntiles + NWAVES - 1) / NWAVES;   // four tiles in flight per workgroup
+  if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
   const size_t part_bytes = ((size_t)blocks * G_TOTAL * sizeof(float) + 15) & ~(size_t)15;
   // range guard (see RANGE_LIMIT): nets the three-piece bf16 kernel covers (K0 <= 52) get that kernel queued behind this one,
   // conditional on the guard word; wider inputs (53 .. 64: no such kernel) keep the saturating arithmetic and only count the event
@@ -2002,28 +910,13 @@ int psdf_mlp_backward_split_f16(int n_layers, const int* dims, int64_t N, const 
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NWAVES * 64), lds_bytes, st, N, K0, rows4, X, dY,                  \
                        reinterpret_cast<const u32x4*>(rec), absmax, dX, partial);                                           \
   } while (0)
-  if (cd_form)
-    hipLaunchKernelGGL(mlp_cd_pack_kernel, dim3((3 * 64 * 8 + TAIL_FLOATS + 255) / 256), dim3(256), 0, st, K0, weights[0], weights[1],
-                       weights[2], weights[3], biases[0], biases[1], biases[2], biases[3], reinterpret_cast<unsigned char*>(rec), absmax);
-  else if (nt0 == 3) PACK(3); else PACK(4);
+  if (nt0 == 3) PACK(3); else PACK(4);
   {
     int64_t ab = ((N >> 2) + 1023) / 1024;     // four 16-byte loads per thread, at most 512 workgroups (= 512 atomics)
     ab = ab < 1 ? 1 : (ab > 512 ? 512 : ab);
     hipLaunchKernelGGL(mlp_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, N, dY, absmax);
   }
-  if (cd_form) {
-    auto kern = mlp_bwd_split_f16_cd_kernel<3>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd::LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PAIR_WAVES * 64), cd::LDS_BYTES, st, N, K0, rows4, X, dY,
-                       reinterpret_cast<const u32x4*>(rec), absmax, dX, partial);
-  } else if (pair_form) {
-    auto kern = mlp_bwd_split_f16_pair_kernel<3>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PAIR_WAVES * 64), pair_lds, st, N, K0, rows4, X, dY,
-                       reinterpret_cast<const u32x4*>(rec), absmax, dX, partial);
-  } else if (nt0 == 3) MAIN(3); else MAIN(4);
+  if (nt0 == 3) MAIN(3); else MAIN(4);
 #undef PACK
 #undef MAIN
   hipLaunchKernelGGL(mlp_split_reduce_kernel, dim3((G_TOTAL + 255) / 256, 16), dim3(256), 0, st, partial, absmax, (int)blocks, K0,

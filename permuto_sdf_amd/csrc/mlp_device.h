@@ -324,18 +324,20 @@ __device__ __forceinline__ void init_bias4(f32x16 (&acc)[T], const float* __rest
 }
 
 // ---- the same with TWO fp16 pieces per operand (round 3; opt-in, see psdf_mlp_forward_f16): a = a0 + a1, a0 = fp16(a) rounded
-// toward zero (the remainder is exact in fp32), a1 = fp16(a - a0); products a1 b0 + a0 b1 + a0 b0 on v_mfma_f32_32x32x16_f16.
+// to nearest (v_cvt_pk_f16_f32; the remainder is exact in fp32 and fits 12 bits), a1 = fp16(a - a0) to nearest (round 6; rounds
+// 3-5 truncated both pieces, a one-sided error of up to 3 * 2^-23 per operand); products a1 b0 + a0 b1 + a0 b0 on v_mfma_f32_32x32x16_f16.
 // Half the MFMAs and about half the splitting work of the three-piece bf16 scheme; gfx950's matrix pipe honours fp16 subnormals
 // (attic/prototypes/mlp_fwd_split_f16.hip), so small low pieces keep an absolute precision of 2^-24; values must stay below 65504.
 // The image keeps the three-slot record layout (slot 2 unused), so SplitPlan is shared.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8h(const float (&x)[8], f16x8& hi, f16x8& lo) {
   u32x4 qh, ql;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const auto h2 = __builtin_amdgcn_cvt_pkrtz(x[2 * i], x[2 * i + 1]);
-    const f32x2 r = f32x2{x[2 * i], x[2 * i + 1]} - f32x2{(float)h2[0], (float)h2[1]};
-    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r.x, r.y);
+    const h2v_t h2 = __builtin_convertvector(f32x2{x[2 * i], x[2 * i + 1]}, h2v_t);   // v_cvt_pk_f16_f32, nearest even
+    const f32x2 r = f32x2{x[2 * i], x[2 * i + 1]} - f32x2{(float)h2[0], (float)h2[1]};      // exact
+    const h2v_t l2 = __builtin_convertvector(r, h2v_t);
     qh[i] = __builtin_bit_cast(uint32_t, h2);
     ql[i] = __builtin_bit_cast(uint32_t, l2);
   }
@@ -344,9 +346,9 @@ __device__ __forceinline__ void split8h(const float (&x)[8], f16x8& hi, f16x8& l
 }
 // two pieces of a float for the pack kernel: {hi, lo} as 16-bit patterns
 __device__ __forceinline__ void split2h_bits(float x, uint32_t (&piece)[3]) {
-  const auto h2 = __builtin_amdgcn_cvt_pkrtz(x, 0.f);
+  const h2v_t h2 = __builtin_convertvector(f32x2{x, 0.f}, h2v_t);
   const float r = x - (float)h2[0];
-  const auto l2 = __builtin_amdgcn_cvt_pkrtz(r, 0.f);
+  const h2v_t l2 = __builtin_convertvector(f32x2{r, 0.f}, h2v_t);
   piece[0] = __builtin_bit_cast(uint32_t, h2) & 0xFFFFu;
   piece[1] = __builtin_bit_cast(uint32_t, l2) & 0xFFFFu;
   piece[2] = 0u;

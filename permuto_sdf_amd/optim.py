@@ -39,6 +39,9 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         for p in getattr(self, "_touched", {}):
             self._rebuild_active(p)
+        # a (consolidated) checkpoint holds FULL moments; under the sharded update a rank must hold zeros outside the ranges it
+        # owns (parallel.consolidated_state_dict sums over the ranks): the next step(owned=...) clears what it does not own
+        self._moments_loaded = True
 
     def state_dict(self, allow_partial=False):
         """Under the sharded data-parallel update (step(owned=...), parallel.ShardedUpdate) a rank holds the moments of the
@@ -67,7 +70,24 @@ class FusedAdamW(torch.optim.Optimizer):
         if owned:
             if not hasattr(self, "_sharded_params"):
                 self._sharded_params = set()
+                self._sharded_ranges = {}
             self._sharded_params.update(owned.keys())
+            for p, ranges in owned.items():
+                ranges = sorted((int(lo), int(hi)) for lo, hi in ranges)
+                if self._sharded_ranges.get(p) != ranges or getattr(self, "_moments_loaded", False):
+                    # first sharded step of this parameter (or the first one after load_state_dict / a change of ownership):
+                    # moments outside the owned ranges are somebody else's -- zero them, so that "a rank holds zeros outside
+                    # its ranges" (what consolidated_state_dict relies on) is a fact and not an assumption
+                    st = self.state.get(p)
+                    if st and "exp_avg" in st:
+                        for k in ("exp_avg", "exp_avg_sq"):
+                            f, prev = st[k].view(-1), 0
+                            for lo, hi in ranges + [(f.numel(), f.numel())]:
+                                if lo > prev:
+                                    f[prev:lo].zero_()
+                                prev = max(prev, hi)
+                    self._sharded_ranges[p] = ranges
+            self._moments_loaded = False
         self.generation += 1
         blocks_pending = []
         for group in self.param_groups:

@@ -13,8 +13,6 @@ hotpath.backward can be checked for races without a second device.
 """
 import os
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (see bench.py); only effective before the HIP runtime starts
-
 import torch
 import torch.distributed as dist
 
@@ -28,6 +26,11 @@ def init(backend=None):
     if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("PSDF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            # this driver stack needs dmabuf IPC for RCCL (hipIpcGetMemHandle fails otherwise) and the variable only counts before
+            # the HIP runtime starts: launch scripts and bench.py export it; importing this module no longer edits the environment
+            _warn_once("HSA_ENABLE_IPC_MODE_LEGACY=0 is not set in this process: RCCL may fail with 'hipIpcGetMemHandle: invalid "
+                       "argument' on hosts whose driver only supports dmabuf IPC -- export it in the launcher")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl" and os.environ.get("PSDF_BENCH_SINGLE_DEVICE") != "1":
@@ -474,10 +477,19 @@ def consolidated_state_dict(optimizer):
             index[p] = i
             i += 1
     state = dict(sd["state"])
+    owned_ranges = getattr(optimizer, "_sharded_ranges", {})
     for p in sorted(sharded, key=lambda q: index[q]):
         st = dict(state[index[p]])
         for k in ("exp_avg", "exp_avg_sq"):
             t = st[k].detach().clone()
+            # only the ranges this rank OWNS enter the sum (after load_state_dict of a consolidated checkpoint every
+            # rank holds full moments until its next sharded step; stale copies must never be added to the owner's values)
+            if p in owned_ranges:
+                f, prev = t.view(-1), 0
+                for lo, hi in list(owned_ranges[p]) + [(f.numel(), f.numel())]:
+                    if lo > prev:
+                        f[prev:lo].zero_()
+                    prev = max(prev, hi)
             if dist.get_backend() == "nccl":
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
             else:

@@ -178,3 +178,38 @@ def test_consolidated_state_dict_gathers_the_sharded_moments():
         assert np.array_equal(ret["m_%d" % r], full) and np.array_equal(ret["v_%d" % r], full ** 2)
         assert np.array_equal(ret["small_%d" % r], np.full(8, 0.5, np.float32))
         assert ret["live_%d" % r] == ret["own_%d" % r]
+
+
+def _roundtrip_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from permuto_sdf_amd import parallel
+    parallel.init(backend="gloo")
+    n = 4096
+    big = torch.nn.Parameter(torch.zeros(n))
+    opt = torch.optim.Adam([big], lr=1e-3)
+    lo, hi = parallel.shard_bounds(n, 4)
+    full_m = torch.arange(n, dtype=torch.float32) + 1.0
+    # the state right after load_state_dict() of a CONSOLIDATED checkpoint: every rank holds the FULL moments ...
+    opt.state[big] = {"step": torch.tensor(3.0), "exp_avg": full_m.clone(), "exp_avg_sq": full_m.clone() ** 2}
+    opt._sharded_params = {big}
+    opt._sharded_ranges = {big: [(lo, hi)]}
+    # ... the owner then takes a step on its range (stands in for FusedAdamW.step(owned=...)); the stale copies elsewhere stay
+    with torch.no_grad():
+        opt.state[big]["exp_avg"][lo:hi] += 0.5
+    sd = parallel.consolidated_state_dict(opt)
+    ret["m_%d" % rank] = sd["state"][0]["exp_avg"].numpy()
+    ret["v_%d" % rank] = sd["state"][0]["exp_avg_sq"].numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_consolidation_after_a_resume_counts_every_element_once():
+    """save -> load -> step -> save: after a resume every rank holds full moments; the second consolidated save must
+    hold the OWNER's updated value of every element, not owner + (world - 1) stale copies."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_roundtrip_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    full = np.arange(4096, dtype=np.float32) + 1.0
+    for r in range(world):
+        assert np.array_equal(ret["m_%d" % r], full + 0.5) and np.array_equal(ret["v_%d" % r], full ** 2)

@@ -34,6 +34,30 @@ def test_library_host_and_oracle_read_the_same_header():
         assert "2531011" not in src, f
 
 
+# The frozen defaults, written out a SECOND time on purpose: product header and oracle read one file, so a typo there would move
+# checker and product together.  These literals are the restated algorithm's own constants (SURVEY.md
+# App. A.2 / A.3: multiplier 2531011, a tie raises the later rank, sqrt((i+1)(i+2)) scaling, no extra inverse-stddev factor,
+# pseudo-level concatenation, lattice init 1e-5, shift scale 10) and must be edited by hand, with a reason, when a convention flips.
+FROZEN_DEFAULTS = {"PSDF_ENC_HASH_MULTIPLIER": 2531011, "PSDF_ENC_RANK_TIE_RAISES_LATER": 1, "PSDF_ENC_SCALE_SQRT_TERM": 1,
+                   "PSDF_ENC_SCALE_INV_STDDEV": 0, "PSDF_ENC_CONCAT_DEFAULT_LAYOUT": 1, "PSDF_ENC_LATTICE_INIT_SCALE": 1e-5,
+                   "PSDF_ENC_RANDOM_SHIFT_SCALE": 10.0, "PSDF_ENC_CONCAT_NONE": 0, "PSDF_ENC_CONCAT_PSEUDO_LEVELS": 1,
+                   "PSDF_ENC_CONCAT_APPEND": 2}
+
+
+def test_the_header_still_holds_the_frozen_defaults():
+    """literal copy of every default, independent of the header's text (and therefore of what product and oracle parse)"""
+    assert po.parse_conventions(HEADER) == FROZEN_DEFAULTS
+    # ... and the oracle's behaviour under them, on a hand-computed case that does not go through any parser: the hash of the
+    # lattice key (1, -2, 3) with 2^18 rows is ((1 * m + (-2 mod 2^32)) * m + 3) * m mod 2^32 mod 2^18, m = 2531011
+    m, h = 2531011, 0
+    for k in (1, -2, 3):
+        h = ((h + (k & 0xFFFFFFFF)) * m) & 0xFFFFFFFF
+    # vertex_index_scalar(rem0, rank, remainder 0) hashes the key rem0 itself
+    assert h % (1 << 18) == po.vertex_index_scalar([1, -2, 3, 0], [0, 0, 0, 0], 0, 3, 1 << 18)
+    rem0 = torch.tensor([[1, -2, 3, 0]])
+    assert h % (1 << 18) == int(po.vertex_indices(rem0, torch.zeros_like(rem0), 1 << 18)[0, 0])
+
+
 def _flipped(tmp_path, **kv):
     txt = open(HEADER).read()
     for k, v in kv.items():

@@ -428,8 +428,7 @@ def test_unfused_widths_raise_unless_opted_in(dev):
                                   # width, the full 64 rows (no zero-padded row in the staging buffer), fewer than 16 rows (no
                                   # 16-byte request at all), a batch smaller than one tile
                                   (52, 262_144), (64, 65_536), (5, 4_096), (36, 8)])
-@pytest.mark.parametrize("form", ["one", "pair", "cd"])
-def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypatch):
+def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale):
     """csrc/mlp_bwd_split_f16.hip (two fp16 pieces per fp32 operand, three products; gradient chain evaluated on dY * 2^k with k
     from max|dY|): every gradient against a float64 evaluation, for upstream gradients of ordinary size, tiny (1e-7: every
     value would be an fp16 subnormal without the scaling), large (3e4: would overflow fp16), and spread over six decades
@@ -439,9 +438,7 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypa
     import ctypes
     from permuto_sdf_amd import _lib as L
     from permuto_sdf_amd.mlp import _dims_array, _zero_grads
-    # form: one wave per SIMD (the default) or the wave-pair kernel of round 5 (two waves per SIMD, K0 <= 48; wider inputs
-    # run the one-wave kernel under either setting -- the form query below says which one ran)
-    monkeypatch.setenv("PSDF_MLP_BWD_F16_FORM", form)
+    # (the two two-waves-per-SIMD forms of round 5 were slower and left the library in round 6: attic/rejected/)
     torch.manual_seed(K0 + N % 7)
     dims = [K0, 64, 64, 64, 1]
     lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
@@ -469,7 +466,7 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypa
     assert rc == 0, rc
     which = L.lib().psdf_mlp_backward_split_f16_form
     which.restype = ctypes.c_int
-    assert which() == ({"pair": 2, "cd": 3}[form] if (form != "one" and K0 <= 48) else 1)
+    assert which() == 1
     got = [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
     names = ["dX", "dW1", "db1", "dW2", "db2", "dW3", "db3", "dW4", "db4"]
     errs = {}
@@ -494,9 +491,8 @@ def test_split_f16_backward_matches_float64(dev, K0, N, dy_scale, form, monkeypa
                arr(dWs), arr(dbs), L.stream()) == -2
 
 
-@pytest.mark.parametrize("form", ["one", "pair", "cd"])
 @pytest.mark.parametrize("what", ["inputs", "hidden", "weights"])
-def test_split_f16_backward_range_guard(dev, what, form, monkeypatch):
+def test_split_f16_backward_range_guard(dev, what):
     """The two-piece fp16 arithmetic holds for |inputs|, |hidden activations| < 2^8 (the H-side operand of the parameter-gradient
     products is pre-scaled by 2^8) and |weights| < 65504.  Outside, the kernel raises a guard word, its summing launch drops
     the clipped images and the three-piece bf16 kernel queued behind it redoes the batch: the gradients are right (float64,
@@ -506,7 +502,6 @@ def test_split_f16_backward_range_guard(dev, what, form, monkeypatch):
     import ctypes
     from permuto_sdf_amd import _lib as L
     from permuto_sdf_amd.mlp import _dims_array, _zero_grads
-    monkeypatch.setenv("PSDF_MLP_BWD_F16_FORM", form)
     torch.manual_seed(11)
     K0, N = 36, 262_144 + 48
     dims = [K0, 64, 64, 64, 1]
@@ -558,7 +553,7 @@ def test_split_f16_backward_range_guard(dev, what, form, monkeypatch):
 
     before = int(events())
     errs = run(x)
-    print("range guard (%s, %s): worst %.1e" % (what, form, max(errs.values())), errs)
+    print("range guard (%s): worst %.1e" % (what, max(errs.values())), errs)
     assert int(events()) == before + 1
     assert max(errs.values()) <= 2e-5, errs
     if what == "inputs":

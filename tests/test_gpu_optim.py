@@ -72,3 +72,35 @@ def test_compat_apex_fused_adam_matches_torch_adamw_on_the_references_groups(dev
     for ga, gb in zip(ra, rb):
         for a, b in zip(ga, gb):
             assert (a - b).abs().max() <= 2e-6 * max(1.0, float(a.abs().max())), (tuple(a.shape), float((a - b).abs().max()))
+
+
+def test_sharded_step_after_a_resume_clears_the_moments_it_does_not_own(dev):
+    """load_state_dict() of a consolidated checkpoint leaves FULL moments on every rank; the first step(owned=...)
+    must zero what lies outside the owned ranges (parallel.consolidated_state_dict sums over the ranks), and must not touch the
+    parameter there."""
+    from permuto_sdf_amd.optim import FusedAdamW
+    torch.manual_seed(1)
+    n = 1 << 17
+    p = torch.nn.Parameter(torch.randn(n, device=dev))
+    opt = FusedAdamW([p], lr=1e-2)
+    p.grad = torch.randn(n, device=dev)
+    opt.step()                                   # full moments everywhere (a replicated step = what a checkpoint holds)
+    sd = opt.state_dict()
+    q = torch.nn.Parameter(p.detach().clone())
+    opt2 = FusedAdamW([q], lr=1e-2)
+    opt2.load_state_dict(sd)
+    before = q.detach().clone()
+    q.grad = torch.randn(n, device=dev)
+    lo, hi = n // 4, n // 2
+    opt2.step(owned={q: [(lo, hi)]})
+    st = opt2.state[q]
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert float(st[k][:lo].abs().max()) == 0.0 and float(st[k][hi:].abs().max()) == 0.0
+        assert float(st[k][lo:hi].abs().max()) > 0.0
+    assert torch.equal(q.detach()[:lo], before[:lo]) and torch.equal(q.detach()[hi:], before[hi:])
+    assert not torch.equal(q.detach()[lo:hi], before[lo:hi])
+    assert opt2._sharded_ranges[q] == [(lo, hi)]
+    # a second sharded step leaves the zeros alone and keeps updating the owned range
+    q.grad = torch.randn(n, device=dev)
+    opt2.step(owned={q: [(lo, hi)]})
+    assert float(st["exp_avg"][:lo].abs().max()) == 0.0

@@ -139,10 +139,6 @@ SPILLING = {
     r"mlp_dbl_bwd_kernelILi3ELi4ELi4ELi4ELi1ELb1EE": 256, r"mlp_dbl_bwd_kernelILi4ELi4ELi4ELi4ELi1ELb1EE": 320,
     # background colour head 80 -> 64x2 -> 3 with parameter gradients (models.py:463-469): every training step, one register
     r"mlp_bwd_kernelILi5ELi4ELi4ELi0ELi1ELb1ELb1ELb1ELi4E": 8,
-    # round 5, OPT-IN form of the split-fp16 backward (PSDF_MLP_BWD_F16_FORM=cd; the default one-wave kernel and the `pair` form do
-    # not spill): the dW wave of the chain / dW pair holds all 176 accumulators in a 256-register budget; measured slower than the
-    # default either way (profiles/r05_mlp_pair_ab.txt)
-    r"mlp_bwd_split_f16_cd_kernelILi3E": 40,
     # fused encode -> MLP forward of a 32-wide net with 33 outputs (psdf_encode_mlp_forward: the sphere tracer's colour pass)
     r"fused_fwd_kernelILi2ELi2ELi2ELi2ELb0EE": 8,
 }
