@@ -45,3 +45,39 @@ def reference_step(pos, dirs, normals, dt, rgb, gt, nr_rays, per_ray, lattice, s
     return dict(feat=feat.detach(), sdf=sdf.detach(), pred=pred.detach(), loss=float(loss), g_lattice=lat.grad,
                 g_weights=[m.weight.grad for m in lin], g_biases=[m.bias.grad for m in lin], alpha=alpha.detach(),
                 weights=w_.detach())
+
+
+def reference_forward(pos, dirs, normals, dt, rgb, gt, nr_rays, per_ray, lattice, scale_per_level, shifts, window, weights, biases,
+                      inv_s, cos_anneal_ratio, points_scaling=1e-3, dtype=torch.float64, chunk_rays=1024):
+    """Forward only (sdf [N,1], radiance [R,3], loss) of the same chain in `dtype`, ray chunk by ray chunk, so that the FULL bench
+    batch (16 384 rays x 128) fits a CPU in about a minute.  dtype = float64 is the ARBITER of the full-size parity test: both
+    the HIP path and an fp32 evaluation of the reference arithmetic are measured against it.  (The simplex of a point is found
+    from the same fp32 positions; the encoding is continuous across simplex boundaries, so a different rounding of the
+    elevated coordinates moves features by O(eps), never by a jump.)"""
+    lat = lattice.detach().to(dtype)
+    sh = shifts.detach().to(dtype)
+    win = torch.as_tensor(window).to(dtype)
+    mods = []
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        lin = torch.nn.Linear(w.shape[1], w.shape[0]).to(dtype)
+        lin.weight.data.copy_(w.to(dtype))
+        lin.bias.data.copy_(b.to(dtype))
+        mods.append(lin)
+        if i < len(weights) - 1:
+            mods.append(torch.nn.GELU())
+    mlp = torch.nn.Sequential(*mods)
+    inv_s = torch.as_tensor(inv_s).to(dtype)
+    sdfs, preds = [], []
+    with torch.no_grad():
+        for r0 in range(0, nr_rays, chunk_rays):
+            r1 = min(nr_rays, r0 + chunk_rays)
+            s = slice(r0 * per_ray, r1 * per_ray)
+            feat = po.encode(pos[s].to(dtype), lat, scale_per_level, sh, win, True, points_scaling)
+            sdf = mlp(feat)
+            alpha, om = no.neus_alpha(sdf, dirs[s].to(dtype), normals[s].to(dtype), dt[s].to(dtype), inv_s, cos_anneal_ratio)
+            pred, _, _ = no.composite_equal(alpha, om, rgb[s].to(dtype), r1 - r0, per_ray, reference_compat=False)
+            sdfs.append(sdf)
+            preds.append(pred)
+    sdf, pred = torch.cat(sdfs), torch.cat(preds)
+    loss = no.rgb_loss(gt.to(dtype), pred, torch.ones(nr_rays, 1, dtype=dtype))
+    return dict(sdf=sdf, pred=pred, loss=float(loss))

@@ -75,7 +75,12 @@ class SdfHotPath:
         # mask pays (sphere tracing).
         feat = encode_forward_raw(cfg, pos, self.enc.lattice_values.detach(), self.enc.scale_factor,
                                   self.enc.random_shift_per_level.detach(), self.window)
+        timed = self.events is not None and "mlp_fwd" in self.events
+        if timed:
+            self.events["mlp_fwd"][0].record()
         sdf = mlp_forward_raw(self.mlp.dims, feat, packed, f16=f16)           # [1, N] feature-major == [N,1] memory
+        if timed:
+            self.events["mlp_fwd"][1].record()
         sdf_col = sdf.view(-1, 1)
         per_ray = self._max_per_ray(rs)
         if self.fuse_compositing and per_ray is not None:

@@ -199,6 +199,13 @@ def test_cfg2_full_batch_dense_gradient_against_float64(dev, dy_kind, L_):
         mods += [lin] + ([torch.nn.GELU()] if i < len(mlp.layers) - 1 else [])
     net = torch.nn.Sequential(*mods)
     lins = [m for m in mods if isinstance(m, torch.nn.Linear)]
+    # the SAME net evaluated the way the reference evaluates it: unmodified torch.nn in fp32 on this GPU (rocBLAS), measured
+    # against the same float64 -- the calibration of "fp32-equivalent" (round 6): printed beside ours, and ours must stay within
+    # a small factor of it
+    import copy
+    net32 = copy.deepcopy(net).float()
+    lins32 = [m for m in net32 if isinstance(m, torch.nn.Linear)]
+    t_sdf = t_dx = 0.0
     g64 = torch.zeros(L_, T_, F_, dtype=torch.float64, device=dev)
     sf = po.scale_factors(enc.scale_per_level, 3)
     shifts = enc.random_shift_per_level.detach()
@@ -213,6 +220,11 @@ def test_cfg2_full_batch_dense_gradient_against_float64(dev, dy_kind, L_):
         e_sdf = max(e_sdf, float((sdf[0, sl].double() - y[:, 0]).abs().max()))
         e_dx = max(e_dx, float((d_feat[:, sl].t().double() - x.grad).abs().max()))
         dx_max = max(dx_max, float(x.grad.abs().max()))
+        x32 = feat[:, sl].t().clone().requires_grad_(True)
+        y32 = net32(x32)
+        y32.backward(dY[:, sl].t())
+        t_sdf = max(t_sdf, float((y32[:, 0].double() - y[:, 0]).abs().max()))
+        t_dx = max(t_dx, float((x32.grad.double() - x.grad).abs().max()))
         pc = pos[sl]            # the restatement's elementwise fp32 arithmetic, evaluated on the GPU (2 M points x 16 levels)
         for l in range(L_):
             rem0, rank, bary = po.simplex(pc, shifts[l], sf[l])
@@ -238,7 +250,13 @@ def test_cfg2_full_batch_dense_gradient_against_float64(dev, dy_kind, L_):
     for i, lin in enumerate(lins):
         errs["dW%d" % i] = float((dWs[i].double() - lin.weight.grad).abs().max() / lin.weight.grad.abs().max())
         errs["db%d" % i] = float((dbs[i].double() - lin.bias.grad).abs().max() / lin.bias.grad.abs().max())
+    t32 = {"sdf": t_sdf / float(sdf.abs().max()), "d_features": t_dx / dx_max}
+    for i, (lin, l32) in enumerate(zip(lins, lins32)):
+        t32["dW%d" % i] = float((l32.weight.grad.double() - lin.weight.grad).abs().max() / lin.weight.grad.abs().max())
+        t32["db%d" % i] = float((l32.bias.grad.double() - lin.bias.grad).abs().max() / lin.bias.grad.abs().max())
     per_level = [float((g_lat[l].double() - g64[l]).abs().max() / g64[l].abs().max()) for l in range(L_)]
+    print("   torch.nn fp32 (rocBLAS) on the same inputs vs the same float64: %s" % " ".join("%s %.1e" % kv for kv in t32.items()))
+    print("   ratio ours / torch-fp32: %s" % " ".join("%s %.1f" % (k, errs[k] / max(t32[k], 1e-12)) for k in t32))
     assert e_rows <= 2e-6 * float(feat.abs().max()), e_rows
     print("cfg 2 (L = %d), all 2 097 152 samples carry gradient (%s), kernels (fwd %d, bwd %d) vs float64: %s; lattice per level max %.1e"
           % (L_, dy_kind, last_path(2), last_path(1), " ".join("%s %.1e" % kv for kv in errs.items()), max(per_level)))
