@@ -14,6 +14,7 @@
 // ray-ordered, reproducible and exactly sized (no holes, no compaction copy).
 #include <cstdlib>
 #include "psdf_common.h"
+#include <stdlib.h>
 
 using namespace psdf;
 
@@ -272,15 +273,11 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 // to count and once to write: the DDA loop is a chain of dependent 1-byte grid probes, the most expensive thing in a
 // volume render after the network itself.)
 template <bool USE_GRID, typename G>
-__global__ void __launch_bounds__(PSDF_BLOCK)
-    march_kernel(int nr_rays, G g, Occ o, const float* __restrict__ origins,
-                 const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
-                 float min_dist, int max_per_ray, Pcg rng, int jitter, int* __restrict__ counts,
-                 float* __restrict__ spacings, float* __restrict__ ztemp) {
-  extern __shared__ uint32_t cm_lds[];
-  const uint32_t* cm = stage_coarse(o, cm_lds);
-  const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
-  if (ray >= nr_rays) return;
+__device__ __forceinline__ void march_ray(int ray, const G& g, const Occ& o, const uint32_t* cm, const float* __restrict__ origins,
+                                          const float* __restrict__ dirs, const float* __restrict__ t_entry,
+                                          const float* __restrict__ t_exit_p, float min_dist, int max_per_ray, Pcg rng,
+                                          int jitter, int* __restrict__ counts, float* __restrict__ spacings,
+                                          float* __restrict__ ztemp) {
   const v3 org = ld3(origins + 3 * (int64_t)ray), dir = ld3(dirs + 3 * (int64_t)ray);
   const v3 idir = safe_inverse(dir);
   const float t_start = t_entry[ray], t_exit = t_exit_p[ray];
@@ -376,6 +373,365 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
   }
   counts[ray] = created;
   spacings[ray] = spacing;
+}
+template <bool USE_GRID, typename G>
+__global__ void __launch_bounds__(PSDF_BLOCK)
+    march_kernel(int nr_rays, G g, Occ o, const float* __restrict__ origins,
+                 const float* __restrict__ dirs, const float* __restrict__ t_entry, const float* __restrict__ t_exit_p,
+                 float min_dist, int max_per_ray, Pcg rng, int jitter, int* __restrict__ counts,
+                 float* __restrict__ spacings, float* __restrict__ ztemp) {
+  extern __shared__ uint32_t cm_lds[];
+  const uint32_t* cm = stage_coarse(o, cm_lds);
+  const int ray = blockIdx.x * PSDF_BLOCK + threadIdx.x;
+  if (ray >= nr_rays) return;
+  march_ray<USE_GRID, G>(ray, g, o, cm, origins, dirs, t_entry, t_exit_p, min_dist, max_per_ray, rng, jitter, counts, spacings,
+                         ztemp);
+}
+
+// ---------------------------------------------------------------------------------- the march of a FEW rays (round 6)
+// A training step marches a few hundred rays: march_kernel then runs on a dozen waves, one per SIMD, and its duration is the
+// length of ONE ray's dependent chain -- ~900 DDA steps of ~100 instructions (4 cycles of issue each for the one wave of a SIMD)
+// plus a global probe's latency per step or group of steps: 207 us for 727 rays (profiles/r05_cfg4_manual_kernel_stats.txt).
+// The float sequence of a ray is a contract (sample counts and positions are bit-exact against the reference), so the walk
+// itself cannot be split over lanes by distance; what CAN be split is the work of one step:
+//   * FOUR LANES PER RAY (a quad): lane c < 3 owns axis c (lane 3 repeats axis 2), so position, voxel coordinate and face
+//     distance of the three axes are ONE instruction stream of scalar-sized work; the three-way minimum and the voxel key are
+//     combined with quad_perm DPP (no LDS, no extra latency).  Same expressions, same order, per axis: bit-identical.
+//   * the first march (occupied length) never waits for memory: the walk does not depend on what it finds, so it only RECORDS
+//     (voxel key, step length) per step in LDS (512 steps per ray: every ray through a 256^3 grid); a second phase reads the
+//     occupancy bytes of all recorded voxels, four per ray and instruction, and adds the lengths up in step order;
+//   * the second march (sample placement) finds its occupancy in that record instead of in memory: it visits the same
+//     voxels in the same order, so a four-entry window (one per lane of the quad) that moves forward answers every probe
+//     whose voxel KEY matches a recorded one -- the answer is the byte of exactly the voxel the reference would read; a voxel
+//     that is not in the window (a corner the first walk skipped, a jump past the window) is probed in memory as before;
+//   * the voxel key is the packed coordinate triple (10 bits each) instead of the Morton index: spreading the bits is only
+//     needed where a byte is read, not on the dependent chain (coordinates >= 1024 keep the reference's multiply form, tagged).
+// Used for fast grids (extent 1, power-of-two n) and nr_rays <= MARCH_QUAD_MAX_RAYS; PSDF_MARCH_FORM=thread|quad overrides.
+constexpr int QCAP = 512, QSTRIDE = QCAP + 1, QRAYS = 16;    // steps recorded per ray; row stride (bank spread); rays per wave
+constexpr int MARCH_QUAD_MAX_RAYS = 8192;
+constexpr uint32_t KEY_OCC = 0x80000000u, KEY_MASK = 0x7fffffffu;   // a key = the voxel's coordinates, 10 bits each; bit 31 = occupied
+template <int J> __device__ __forceinline__ uint32_t qb(uint32_t v) {       // lane J of the quad, to all four
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, true);
+}
+template <int J> __device__ __forceinline__ float qbf(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J * 0x55, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {                   // OR over the quad, in all four lanes
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+  return v;
+}
+// minimum of |x| over the quad.  The operands are magnitudes (sign bit clear), so the order of the floats is the order of
+// their bit patterns as unsigned integers and a NaN is larger than every number: the unsigned minimum IS fminf(fminf(|a|, |b|),
+// |c|) -- "a NaN is a missing value" included -- and v_min_u32 takes a DPP operand directly (fminf's lowering puts a
+// canonicalising v_max in front of every minimum: three instructions instead of one)
+__device__ __forceinline__ float quad_min_abs(float x) {
+  uint32_t v = __builtin_bit_cast(uint32_t, x) & 0x7fffffffu;
+  const uint32_t v1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+  v = v < v1 ? v : v1;
+  const uint32_t v2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);
+  v = v < v2 ? v : v2;
+  return __builtin_bit_cast(float, v);
+}
+struct QAxis {     // what a lane knows of its ray: one axis
+  float org, dir, idir, hs, tr;
+  int ax;
+};
+// Key of the voxel of a position (GridFast::pos_to_idx, one axis per lane): the three coordinates side by side -- spreading
+// their bits into the Morton index is only needed where a byte is read (key_to_vox), not on the chain of a step.  Inside the grid
+// <=> no coordinate has a bit at or above log2 n (`hi`).  umax collects the lane's largest coordinate: beyond 1023 the fields
+// overlap and the reference's multiply form of the bit spreading differs from the shift form -- such a ray (it would have to be
+// four grid widths outside) is redone by march_ray at the end.
+__device__ __forceinline__ uint32_t quad_key(const QAxis& a, const GridFast& g, float pos, uint32_t& umax) {
+  float x = pos - a.tr;
+  x = (x + 0.5f) * g.nf;
+  const uint32_t u = sat_u32(x);
+  umax = umax > u ? umax : u;
+  return quad_or(u << (10 * a.ax));
+}
+__device__ __forceinline__ int key_to_vox(uint32_t key) {
+  return (int)(expand_bits10_small(key & 1023u) | (expand_bits10_small((key >> 10) & 1023u) << 1) |
+               (expand_bits10_small((key >> 20) & 1023u) << 2));
+}
+__device__ __forceinline__ float quad_dist(const QAxis& a, const GridFast& g, float pos) {   // dist_to_next_voxel
+  const float p = g.nf * pos;
+  const float tx = (floorf(p + 0.5f + a.hs) - p) * a.idir;
+  return fmaxf(quad_min_abs(tx) * g.inv_n, 0.0f);
+}
+#if defined(PSDF_MARCH_DEBUG)
+__device__ unsigned long long g_march_dbg[16];
+#define DBG_T(i) if (blockIdx.x == 0 && threadIdx.x == 0) g_march_dbg[i] = __builtin_readcyclecounter();
+#else
+#define DBG_T(i)
+#endif
+// PCG32 output function of a state, as the [0, 1) float Pcg::next_float makes of it
+__device__ __forceinline__ float pcg_float_of(uint64_t old) {
+  const uint32_t xs = (uint32_t)(((old >> 18u) ^ old) >> 27u), rot = (uint32_t)(old >> 59u);
+  const uint32_t u = (xs >> rot) | (xs << ((~rot + 1u) & 31u));
+  return __builtin_bit_cast(float, (u >> 9) | 0x3f800000u) - 1.0f;
+}
+// Every loop body below is ONE basic block with its exit test and its rare cases at the END: a step is a chain of ~20 dependent
+// vector instructions at ~10 cycles each for the single wave of a SIMD, and a branch in the middle of it makes the chains on
+// either side run one after the other instead of interleaved (the first build of this kernel, with the break between the voxel
+// and the face distance: 450 cycles per step of the first walk).
+__global__ void __launch_bounds__(64)
+    march_quad_kernel(int nr_rays, GridFast g, Occ o, const float* __restrict__ origins, const float* __restrict__ dirs,
+                      const float* __restrict__ t_entry, const float* __restrict__ t_exit_p, float min_dist, int max_per_ray,
+                      Pcg rng, int jitter, int* __restrict__ counts, float* __restrict__ spacings, float* __restrict__ ztemp) {
+  extern __shared__ uint32_t q_lds[];
+  uint32_t* keyA = q_lds;                                                   // [QRAYS][QSTRIDE] voxel keys (+ occupancy bit)
+  float* ddA = reinterpret_cast<float*>(q_lds + QRAYS * QSTRIDE);           // [QRAYS][QSTRIDE] step lengths; later the samples
+  float* rnA = reinterpret_cast<float*>(q_lds + 2 * QRAYS * QSTRIDE);       // [QRAYS][QSTRIDE] the ray's jitter numbers
+  uint32_t* cm_l = q_lds + 3 * QRAYS * QSTRIDE;
+  const uint32_t* cm = stage_coarse(o, cm_l);
+  const int lane = threadIdx.x, q = lane >> 2, c = lane & 3;
+  const int ray_raw = blockIdx.x * QRAYS + q;
+  const bool valid = ray_raw < nr_rays;
+  const int ray = valid ? ray_raw : nr_rays - 1;           // (spare quads repeat the last ray and write nothing)
+  QAxis a;
+  a.ax = c < 3 ? c : 2;
+  a.org = origins[3 * (int64_t)ray + a.ax];
+  a.dir = dirs[3 * (int64_t)ray + a.ax];
+  a.idir = fabsf(a.dir) < 1e-16f ? 0.f : (float)(1.0 / (double)a.dir);
+  a.hs = 0.5f * sgn(a.dir);
+  a.tr = a.ax == 0 ? g.tx : (a.ax == 1 ? g.ty : g.tz);
+  const float t_start = t_entry[ray], t_exit = t_exit_p[ray];
+  uint32_t* krow = keyA + q * QSTRIDE;
+  float* drow = ddA + q * QSTRIDE;
+  float* rrow = rnA + q * QSTRIDE;
+  // lane 0 records the key, lane 1 the step length; lanes 2 / 3 (and steps that are not taken) write the row's spare word
+  uint32_t* rec = c == 0 ? krow : reinterpret_cast<uint32_t*>(drow);
+  uint32_t* spare = reinterpret_cast<uint32_t*>(drow) + QCAP;
+  uint32_t umax = 0u;
+  const uint32_t hi = (1023u & ~(uint32_t)(g.n - 1)) * 0x00100401u;     // bits >= log2 n of the three coordinate fields
+  const Pcg rng0 = rng;      // (the stream as the launch received it: march_ray below positions it itself)
+  DBG_T(0)
+  // ---- first march: occupied length
+  float occupied = 0.f;
+  float t = t_start;
+  int steps = 0;            // all steps of the walk
+  int kk = 0;               // steps recorded in the current chunk
+  bool walking = true, cached = true;
+  uint32_t last_key = 0u;
+  while (true) {
+    // -- walk up to QCAP steps, recording (voxel, length).  kcap = the steps this ray may still record in the chunk: QCAP, less if
+    // the walk's step bound comes first, 0 once the walk has ended (one compare per step instead of three)
+    const int steps0 = steps;
+    int kcap = walking ? (MAX_DDA_STEPS - steps0 < QCAP ? MAX_DDA_STEPS - steps0 : QCAP) : 0;
+    const int kcap0 = kcap;
+    kk = 0;
+    while (true) {
+      const float pos = a.org + t * a.dir;
+      const uint32_t key = quad_key(a, g, pos, umax);
+      const float d = quad_dist(a, g, pos);
+      const bool cont = kk < kcap;
+      const bool go = cont && (t < t_exit) && ((key & hi) == 0u);
+      kcap = (cont && !go) ? kk : kcap;                    // the walk of this ray ends here
+      uint32_t* dst = (go && c < 2) ? rec + kk : spare;
+      *dst = c == 0 ? key : __builtin_bit_cast(uint32_t, d);
+      t = go ? (t + d) + DDA_EPS : t;
+      kk += go ? 1 : 0;
+      if (!__any(go)) break;
+    }
+    steps = steps0 + kk;
+    walking = walking && kk == kcap0 && steps < MAX_DDA_STEPS;      // a full chunk: the walk goes on (or ends with an empty one)
+    DBG_T(1)
+    // -- occupancy of the recorded voxels: lane c of the quad takes entries 4 j + c; the byte loads run PD entries ahead; the
+    // lengths of the occupied steps are compacted in place (a compacted slot never lies ahead of the entry being read)
+    const int jmax = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, (kk + 3) >> 2));
+    constexpr int PD = 8;
+    uint32_t kq[PD];
+    float dq[PD];
+    uint8_t bq[PD];
+#pragma unroll
+    for (int s = 0; s < PD; s++) {
+      const int k = 4 * s + c;
+      const bool act = k < kk;
+      kq[s] = krow[act ? k : 0];
+      dq[s] = drow[act ? k : 0];
+      bq[s] = o.bytes[act ? key_to_vox(kq[s]) : 0];
+    }
+    int nocc = 0;
+    for (int j0 = 0; j0 < jmax; j0 += PD) {
+#pragma unroll
+      for (int s = 0; s < PD; s++) {
+        const int k = 4 * (j0 + s) + c;
+        const bool act = k < kk;
+        const uint32_t f = (act && bq[s]) ? 1u : 0u;
+        const uint32_t f0 = qb<0>(f), f1 = qb<1>(f), f2 = qb<2>(f), f3 = qb<3>(f);
+        const int pre = (c > 0 ? f0 : 0u) + (c > 1 ? f1 : 0u) + (c > 2 ? f2 : 0u);
+        if (act) krow[k] = kq[s] | (f ? KEY_OCC : 0u);
+        if (f) drow[nocc + pre] = dq[s];
+        nocc += (int)(f0 + f1 + f2 + f3);
+        // refill the slot with the entry PD groups ahead
+        const int k2 = k + 4 * PD;
+        const bool act2 = k2 < kk;
+        kq[s] = krow[act2 ? k2 : 0];
+        dq[s] = drow[act2 ? k2 : 0];     // (k2 > every slot written so far: nocc + pre <= k)
+        bq[s] = o.bytes[act2 ? key_to_vox(kq[s]) : 0];
+      }
+    }
+    // -- the occupied lengths, added in step order (x + 0 = x: the padding of the last group adds nothing)
+    const int imax = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, (nocc + 3) >> 2));
+    for (int i = 0; i < imax; i++) {
+      const int e = 4 * i + c;
+      const float v = e < nocc ? drow[e] : 0.f;
+      occupied += qbf<0>(v);
+      occupied += qbf<1>(v);
+      occupied += qbf<2>(v);
+      occupied += qbf<3>(v);
+    }
+    if (kk > 0) last_key = krow[kk - 1];
+    DBG_T(2)
+    if (!__any(walking)) break;
+    if (walking) cached = false;          // the record no longer starts at the ray's first step
+  }
+  // only the LAST step of a walk can end beyond the exit (the walk stops there): the reference's clip of an occupied step
+  if (steps > 0 && (last_key & KEY_OCC) && (t - DDA_EPS) > t_exit) occupied -= (t - DDA_EPS) - t_exit;
+  const int krec = cached ? kk : 0;       // valid entries of the record for the second march
+
+  int to_create = (int)(occupied / min_dist);
+  to_create = clampi(to_create, 0, max_per_ray);
+  const float spacing = occupied / to_create;
+  int created = 0;
+  // ---- second march: sample placement
+  if (__any(to_create > 1)) {
+    bool alive = to_create > 1;
+    t = t_start;
+    steps = 0;
+    // the ray's jitter numbers: entry i = the i-th next_float() of the ray's stream.  Lane c of the quad makes entries 4 j + c
+    // with the generator stepped four at a time (state' = M^4 state + (M^3 + M^2 + M + 1) inc); the second march then
+    // reads instead of running the 64-bit generator on its dependent chain.  As many as the first walk took steps (+ 8): an
+    // empty step of the second march leaves a voxel as well; a ray that needs more computes them by jumping ahead (exact).
+    uint64_t base_state = 0;
+    int npre = 0;
+    if (jitter) {
+      rng.advance((uint64_t)(int64_t)ray);
+      base_state = rng.state;
+      const uint64_t M = PSDF_PCG_MULT, M2 = M * M, M3 = M2 * M, M4 = M2 * M2, P4 = (M3 + M2 + M + 1ull) * rng.inc;
+      uint64_t st = base_state;
+      if (c > 0) st = st * M + rng.inc;
+      if (c > 1) st = st * M + rng.inc;
+      if (c > 2) st = st * M + rng.inc;
+      npre = (cached && krec + 8 < QCAP) ? krec + 8 : QCAP;     // (a walk longer than the record: all of them)
+      const int gmax = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, (npre + 3) >> 2));
+      for (int j = 0; j < gmax; j++) {
+        const int e = 4 * j + c;
+        if (e < QCAP) rrow[e] = pcg_float_of(st);
+        st = st * M4 + P4;
+      }
+      npre = (npre + 3) & ~3;
+      npre = npre < QCAP ? npre : QCAP;
+    }
+    auto jitter_at = [&](int i) -> float {           // the i-th number of the ray's stream
+      if (i < npre) return rrow[i];
+      Pcg r2{base_state, rng.inc};
+      r2.advance((uint64_t)i);
+      return r2.next_float();
+    };
+    int ri = 0;
+    if (jitter && alive) {
+      t = t + spacing * jitter_at(0);
+      ri = 1;
+    }
+    float r_cur = jitter ? jitter_at(ri) : 0.f;
+    int ptr = 0;
+    uint32_t win = krow[c];                 // window: entry ptr + c
+    const int lim = krec - c;                     // entry ptr + c of the window is a recorded one <=> ptr < lim
+    const uint32_t cval = 8u | (uint32_t)c;       // "a match, in lane c"
+    if (!jitter) r_cur = 0.f;                     // dist + spacing * 0 = dist
+    // steps <= iterations: the reference's bound on the steps of a ray cannot bind before the wave has made that many iterations;
+    // a wave that gets there (degenerate rays) hands its unfinished rays to march_ray
+    int iter = 0;
+    bool overrun = false;
+    while (true) {
+      const bool al = alive && (t < t_exit);
+      const float tc = fmaxf(t_start, fminf(t, t_exit));
+      const float pos = a.org + tc * a.dir;
+      const uint32_t key = quad_key(a, g, pos, umax);
+      const float dist = quad_dist(a, g, pos);
+      const bool al2 = al && ((key & hi) == 0u);
+      // occupancy of the voxel: from the record where it is in the window (entries ptr .. ptr + 3, one per lane; consecutive
+      // entries are different voxels, so one lane matches -- should an entry repeat, the lanes' indices OR to a later one and
+      // the following lookups go through the rare path below: slower, the same answers)
+      const uint32_t x = win ^ key;                                      // 0 or KEY_OCC: this entry is the voxel
+      const bool m = ((x << 1) == 0u) && (ptr < lim);
+      const uint32_t w = quad_or(m ? (cval | ((win >> 31) << 2)) : 0u);  // bit 3: found, bits 0-1: where, bit 2: occupied
+      const bool hit = w >= 8u;
+      const bool commit = al2 && hit;
+      const bool miss = al2 && !hit;                        // handled at the end of the iteration
+      const bool place = commit && (w & 4u) != 0u && created < to_create;
+      // move the window to the matching entry (a later sample may sit in the same voxel); the read is used a step later
+      ptr += commit ? (int)(w & 3u) : 0;
+      win = krow[ptr + c < QCAP ? ptr + c : QCAP - 1];
+      drow[created] = tc;                                   // the sample, should one be placed (else overwritten by the next)
+      const float delta = dist + spacing * r_cur;
+      const float s1 = tc + (place ? spacing : delta);
+      const float s2 = s1 + DDA_EPS;
+      t = commit ? (place ? s1 : s2) : t;
+      created += place ? 1 : 0;
+      ri += (commit && !place) ? 1 : 0;
+      if (jitter) r_cur = rrow[ri < QCAP ? ri : QCAP - 1];
+      alive = al2;
+      iter++;
+      if (!__any(al2)) break;
+      if (__builtin_expect(iter >= MAX_DDA_STEPS, 0)) {
+        overrun = al2;
+        break;
+      }
+      if (__builtin_expect(__any(miss || (jitter && al2 && ri >= npre)), 0)) {
+        if (miss) {
+          // not in the window: look further along the record (the walk only moves forward), at most 8 windows; a voxel the
+          // first march did not record at all is read from memory (the window stays: later probes may match again)
+          int p2 = ptr;
+          uint32_t w2 = 0u, win2 = win;
+          for (int it = 0; it < 8 && w2 < 8u; it++) {
+            p2 += 4;
+            if (p2 >= krec) break;
+            win2 = krow[p2 + c < QCAP ? p2 + c : QCAP - 1];
+            const bool mm = (((win2 ^ key) << 1) == 0u) && (p2 + c < krec);
+            w2 = quad_or(mm ? (cval | ((win2 >> 31) << 2)) : 0u);
+          }
+          bool occ;
+          if (w2 >= 8u) {
+            ptr = p2 + (int)(w2 & 3u);
+            win = krow[ptr + c < QCAP ? ptr + c : QCAP - 1];
+            occ = (w2 & 4u) != 0u;
+          } else {
+            occ = probe(o, cm, key_to_vox(key));
+          }
+          // the step itself, as above
+          const bool pl = occ && created < to_create;
+          const float s1b = tc + (pl ? spacing : delta);
+          t = pl ? s1b : s1b + DDA_EPS;
+          created += pl ? 1 : 0;
+          ri += pl ? 0 : 1;
+          if (jitter) r_cur = rrow[ri < QCAP ? ri : QCAP - 1];
+        }
+        if (jitter && al2 && ri >= npre) r_cur = jitter_at(ri);
+      }
+    }
+    umax = overrun ? 0xffffffffu : umax;          // (hand the ray to march_ray)
+    if (created <= 2) created = 0;
+  }
+  DBG_T(3)
+#if defined(PSDF_MARCH_DEBUG)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g_march_dbg[4] = steps; g_march_dbg[5] = kk; g_march_dbg[6] = created; }
+#endif
+  const bool bail = quad_or(umax) >= 1024u;
+  if (!bail && valid) {
+    float* __restrict__ zrow = ztemp + (int64_t)ray * max_per_ray;
+    for (int i = c; i < created; i += 4) zrow[i] = drow[i];
+    if (c == 0) {
+      counts[ray] = created;
+      spacings[ray] = spacing;
+    }
+  }
+  if (__builtin_expect(__any(bail), 0)) {     // coordinates beyond 1023: the reference's arithmetic, one lane per ray
+    if (bail && valid && c == 0)
+      march_ray<true, GridFast>(ray, g, o, cm, origins, dirs, t_entry, t_exit_p, min_dist, max_per_ray, rng0, jitter, counts,
+                                spacings, ztemp);
+  }
 }
 
 // Pass 3 (wave per ray): samples from the stored distances, at the ray's exact offset.
@@ -1043,6 +1399,7 @@ inline unsigned wave_ray_grid(int nr_rays) {
   return b < 16384u ? (b ? b : 1u) : 16384u;
 }
 
+int g_march_form = 0;
 }  // namespace
 
 // ================================================================================== C ABI
@@ -1107,6 +1464,12 @@ int psdf_occupancy_coarse_mask(int nr_voxels_per_dim, const uint8_t* grid_occupa
   return PSDF_OK;
 }
 
+// 1 = the last psdf_march_samples ran march_kernel (a thread per ray), 2 = march_quad_kernel (four lanes per ray); debug query
+int psdf_march_form(void) { return g_march_form; }
+#if defined(PSDF_MARCH_DEBUG)
+int psdf_march_debug(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_march_dbg), 16 * 8); }
+#endif
+
 // use_grid=1: OccupancyGrid::compute_samples_in_occupied_regions; use_grid=0: RaySampler::compute_samples_fg.
 // scratch: nr_rays * (3 + max_nr_samples_per_ray) 4-byte words.  cur_nr_samples (device int) receives the exact total.
 int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float extent, const float* grid_translation,
@@ -1129,7 +1492,18 @@ int psdf_march_samples(int use_grid, int nr_rays, int nr_voxels_per_dim, float e
 #define MARCH(G_, T_, g_)                                                                                                \
   hipLaunchKernelGGL((march_kernel<G_, T_>), GRID1C(nr_rays, oc), nr_rays, g_, oc, ray_origins, ray_dirs, ray_t_entry,    \
                      ray_t_exit, min_dist_between_samples, max_nr_samples_per_ray, rng, jitter, counts, spacings, ztemp)
-  if (use_grid && grid_is_fast(g))
+  const char* form = getenv("PSDF_MARCH_FORM");
+  const bool quad = use_grid && grid_is_fast(g) && nr_voxels_per_dim <= 1024 && max_nr_samples_per_ray <= QCAP &&
+                    (form ? form[0] == 'q' : nr_rays <= MARCH_QUAD_MAX_RAYS);
+  g_march_form = quad ? 2 : 1;
+  if (quad) {
+    const size_t lds = (size_t)(3 * QRAYS * QSTRIDE + (oc.coarse ? oc.words : 0)) * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)march_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(march_quad_kernel, dim3((nr_rays + QRAYS - 1) / QRAYS), dim3(64), lds, st, nr_rays, mk_fast(g), oc,
+                       ray_origins, ray_dirs, ray_t_entry, ray_t_exit, min_dist_between_samples, max_nr_samples_per_ray, rng,
+                       jitter, counts, spacings, ztemp);
+  } else if (use_grid && grid_is_fast(g))
     MARCH(true, GridFast, mk_fast(g));
   else if (use_grid)
     MARCH(true, Grid, g);

@@ -184,13 +184,26 @@ def compare_packed(rs, ref, exact=True):
     return c
 
 
+def _march_form():
+    import ctypes
+    from permuto_sdf_amd import _lib as L
+    fn = L.lib().psdf_march_form
+    fn.restype = ctypes.c_int
+    return int(fn())
+
+
+@pytest.mark.parametrize("form", ["thread", "quad"])
 @pytest.mark.parametrize("jitter", [False, True])
-def test_compute_samples_in_occupied_regions(port, world, dev, jitter):
+def test_compute_samples_in_occupied_regions(port, world, dev, jitter, form, monkeypatch):
+    """both forms of the march (csrc/sampling.hip: a thread per ray; four lanes per ray with the recorded first walk, round 6)
+    against the oracle, bit for bit; the generic (non-unit) grid has no quad form and runs the thread kernel either way"""
     from permuto_sdf import OccupancyGrid
     w = world
+    monkeypatch.setenv("PSDF_MARCH_FORM", form)
     st = (OccupancyGrid._rng.state, OccupancyGrid._rng.inc)
     rs = w["grid"].compute_samples_in_occupied_regions(T(w["o"], dev), T(w["d"], dev), T(w["te"], dev), T(w["tx"], dev),
                                                        1e-3, 64, jitter)
+    assert _march_form() == (2 if (form == "quad" and w["gridnp"][1] == 1.0) else 1)
     ref = port.march_samples(w["o"], w["d"], w["te"], w["tx"], 1e-3, 64, 1 << 21, grid=w["gridnp"], jitter=jitter, rng=st)
     ref_c = port.compact(ref)
     assert ref_c.total() > 10000
@@ -411,3 +424,45 @@ def test_coarse_mask_words_and_marches_unchanged(world, dev):
     finally:
         occ.copy_(saved)
         OccupancyGrid.COARSE_MIN_RAYS = keep
+
+
+@pytest.mark.parametrize("n,R,per_ray,min_dist", [(256, 727, 64, 1e-4), (256, 20000, 64, 1e-4), (512, 3000, 128, 1e-4),
+                                                   (128, 5000, 32, 5e-3), (1024, 600, 64, 1e-4)])
+@pytest.mark.parametrize("jitter", [False, True])
+def test_quad_march_equals_thread_march(dev, n, R, per_ray, min_dist, jitter, monkeypatch):
+    """march_quad_kernel == march_kernel (which the tests above hold against the oracle), bit for bit, where the quad form's
+    special cases live: a training step's ray count; more rays than one round of workgroups; n = 512 and 1024, where a walk is
+    longer than the 512-step record (several chunks, the second march then probes memory); a coarse grid with few long steps;
+    rays that START outside the grid (coordinates beyond it: the walk ends at once) and axis-parallel directions (a zero
+    component: safe_inverse)."""
+    from permuto_sdf import OccupancyGrid, Sphere
+    g = torch.Generator().manual_seed(n + R)
+    grid = OccupancyGrid(n, 1.0, [0, 0, 0])
+    pts = grid.compute_grid_points(False)
+    r = pts.norm(dim=1)
+    occ = ((r - 0.3).abs() < 0.03) | ((r - 0.12).abs() < 0.01) | (torch.rand(pts.shape[0], generator=g).to(dev) < 0.002)
+    grid.set_grid_occupancy(occ.contiguous())
+    o = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=1) * 1.5
+    d = torch.nn.functional.normalize((torch.rand(R, 3, generator=g) - 0.5) * 0.7 - o, dim=1)
+    d[:8] = torch.tensor([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, -1.0]]).repeat(2, 1)   # axis-parallel
+    o[:8] = -1.5 * d[:8] + torch.tensor([0.013, -0.021, 0.007]) * (1 - d[:8].abs())
+    o, d = o.to(dev).contiguous(), d.to(dev).contiguous()
+    _, te, _, tx, _ = Sphere(0.5, [0, 0, 0]).ray_intersection(o, d)
+    te[8:16] = -3.0                   # these rays start far outside the grid: the walk must end at its first step
+    out = {}
+    for form in ("thread", "quad"):
+        monkeypatch.setenv("PSDF_MARCH_FORM", form)
+        st = (OccupancyGrid._rng.state, OccupancyGrid._rng.inc)
+        rs = grid.compute_samples_in_occupied_regions(o, d, te, tx, min_dist, per_ray, jitter)
+        assert _march_form() == (2 if form == "quad" else 1)
+        OccupancyGrid._rng.state, OccupancyGrid._rng.inc = st          # the same jitter stream for both
+        c = rs.compact_to_valid_samples()
+        out[form] = [t.clone() for t in (c.ray_start_end_idx, c.samples_z, c.samples_pos, c.samples_dt, c.ray_fixed_dt,
+                                         c.samples_dirs)]
+    assert out["thread"][1].shape[0] > 3 * R
+    for a, b in zip(out["thread"], out["quad"]):
+        assert a.shape == b.shape
+        if a.dtype == torch.float32:      # bit patterns (NaN spacing of rays without samples included)
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        else:
+            assert torch.equal(a, b)
