@@ -554,7 +554,7 @@ def main():
                 else:
                     r = tb.measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=start)
                 rows["start_iter_%d" % start] = {k: r[k] for k in ("value", "unit", "ms_per_step", "fg_samples_per_step_per_gpu",
-                                                                    "rays_last_step", "steps", "warmup", "repeats_it_per_s", "backward")}
+                                                                    "rays_last_step", "steps", "warmup", "repeats_it_per_s", "backward", "dp") if k in r}
             extra["train_iters_per_s"] = {
                 "metric": "train iters/sec (cfg 4: train_permuto_sdf.py's full SDF + colour + background step -- occupancy sampling, "
                           "2 rounds of importance sampling, eikonal + curvature + off-surface losses, AdamW, grid refresh every 8th "

@@ -124,10 +124,11 @@ class Loopback:
     data), and `wait()` makes the caller's current stream wait for it.  The 'sum over `world` ranks' of identical replicas is
     t * world.  Activate with `parallel.set_loopback(Loopback(world=2))`; world_size() then reports `world`."""
 
-    def __init__(self, world=2, delay_cycles=2_000_000):
+    def __init__(self, world=2, delay_cycles=2_000_000, serialize=False):
         self.world, self.delay = int(world), int(delay_cycles)
         self.stream = torch.cuda.Stream()
         self.launched = []      # (kind, numel) log for the tests
+        self.serialize = bool(serialize)    # every collective is waited for at once: the race-free reference schedule
 
     class _Work:
         def __init__(self, ev):
@@ -144,6 +145,26 @@ class Loopback:
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.launched.append((kind, numel))
+        if self.serialize:
+            torch.cuda.current_stream().wait_event(ev)
+        return Loopback._Work(ev)
+
+    def gather_params(self, flat):
+        """the parameter all-gather of the sharded update: identical virtual replicas already hold every owner's bytes, so the
+        result is `flat` itself -- but WHILE the collective runs the buffer holds NaN (a real all-gather overwrites the ranges of
+        the other owners while it runs): a reader that did not wait sees them"""
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            keep = flat.clone()
+            flat.fill_(float("nan"))
+            torch.cuda._sleep(self.delay)
+            flat.copy_(keep)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        keep.record_stream(self.stream)
+        self.launched.append(("all_gather_params", flat.numel()))
+        if self.serialize:
+            torch.cuda.current_stream().wait_event(ev)
         return Loopback._Work(ev)
 
     def all_reduce(self, t, op="sum"):
@@ -418,7 +439,10 @@ class ShardedUpdate:
 
     def all_gather(self, flat, own):
         """every rank's [own) range of `flat` (same bounds rule on every rank) -> all of `flat`, in place"""
-        if not collectives_active() or _loopback is not None:
+        if not collectives_active():
+            return
+        if _loopback is not None:
+            self.works.append(_loopback.gather_params(flat))
             return
         lo, hi = own
         if dist.get_backend() == "nccl":

@@ -185,6 +185,7 @@ class ManualTrainer(Trainer):
         """4-D lattice -> density + feature net -> [gelu(features), SH4(dir)] -> colour head -> (calibrated) sigmoid.  Everything
         the compositing and the backward need, as a dict."""
         bgn = self.bg
+        self._params_ready(2)              # the background lattice's parameters (all-gather of the previous step, data parallel)
         M = bg.samples_pos_4d.shape[0]
         p4, dirs_b = bg.samples_pos_4d, bg.samples_dirs
         feat4 = _enc_fwd(bgn.encoding, p4, bgn._win)
@@ -285,6 +286,7 @@ class ManualTrainer(Trainer):
             fg, bg = self._samples(o, d, it, True, begun=begun, between=None if side is not None else
                                    (lambda bg_: early_bg.__setitem__("B", self._bg_forward(bg_, calib))))
             n_fg = fg.samples_pos.shape[0]
+            self._params_ready(0)          # the SDF lattice's parameters (all-gather of the previous step, data parallel)
             sdfn, rgbn = self.sdf, self.rgb
             gb = self.grad_buffers[0]
             lin = list(sdfn.mlp_sdf.layers)
@@ -310,6 +312,7 @@ class ManualTrainer(Trainer):
                 y = mlp_forward_raw(dims_s, feat, packed_s)                                   # [33, N]: sdf, geometry features
                 n, dfeat, e0 = self._sdf_gradient(feat, pts, win, ws, bs)
                 # colour network
+                self._params_ready(1)
                 feat2 = _enc_fwd(rgbn.encoding, pts, rgbn._win)
                 sh = PermutoSDF.spherical_harmonics(dirs, 5)
                 nn = _normalize3(n)
@@ -343,6 +346,8 @@ class ManualTrainer(Trainer):
             fork(self._events[2])
             with side_ctx():
                 g_cw_bg, g_cb_bg = self._bg_backward(B, g_raw, g_rgbb, calib, R)
+            if side is None:
+                self._dp_lattice_final(2)      # the background lattice's gradient is final: its reduction overlaps what follows
             g_n = None
             curv = None
             if n_fg:
@@ -389,6 +394,7 @@ class ManualTrainer(Trainer):
                 for i, (w, c) in enumerate(zip(m.weights_per_layer, m.lipshitz_bound_per_layer)):
                     w.grad, c.grad, m.biases_per_layer[i].grad = dws[i], dcs[i].view_as(c), dbr[i]
                 _enc_bwd(rgbn.encoding, pts, rgbn._win, dXr[:c_enc])
+                self._dp_lattice_final(1)      # the colour lattice's gradient is final
                 g_n = g_n + g_nc + _normalize3(n, dXr[c_sh:c_sh + 3].t().contiguous())
                 g_y = torch.cat([g_sdf.view(1, -1), dXr[c_sh + 3:]], 0)                           # [33, N]
                 if curv is not None:
@@ -402,6 +408,8 @@ class ManualTrainer(Trainer):
                 # first evaluation: from (sdf, geom) directly and from n through the double backward; ONE lattice scatter
                 dX1, _, _ = mlp_backward_raw(dims_s, feat, ws, bs, g_y, need_dx=True, into=(gb.dWs, gb.dbs))
                 self._sdf_gradient_backward(g_n, feat, dfeat, e0, pts, win, ws, bs, gb, extra_dfeat=dX1)
+            else:
+                self._dp_lattice_final(1)      # (no foreground samples on this rank: the same collective at the same point)
             # ---- off-surface points
             dXo, _, _ = mlp_backward_raw(dims_s, feat_o, ws, bs, self._g_yo, need_dx=True, into=(gb.dWs, gb.dbs))
             _enc_bwd(sdfn.encoding, off, win, dXo)

@@ -31,6 +31,8 @@ offline): `SyntheticReel` has the TensorReel fields `random_rays_from_reel` read
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -401,6 +403,13 @@ class Trainer:
         self.iter = 0
         self.capture_grads = None     # set to {} to have step() record the gradients it hands to the optimiser
         self.shard_optimizer = parallel.sharded_optimizer_default()   # data parallel: lattices updated by their owners only
+        # data-parallel schedule of a step (round 6): a lattice's gradient leaves (reduce-scatter) as soon as its last backward
+        # kernel is enqueued (_dp_lattice_final: background -> colour -> SDF in the hand-written step), the parameters come back
+        # (all-gather) in the order the NEXT step reads them and are only waited for where it does (_params_ready)
+        self._dp_started = {}         # lattice index -> (ShardedUpdate | None, own range | None) of the running step
+        self._dp_buckets = None
+        self._pending_gather = {}     # lattice index -> ShardedUpdate whose all-gather of the parameters is in flight
+        self.defer_param_gather = os.environ.get("PSDF_DP_DEFER_GATHER", "1") == "1"
         self._pinned_counts = None    # host landing zones of the march's per-ray counts (one asynchronous copy per step)
         self._pinned_flip = 0
         self._colour_window_t = 1.0   # the t the colour / background lattices' windows (`_win`, ones) currently hold
@@ -544,12 +553,46 @@ class Trainer:
         dists = pts.norm(dim=-1, keepdim=True) - 0.3
         return ((sdf - dists) ** 2).mean() * 3e3 + eikonal_loss(grad) * 5e1
 
+    # ------------------------------------------------------------------ data parallel: early reduction, late gather
+    def _dp_lattice_final(self, k):
+        """The gradient buffer of lattice k (0 SDF, 1 colour, 2 background) is final for this step: start its reduction NOW, on
+        the collective's stream, while the rest of the backward is still being enqueued.  Idempotent; step() calls it for
+        whatever was not started earlier.  Also ORs the touched-block byte map over the ranks (a block touched on ANY rank
+        carries gradient after the sum)."""
+        if k in self._dp_started or not parallel.collectives_active() or not self.touched:
+            return
+        tr = self.touched[k]
+        su = parallel.ShardedUpdate()
+        own = su.reduce_scatter(tr.grad.view(-1), unit=tr.block_elems) if self.shard_optimizer else None
+        if own is None:
+            if self._dp_buckets is None:
+                self._dp_buckets = parallel.GradientBuckets()
+            self._dp_buckets.reduce([tr.grad])       # one bucket per lattice: the ring is per-link bound, fewer larger messages
+            su = None
+        parallel.all_reduce_max_(tr.touched)
+        self._dp_started[k] = (su, own)
+
+    def _params_ready(self, k=None):
+        """make the current stream wait for the all-gather of lattice k's parameters (all of them: k = None) that the previous
+        step left in flight; no-op when nothing is pending.  Everything that READS lattice parameters calls this first."""
+        if not self._pending_gather:
+            return
+        for key in ([k] if k is not None else list(self._pending_gather)):
+            su = self._pending_gather.pop(key, None)
+            if su is not None:
+                su.wait()
+
+    def sync_parameters(self):
+        """public form of _params_ready(): call before reading parameters from outside a step (checkpoints, comparisons)"""
+        self._params_ready()
+
     def _refresh_and_adapt(self, it, git, n_fg):
         """occupancy refresh every 8th step, BEFORE this iteration's backward / optimiser step as in the reference
         (train_permuto_sdf.py:383-391), from the same random voxels on every rank; adaptive ray count (:393-397)"""
         hp = self.hp
         with torch.no_grad():
             if git % 8 == 0:
+                self._params_ready()            # (the refresh evaluates the SDF)
                 parallel.seed_generators(977 + git, self.dev)
                 centres, idx = self.grid.compute_random_sample_of_grid_points(256 * 256 * 4, True)
                 inv_s = self.rgb.last_inv_s if self.rgb.last_inv_s is not None else torch.tensor(20.0, device=self.dev)
@@ -567,6 +610,7 @@ class Trainer:
         """forward + losses of one iteration of the main phase as an autograd graph -> (loss, n_fg, nr_rays, False): the caller
         runs loss.backward().  train_manual.ManualTrainer overrides this with a hand-written backward over the raw kernels."""
         hp = self.hp
+        self._params_ready()
         cos_anneal_ratio = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.0, 1.0)
         forced_variance = map_range_val(it, 0.0, hp.forced_variance_finish_iter, 0.3, hp.forced_variance_finish)
         o, d, gt, hit, img_idx, gt_mask = self._draw_rays(reel)
@@ -612,6 +656,7 @@ class Trainer:
             p.grad = None
         grads_done = False
         if in_sphere_init:
+            self._params_ready()
             loss = self._sphere_init_loss(it)
         else:
             # rgb_nr_iters_for_c2f = background_nr_iters_for_c2f = 1 (train_permuto_sdf.py:102-103; models.py:368,496): the colour and
@@ -647,8 +692,10 @@ class Trainer:
                 tr.grad.add_(p.grad)
                 p.grad = None
         owned = None
-        if parallel.world_size() > 1:
-            buckets = parallel.GradientBuckets()
+        dp = parallel.collectives_active()
+        if dp:
+            buckets = self._dp_buckets if self._dp_buckets is not None else parallel.GradientBuckets()
+            self._dp_buckets = None
             small = [g for g in grads if g.numel() < (1 << 20)]
             big = [g for g in grads if g.numel() >= (1 << 20)]
             buckets.reduce(small)
@@ -656,27 +703,42 @@ class Trainer:
                 buckets.reduce([g])
             # the lattices (50 MB each): reduce-scatter IN PLACE, the owner updates its 1/world of the table, the ranks all-gather
             # the PARAMETERS (parallel.ShardedUpdate); PSDF_DP_OPTIMIZER=replicated (or a table that cannot be cut evenly):
-            # reduce-scatter + all-gather of the gradient, every rank updates everything
-            su = parallel.ShardedUpdate()
-            owned, mine = {}, {}
-            for m, tr in zip((self.sdf, self.rgb, self.bg), self.touched):
+            # reduce-scatter + all-gather of the gradient, every rank updates everything.  Lattices whose gradient was final
+            # earlier in the backward are already on their way (_dp_lattice_final).
+            for k in range(len(self.touched)):
+                self._dp_lattice_final(k)
+            owned, mine, sus, sbytes = {}, {}, {}, []
+            for k, (m, tr) in enumerate(zip((self.sdf, self.rgb, self.bg), self.touched)):
+                su, own = self._dp_started[k]
+                if su is None:
+                    continue
                 p = m.encoding.lattice_values
-                own = su.reduce_scatter(tr.grad.view(-1), unit=tr.block_elems) if self.shard_optimizer else None
-                if own is None:
-                    buckets.reduce([tr.grad])     # one bucket per lattice: the ring is per-link bound, fewer larger messages
-                else:
-                    mine[p] = own
-                    owned[p] = [parallel.shard_bounds(p.numel(), tr.block_elems, rank_=r) for r in su.virtual_ranks()]
-            for tr in self.touched:  # a block touched on ANY rank carries a gradient after the sum: OR of the byte maps
-                parallel.all_reduce_max_(tr.touched)
+                mine[k] = (p, own)
+                sus[k] = su
+                owned[p] = [parallel.shard_bounds(p.numel(), tr.block_elems, rank_=r) for r in su.virtual_ranks()]
             buckets.finish()
-            su.wait()
-        self.opt.step(grad_scale=1.0 / parallel.world_size(), owned=owned)
+            for su in sus.values():
+                su.wait()
+                sbytes += list(su.bytes)
+            self._dp_started = {}
+            if self.capture_grads is not None:      # tests: the lattice gradients AFTER the sum over the ranks
+                self.capture_grads["lattices_reduced"] = [tr.grad.clone() for tr in self.touched]
+        self.opt.step(grad_scale=1.0 / parallel.world_size(), owned=owned or None)
         if owned:
-            for p, own in mine.items():
-                su.all_gather(p.data.view(-1), own)
-            su.wait()
-            self.last_dp = {"optimizer": "sharded", "sharded_bytes": list(su.bytes), "bucket_bytes": list(buckets.bytes)}
+            # the owners' bytes to everybody, in the order the next step reads the tables (background first: its forward is
+            # enqueued during the march; then the SDF lattice; the colour lattice last); waited for where they are read
+            for k in sorted(mine, key=lambda kk: {2: 0, 0: 1, 1: 2}.get(kk, 3)):
+                p, own = mine[k]
+                g = parallel.ShardedUpdate()
+                g.all_gather(p.data.view(-1), own)
+                self._pending_gather[k] = g
+            if not self.defer_param_gather:
+                self._params_ready()
+            gather_bytes = [p.numel() * 4 for p, _ in mine.values()]
+            self.last_dp = {"optimizer": "sharded", "sharded_bytes": sbytes, "bucket_bytes": list(buckets.bytes),
+                            "gather_bytes": gather_bytes, "deferred_gather": bool(self.defer_param_gather)}
+        elif dp:
+            self.last_dp = {"optimizer": "replicated", "bucket_bytes": list(buckets.bytes)}
         for gb in self.grad_buffers:
             gb.zero()
         self.iter += 1

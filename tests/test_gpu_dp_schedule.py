@@ -1,0 +1,72 @@
+"""GPU: the data-parallel SCHEDULE of the cfg-4 training step (round 6) under an asynchronous collective backend.
+
+`Trainer.step` / `ManualTrainer` start a lattice's reduce-scatter as soon as its last backward kernel is enqueued
+(`_dp_lattice_final`: background, colour, then the SDF lattice at the end of the backward) and leave the all-gather of the updated
+PARAMETERS in flight when the step returns; the next step waits for each table where it first reads it (`_params_ready`).  Two
+ranks of RCCL cannot share this box's one GPU, so the asynchronous backend is `parallel.Loopback`: every collective runs on a side
+stream behind a device sleep, and the parameter all-gather holds NaN in the table while it runs -- a reader that forgot to wait
+computes NaN, a reduction that started before its gradient was final sums stale data.  The reference is the SAME run with every
+collective waited for at once (`serialize=True`): race-free by construction.  (The arithmetic of the sum over real ranks:
+tests/test_dp_gloo.py; the real RCCL calls on one rank: tests/test_gpu_rccl_single_rank.py.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(dev, steps, serialize, defer, start_iter):
+    from permuto_sdf_amd import parallel
+    from permuto_sdf_amd.train_manual import ManualTrainer
+    from permuto_sdf_amd.train_step import SyntheticReel
+    from permuto_sdf_amd import bridge
+    for cls in (bridge.OccupancyGrid, bridge.RaySampler, bridge.VolumeRendering):     # the process-global jitter streams
+        cls._rng = bridge.Pcg32()
+    lb = parallel.Loopback(world=2, delay_cycles=3_000_000, serialize=serialize)
+    prev = parallel.set_loopback(lb)
+    try:
+        torch.manual_seed(0)
+        tr = ManualTrainer(dev)
+        tr.defer_param_gather = defer
+        reel = SyntheticReel(dev)
+        tr.iter = start_iter
+        losses, first = [], None
+        for i in range(steps):
+            tr.capture_grads = {} if i == 0 else None
+            losses.append(tr.step(reel))
+            if i == 0:
+                first = [g.clone() for g in tr.capture_grads["lattices_reduced"]]
+        assert tr.last_dp and tr.last_dp["optimizer"] == "sharded" and tr.last_dp["deferred_gather"] == defer
+        if defer:
+            assert tr._pending_gather, "the parameter all-gather should still be in flight when step() returns"
+        tr.sync_parameters()
+        torch.cuda.synchronize()
+        kinds = [k for k, _ in lb.launched]
+        return first, [p.detach().clone() for p in tr.params], torch.stack(losses).cpu(), kinds
+    finally:
+        parallel.set_loopback(prev)
+
+
+@pytest.mark.parametrize("start_iter", [7, 20007])
+def test_early_reduce_and_deferred_gather_equal_the_serialised_schedule(dev, start_iter):
+    """start_iter 7 / 20007: the second step refreshes the occupancy grid (every 8th iteration reads the SDF lattice outside the
+    main phase) while the first step's parameter all-gather is still in flight.  Parameters are not compared entry by entry: Adam
+    turns the last-bit noise of the lattice scatter's float atomics into +- lr on entries whose gradient is ~0 (two SERIALISED
+    runs differ by O(1) relative in the worst entry); what is compared is what the schedule can break -- the reduced gradients of
+    the first step (same state in both runs), finite values everywhere (the gather holds NaN while it runs) and the losses."""
+    steps = 4
+    g_ref, p_ref, loss_ref, _ = _run(dev, steps, serialize=True, defer=False, start_iter=start_iter)
+    g_ref2, _, loss_ref2, _ = _run(dev, steps, serialize=True, defer=False, start_iter=start_iter)
+    g_got, p_got, loss_got, kinds = _run(dev, steps, serialize=False, defer=True, start_iter=start_iter)
+    assert bool(torch.isfinite(loss_got).all()), loss_got
+    assert all(bool(torch.isfinite(p).all()) for p in p_got)
+    # three lattices per step: a reduction each and an all-gather of the parameters each
+    assert kinds.count("all_gather_params") == 3 * steps and kinds.count("all_reduce") >= 3 * steps
+    for k, (a, a2, b) in enumerate(zip(g_ref, g_ref2, g_got)):
+        scale = float(a.abs().max())
+        noise = float((a - a2).abs().max())
+        err = float((a - b).abs().max())
+        print("lattice %d: reduced gradient, async vs serialised %.2e, serialised vs itself %.2e (of a largest entry %.2e)" % (k, err, noise, scale))
+        assert scale > 0 and err <= max(3.0 * noise, 1e-5 * scale), (k, err, noise, scale)
+    noise = float((loss_ref - loss_ref2).abs().max())
+    print("losses", loss_ref.tolist(), loss_got.tolist(), "noise", noise)
+    assert float((loss_ref - loss_got).abs().max()) <= max(5.0 * noise, 1e-3 * float(loss_ref.abs().max()))

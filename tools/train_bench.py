@@ -49,6 +49,34 @@ def measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=0):
             torch.distributed.all_reduce(e, op=torch.distributed.ReduceOp.MAX)
         reps.append(float(e.item()))
     el = sorted(reps)[len(reps) // 2]
+    tr.sync_parameters()     # (data parallel: the last step's parameter all-gather may still be in flight)
+    dp = None
+    if parallel.collectives_active() and getattr(tr, "last_dp", None):
+        # what a step exchanges per GPU, and the analytic budget of an 8-GPU node (no such node has run this code: a model, not a
+        # measurement).  xGMI: 7 point-to-point links per GPU, ~76.8 GB/s per link and direction (153.6 GB/s bidirectional);
+        # reduce-scatter and all-gather of B bytes each move (w-1)/w * B per GPU and direction over all links at once.
+        ld = tr.last_dp
+        rs_b = sum(ld.get("sharded_bytes", [])) + sum(ld.get("bucket_bytes", []))
+        ag_b = sum(ld.get("gather_bytes", []))
+        w8 = 8
+        peak = 7 * 76.8e9
+        eff = 0.6 * peak                       # what RCCL typically sustains of the link peak at these message sizes (assumption)
+        t_rs = (w8 - 1) / w8 * rs_b / eff * 1e3
+        t_ag = (w8 - 1) / w8 * ag_b / eff * 1e3
+        per_lat_rs, per_lat_ag = t_rs / 3.0, t_ag / 3.0
+        # hidden by the schedule: the background and colour lattices' reduce-scatter (their gradients are final ~1.0 / ~0.5 ms before
+        # the end of the backward), the colour lattice's all-gather (read ~0.3 ms into the next step) and ~0.15 ms of the others
+        # behind the next step's ray draw + march
+        exposed = max(0.0, per_lat_rs) + max(0.0, 2 * per_lat_ag - 0.15)
+        dp = {"comm_bytes_per_step_per_gpu": {"reduce_scatter_gradients": rs_b, "all_gather_parameters": ag_b},
+              "schedule": "reduce-scatter of a lattice's gradient starts when its last backward kernel is enqueued (background, colour, "
+                          "then SDF at the end of the backward); sharded AdamW on the owned 1/world; all-gather of the PARAMETERS in "
+                          "the order the next step reads them (background, SDF, colour), each waited for where it is first read",
+              "deferred_gather": ld.get("deferred_gather"), "optimizer": ld.get("optimizer"),
+              "analytic_8gpu_budget_ms": {"model": "7 xGMI links x 76.8 GB/s per direction, 60 % sustained (assumption, not measured)",
+                                          "reduce_scatter_total": round(t_rs, 3), "all_gather_total": round(t_ag, 3),
+                                          "exposed_after_overlap": round(exposed, 3),
+                                          "budget_for_6x_of_8": round(el / steps * 1e3 * (8 / 6 - 1), 3)}}
     if world > 1:   # replicas must have stayed identical: same parameters on every rank after the run
         chk = torch.stack([p.detach().double().sum() for p in tr.params]).to(dev)
         lo, hi = chk.clone(), chk.clone()
@@ -61,7 +89,7 @@ def measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=0):
             "fg_samples_per_step_per_gpu": samples / steps, "rays_last_step": tr.last["nr_rays"],
             "scaling": "weak", "dtype": "f32", "data": "synthetic", "start_iter": start_iter,
             "backward": "hand-written (train_manual.py)" if manual else "torch autograd over the fused operators",
-            "repeats_it_per_s": [round(steps / r, 1) for r in reps]}
+            "repeats_it_per_s": [round(steps / r, 1) for r in reps], "dp": dp}
 
 
 def main():
