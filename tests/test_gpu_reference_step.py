@@ -10,9 +10,12 @@ background, BCE on the weight sum).
 What the numbers mean (measured on MI355X, profiles/r04_reference_step_parity.json):
   * `*_same_samples` (the reference's foreground samples handed to our trainers): everything agrees to a few 1e-5 in every state,
     curvature term included.  Bar: 1e-4 of the largest entry for dense gradients and for each lattice, 1e-5 for the loss -- or
-    3x the reference's OWN rounding noise on those samples where that is larger (`reference_self_noise_same_samples`: the
-    reference re-run with the hidden units of its SDF MLP re-numbered and the same samples forced; in the `late` state its SDF
-    bias gradients, sums of large cancelling NeuS terms, move by 7e-5 that way, and ours sit at the same distance).
+    twice the reference's OWN rounding noise on those samples where that is larger, tensor by tensor
+    (`reference_self_noise_same_samples`: the reference re-run SIX times with the hidden units of its SDF MLP re-numbered and
+    the same samples forced, the largest deviation kept; in the `late` state its last SDF bias gradient, a sum of ~50 000
+    cancelling NeuS terms, moves by ~1e-4 that way, and ours sit at the same distance).  A float64 arbiter of that one entry
+    (`arbiter_last_sdf_bias`: the reference's own per-sample terms summed in float64) shows where the difference is NOT: the
+    fp32 summation is exact to 1e-7; it is the terms that move with the last bits of the SDF values.
   * whole step, each side drawing its own samples: the importance samples follow each side's own SDF evaluations, and the
     finest lattice levels have cells of 1e-4 -- last-bit differences of the SDF (our fused evaluator vs torch.nn) move samples
     across cells.  The reference run against ITSELF with the hidden units of its SDF MLP re-numbered (`reference_self_noise`:
@@ -75,44 +78,56 @@ def test_sphere_initialisation_step(parity):
         assert m["loss_rel"] <= 1e-5 and m["worst_dense"] <= 1e-4 and m["worst_lattice"] <= 1e-4, (n, m["loss_rel"], m["worst_dense"])
 
 
-LATE_SELF_NOISE = 7.8e-5   # reference vs its hidden-unit re-numbered self, `late` state: largest of six invocations (see below)
-
-
 @pytest.mark.parametrize("mode", ["early", "late", "mask"])
 def test_step_with_the_reference_samples(parity, mode):
-    """only the step differs (the reference's foreground samples are handed to our trainers): the north_star bar, 1e-4"""
+    """only the step differs (the reference's foreground samples are handed to our trainers): the north_star bar, 1e-4 of the
+    largest entry of every gradient -- or twice what the reference deviates from itself on the same samples (effective bar in the
+    `late` state for the SDF net's last bias: ~2.5e-4; everything else 1e-4)"""
     c = parity["cases"][mode]
     # the reference against ITSELF on the same samples, hidden units of its SDF MLP re-numbered (the same function, another fp32
     # summation order): what rounding alone does to this step's gradients.  In the `late` state (NeuS variance exp(8): every
     # gradient is a difference of large terms) that is up to ~1e-4 for the SDF net's last bias, 1e-5 elsewhere.
     noise, rep = c["reference_self_noise_same_samples"], c["reference_repeat_noise"]
-    print("  reference, hidden units re-numbered, same samples: dense %.1e  lattice max %.1e L2 %.1e   (simply run again: dense %.1e)" % (
-        noise["worst_dense"], noise["worst_lattice"], noise["worst_lattice_l2"], rep["worst_dense"]))
+    arb = c["arbiter_last_sdf_bias"]
+    print("  reference, hidden units re-numbered (six draws), same samples: dense %.1e (draws %s)  lattice max %.1e L2 %.1e   (simply "
+          "run again: dense %.1e)" % (noise["worst_dense"], " ".join("%.1e" % v for v in noise["draws_worst_dense"]),
+                                      noise["worst_lattice"], noise["worst_lattice_l2"], rep["worst_dense"]))
+    print("  float64 arbiter of %s (sum of %d per-sample terms of the reference): reference %.1e, re-numbered reference %s, ours %.1e / %.1e"
+          % (arb["tensor"], arb["terms_summed"], arb["reference_vs_f64"],
+             " ".join("%.1e" % v for v in arb["reference_renumbered_same_samples_vs_f64"]),
+             arb["manual_same_samples_vs_f64"], arb["autograd_same_samples_vs_f64"]))
     _report(c, ("manual_same_samples", "autograd_same_samples"))
+    # the arbiter's finding (round 6): torch sums the last bias's ~50 000 terms to 1e-7 of their float64 sum -- the summation is
+    # not where the sides part.  The TERMS move: re-numbering the hidden units changes the SDF values in their last bits, and
+    # through the late state's NeuS variance (inv_s = e^8) that moves the cancelling per-sample terms by ~1e-4 of their sum.
+    assert arb["reference_vs_f64"] <= 1e-5
     for n in ("manual_same_samples", "autograd_same_samples"):
         m = c[n]
         assert not m["not_in_reference"] and all("missing" not in v for v in m["grads"].values())
         assert m["nr_fg_samples"] == c["reference_terms"]["nr_fg_samples"]
         assert m["loss_rel"] <= 1e-5, (n, m["loss_rel"])
-        # north_star bar 1e-4 -- or three times the reference's own rounding noise on these samples where that is larger.
-        # ONE re-numbering is one draw of that noise: over six invocations on MI355X (round 5) the `late` state's worst dense
-        # entry -- always sdf.mlp_sdf.layers.3.bias, the plain sum of ~49 000 cancelling NeuS terms -- moved by 1.1e-5 .. 7.8e-5
-        # between the reference and its re-numbered self and sat 1.0e-5 .. 1.45e-4 from ours, the two draws independent of each
-        # other (a run with a small draw of the former and a large one of the latter failed the bar).  The `late` bar therefore
-        # uses the largest noise seen, not the draw of the run.
-        floor = LATE_SELF_NOISE if mode == "late" else 0.0
-        assert m["worst_dense"] <= max(1e-4, 3 * max(noise["worst_dense"], floor)), (n, m["worst_dense"], noise["worst_dense"])
-        assert m["worst_lattice"] <= max(1e-4, 3 * noise["worst_lattice"]), (n, m["worst_lattice"], noise["worst_lattice"])
+        # north_star bar 1e-4 of the largest entry -- or, tensor by tensor, twice the largest deviation the reference shows
+        # from ITSELF over six re-numberings on these samples (measured in this very run; no constant from another day)
+        for k, v in m["grads"].items():
+            if "max_rel" not in v:
+                continue
+            own = noise["by_tensor_max"].get(k, 0.0)
+            bar = max(1e-4, (3.0 if "lattice" in k else 2.0) * own)
+            assert v["max_rel"] <= bar, (n, k, v["max_rel"], own)
         assert m["worst_lattice_l2"] <= max(1e-4, 3 * noise["worst_lattice_l2"]), (n, m["worst_lattice_l2"])
+        # the last bias against the float64 sum of the reference's terms: no further from it than the reference's re-numbered self
+        assert arb[n + "_vs_f64"] <= max(1e-4, 2.0 * arb["reference_renumbered_same_samples_vs_f64_max"]), (n, arb)
 
 
 # whole-step bars (dense max, lattice max, lattice L2), per state: measured deviations in parentheses, over seven runs
-# `late` has NO gradient bar: measured 7e-5 .. 2.5e-2 (dense), 2e-2 .. 4.4e-1 (lattice max), 7e-3 .. 7.5e-2 (lattice L2) -- a bar
-# above that would pass a 100 % error, i.e. carry no information (review of round 4); what is asserted there is the samplers'
-# agreement and the loss, and the gradients are held by test_step_with_the_reference_samples (shared samples, <= 5e-5).
+# `late`: measured 7e-5 .. 2.5e-2 (dense), 2e-2 .. 4.4e-1 (lattice max), 7e-3 .. 7.5e-2 (lattice L2): only an O(1) sanity bar
+# makes sense there; what is asserted tightly is the samplers' agreement and the loss, and the gradients are held by
+# test_step_with_the_reference_samples (shared samples).
 WHOLE_STEP_BARS = {"early": (1e-2, 5e-2, 2e-2),      # (2e-5 .. 2e-4, 1e-5 .. 2e-3, 3e-5 .. 1.4e-3)
                    "mask": (1e-2, 5e-2, 2e-2),       # (4e-6 .. 2e-5, 2e-5, 3e-5)
-                   "late": None}
+                   # O(1) sanity bars (ADVICE r5): a wrong sign or a missing loss term moves these by ~1; the measured noise
+                   # (dense <= 2.5e-2, lattice max <= 4.4e-1, lattice L2 <= 7.5e-2) passes with room
+                   "late": (0.25, 1.0, 0.5)}
 
 
 @pytest.mark.parametrize("mode", ["early", "late", "mask"])
