@@ -81,3 +81,20 @@ def test_real_rccl_collectives_on_one_rank(dev):
         assert len(res[mode]["bucket_bytes"]) == 3            # MLP bucket + two lattice level ranges
     # rows 100..163 of level 1, blocks of 64 floats = 32 rows: three touched blocks travel, not the 32 KB table
     assert res["ragged_bucket_ok"] and res["bytes"][1] == 3 * 64 * 4
+
+
+def test_training_step_schedule_through_real_rccl_on_one_rank(dev):
+    """The cfg-4 hand-written step with its round-6 data-parallel schedule -- early reduce-scatter per lattice, sharded AdamW,
+    parameter all-gather left in flight and waited for where the next step reads each table -- through the REAL RCCL calls
+    (`reduce_scatter_tensor`, `all_gather_into_tensor`, async) on a one-rank group: the stream ordering between RCCL's stream and
+    the compute stream is the real one; tools/train_bench.py asserts finite parameters at the end."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29513",
+               PSDF_DP_FORCE_COLLECTIVES="1", PSDF_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--manual", "--steps", "12", "--warmup", "4",
+                        "--repeats", "1", "--start-iter", "20000"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(d["value"], d["dp"])
+    assert d["value"] > 0 and d["dp"] and d["dp"]["optimizer"] == "sharded" and d["dp"]["deferred_gather"] is True
+    b = d["dp"]["comm_bytes_per_step_per_gpu"]
+    assert b["all_gather_parameters"] == 3 * 24 * (1 << 18) * 2 * 4 and b["reduce_scatter_gradients"] >= b["all_gather_parameters"]

@@ -50,6 +50,8 @@ def measure(dev, manual=True, steps=60, warmup=20, repeats=3, start_iter=0):
         reps.append(float(e.item()))
     el = sorted(reps)[len(reps) // 2]
     tr.sync_parameters()     # (data parallel: the last step's parameter all-gather may still be in flight)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(p).all()) for p in tr.params), "a parameter is not finite after the run"
     dp = None
     if parallel.collectives_active() and getattr(tr, "last_dp", None):
         # what a step exchanges per GPU, and the analytic budget of an 8-GPU node (no such node has run this code: a model, not a
