@@ -159,6 +159,10 @@ int psdf_mlp_backward_split_f16_form(void);
 unsigned psdf_mlp_f16_range_events(void);
 
 /* ---- mlp_wide.hip ---- */
+/* which kernel the last psdf_mlp_backward_wide launched: 1 = fp32 MFMAs (mlp_wide_bwd_kernel), 2 = two fp16 pieces per operand on
+   the fp16 matrix pipe (mlp_wide_bwd_f16_kernel, the default since round 6; PSDF_MLP_WIDE_SPLIT=f32 selects the other, and so does a
+   value beyond the fp16 range met by an earlier launch); 0 = none yet.  Debug query (host only). */
+int psdf_mlp_backward_wide_form(void);
 /* same contract as psdf_mlp_backward for 4-layer nets wider than one wave's register file holds (dims[0] <= 112, dims[1],
    dims[2] <= 128, dims[3] <= 64, dims[4] <= 16): the colour network LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3 of
    permuto_sdf_py/models/models.py:54-129,349-350 (weights = the already normalised ones).  Workgroup-cooperative: 8 waves

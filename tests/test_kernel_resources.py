@@ -139,6 +139,10 @@ SPILLING = {
     r"mlp_dbl_bwd_kernelILi3ELi4ELi4ELi4ELi1ELb1EE": 256, r"mlp_dbl_bwd_kernelILi4ELi4ELi4ELi4ELi1ELb1EE": 320,
     # background colour head 80 -> 64x2 -> 3 with parameter gradients (models.py:463-469): every training step, one register
     r"mlp_bwd_kernelILi5ELi4ELi4ELi0ELi1ELb1ELb1ELb1ELi4E": 8,
+    # round 6, the colour network's split-fp16 backward (two waves per SIMD, 256 registers): what is parked in scratch is written in
+    # the prologue and read in the epilogue (addresses of the gradient image) -- the tile loop itself has no scratch access
+    # (checked on the ISA; a scratch reload inside the loop would wait for the LDS-DMA prefetch in flight, csrc/mlp_wide.hip)
+    r"mlp_wide_bwd_f16_kernelILi7ELi8ELi8ELi4ELi1E": 72,
     # fused encode -> MLP forward of a 32-wide net with 33 outputs (psdf_encode_mlp_forward: the sphere tracer's colour pass)
     r"fused_fwd_kernelILi2ELi2ELi2ELi2ELb0EE": 8,
 }
