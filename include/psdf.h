@@ -159,6 +159,13 @@ int psdf_mlp_backward_split_f16_form(void);
 unsigned psdf_mlp_f16_range_events(void);
 
 /* ---- mlp_wide.hip ---- */
+/* Forward of the reference's colour network shape (LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3, models.py:54-129,349-350: dims[0] <= 112,
+   dims[1], dims[2] <= 128, dims[3] <= 64, dims[4] <= 16) on the fp16 matrix pipe with two pieces per fp32 operand: X [dims[0], N],
+   Y [dims[4], N] feature-major; weights[l] [dims[l+1], dims[l]] (for a LipshitzMLP the NORMALISED weights), biases[l]; GELU between
+   the layers, the last one linear.  -2: another shape, stream capture, PSDF_MLP_WIDE_SPLIT=f32, or a value beyond the fp16 range met
+   earlier (psdf_mlp_forward evaluates every shape with fp32 MFMAs). */
+int psdf_mlp_forward_wide_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+    const float* const* biases, float* Y, void* stream);
 /* which kernel the last psdf_mlp_backward_wide launched: 1 = fp32 MFMAs (mlp_wide_bwd_kernel), 2 = two fp16 pieces per operand on
    the fp16 matrix pipe (mlp_wide_bwd_f16_kernel, the default since round 6; PSDF_MLP_WIDE_SPLIT=f32 selects the other, and so does a
    value beyond the fp16 range met by an earlier launch); 0 = none yet.  Debug query (host only). */

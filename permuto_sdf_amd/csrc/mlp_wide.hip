@@ -548,6 +548,7 @@ struct PackH {
 };
 __global__ void mlp_wide_f16_pack_kernel(PackH p) {
   const int l = blockIdx.y >> 1, tr = blockIdx.y & 1;
+  if (tr && !p.AT[l]) return;                                        // (forward only: no transposed records)
   const int rows_t = tr ? p.in_tiles[l] : p.out_tiles[l];            // tiles of the records' rows
   const int ks = wns(tr ? p.out_tiles[l] : p.in_tiles[l]);           // k-steps
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1016,6 +1017,142 @@ __global__ void __launch_bounds__(WN * 64, 1)
   if (wave < T4) put_db(GI::B4, wave, db4);
 }
 
+// ---- forward only (round 6): the colour network's evaluation on the same records.  No parameter gradients, so no accumulators,
+// no T records, no gelu': 56 KB of LDS, two workgroups per CU.  Y [OUT, N] feature-major.
+template <int TI0, int T1, int T2, int T3, int T4>
+__global__ void __launch_bounds__(WN * 64, 2)
+    mlp_wide_fwd_f16_kernel(WideArgsH a, int64_t N, const float* __restrict__ X, float* __restrict__ Y) {
+  static_assert(TI0 <= WN && T1 <= WN && T2 <= WN && T3 <= WN && T4 <= WN && wns(TI0) * 2 <= WN, "one output tile per wave and layer");
+  constexpr int NS0 = wns(TI0), NS1 = wns(T1), NS2 = wns(T2), NS3 = wns(T3);
+  static_assert(NS0 <= 4 && NS1 <= 4 && NS2 <= 4 && NS3 <= 4, "four k-steps of weight records per phase");
+  extern __shared__ __align__(16) wu32x4 wl[];
+  wu32x4* B0 = wl;
+  wu32x4* B1 = B0 + NS0 * 256;
+  wu32x4* B2 = B1 + NS1 * 256;
+  wu32x4* B3 = B2 + NS2 * 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+  const int K0 = a.dims[0], OUT = a.dims[4];
+  const int64_t ntiles = (N + TS - 1) / TS;
+  float vmax = 0.f;
+  auto put_b = [&](wu32x4* Breg, int t, const f32x4 (&v)[2]) {
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++) {
+      uint32_t h0, l0, h1, l1;
+      wsplit2(v[sb][0], v[sb][1], h0, l0);
+      wsplit2(v[sb][2], v[sb][3], h1, l1);
+      wu32x2* rec = reinterpret_cast<wu32x2*>(Breg + ((t >> 1) * 2 + sb) * 128 + lane) + (t & 1);
+      rec[0] = wu32x2{h0, h1};
+      rec[128] = wu32x2{l0, l1};
+    }
+  };
+  auto request = [&](int64_t t2) {      // the next tile's inputs by LDS-DMA into the wave's own 2 KB of the input records (see the backward)
+    const int64_t m0 = (t2 < ntiles ? t2 : ntiles - 1) * TS;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int c2 = lane_o & 15, g2 = lane_o >> 4;
+    if (wave < NS0 * 2) {
+      const int s = wave >> 1, sb = wave & 1;
+      int64_t n = m0 + 16 * sb + c2;
+      n = n < N ? n : N - 1;
+      float* dst = reinterpret_cast<float*>(B0 + wave * 128);
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        int row = wkf(s, g2, j);
+        row = row < K0 ? row : K0 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (int64_t)row * N + n),
+                                         (__attribute__((address_space(3))) void*)(dst + j * 64), 4, 0, 0);
+      }
+    }
+  };
+  const f32x4 zero2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  request(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave < NS0 * 2) {
+      const int s = wave >> 1, sb = wave & 1;
+      const float* src = reinterpret_cast<const float*>(B0 + wave * 128);
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        x[j] = (wkf(s, g, j) < K0 && n0 + 16 * sb + c < N) ? src[j * 64 + lane] : 0.f;
+        vmax = fmaxf(vmax, fabsf(x[j]));
+      }
+      wu32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t h, l;
+        wsplit2(x[2 * j], x[2 * j + 1], h, l);
+        hi[j] = h;
+        lo[j] = l;
+      }
+      wu32x4* rec = B0 + (s * 2 + sb) * 128 + lane;
+      rec[0] = hi;
+      rec[64] = lo;
+    }
+    auto layer = [&](const wu32x4* Aw, const float* bias, int out_true, int ns, int tiles, const wu32x4* Bin, f32x4 (&acc)[2]) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = 16 * wave + 4 * g + r;
+        const float bv = (wave < tiles && row < out_true) ? bias[row] : 0.f;
+        acc[0][r] = bv;
+        acc[1][r] = bv;
+      }
+      if (wave < tiles) {
+        WRec w[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          if (s < ns) w[s] = wload(Aw + ((size_t)(wave * ns + s) * 2) * 64 + lane);
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+          if (s < ns) {
+#pragma unroll
+            for (int sb = 0; sb < 2; sb++) acc[sb] = wmac3(w[s], wload(Bin + (s * 2 + sb) * 128 + lane), acc[sb]);
+          }
+      }
+    };
+    auto act = [&](f32x4 (&acc)[2], wu32x4* Bout, int tiles) {
+      if (wave < tiles) {
+        f32x4 h[2], gp;
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++) {
+          wgelu4(acc[sb], h[sb], gp);
+#pragma unroll
+          for (int r = 0; r < 4; r++) vmax = fmaxf(vmax, fabsf(h[sb][r]));
+        }
+        put_b(Bout, wave, h);
+        if ((tiles & 1) && wave == tiles - 1) put_b(Bout, wave + 1, zero2);
+      }
+    };
+    f32x4 acc[2];
+    __syncthreads();
+    layer(a.A[0], a.b[0], a.dims[1], NS0, T1, B0, acc);
+    act(acc, B1, T1);
+    __syncthreads();
+    request(tile + gridDim.x);       // (the input records have had their last reader)
+    layer(a.A[1], a.b[1], a.dims[2], NS1, T2, B1, acc);
+    act(acc, B2, T2);
+    __syncthreads();
+    layer(a.A[2], a.b[2], a.dims[3], NS2, T3, B2, acc);
+    act(acc, B3, T3);
+    __syncthreads();
+    layer(a.A[3], a.b[3], a.dims[4], NS3, T4, B3, acc);
+    if (wave < T4) {
+#pragma unroll
+      for (int sb = 0; sb < 2; sb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 16 * wave + 4 * g + r;
+          const int64_t n = n0 + 16 * sb + c;
+          if (row < OUT && n < N) Y[(int64_t)row * N + n] = acc[sb][r];
+        }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (vmax >= 32768.f && a.overflow) atomicOr(a.overflow, 1u);
+}
+
 static uint32_t* wide_overflow_word() {
   static uint32_t* w = [] {
     uint32_t* h = nullptr;
@@ -1076,9 +1213,65 @@ int wide_launch_f16(const int* dims, int64_t N, const float* X, const float* con
   return PSDF_OK;
 }
 
+template <int TI0, int T1, int T2, int T3, int T4>
+int wide_forward_f16(const int* dims, int64_t N, const float* X, const float* const* weights, const float* const* biases, float* Y,
+                     hipStream_t st) {
+  const int tiles[5] = {TI0, T1, T2, T3, T4};
+  size_t nrec = 0;
+  for (int l = 0; l < 4; l++) nrec += (size_t)tiles[l + 1] * wns(tiles[l]) * 128;
+  char* scratch = (char*)psdf::stream_scratch(nrec * 16, st);  // NULL while capturing
+  if (!scratch) return PSDF_ERR_UNSUPPORTED;
+  WideArgsH a;
+  PackH pk;
+  wu32x4* wp = reinterpret_cast<wu32x4*>(scratch);
+  int nmax = 0;
+  for (int l = 0; l < 4; l++) {
+    pk.out[l] = dims[l + 1], pk.in[l] = dims[l], pk.out_tiles[l] = tiles[l + 1], pk.in_tiles[l] = tiles[l];
+    pk.W[l] = weights[l];
+    pk.A[l] = wp;
+    pk.AT[l] = nullptr;
+    wp += (size_t)tiles[l + 1] * wns(tiles[l]) * 128;
+    a.A[l] = pk.A[l], a.AT[l] = nullptr, a.b[l] = biases[l];
+    const int n1 = tiles[l + 1] * wns(tiles[l]) * 64;
+    nmax = n1 > nmax ? n1 : nmax;
+  }
+  for (int i = 0; i < 5; i++) a.dims[i] = dims[i];
+  a.overflow = wide_overflow_word();
+  hipLaunchKernelGGL(mlp_wide_f16_pack_kernel, dim3((nmax + 255) / 256, 8), dim3(256), 0, st, pk);
+  const int64_t ntiles = (N + TS - 1) / TS;
+  int64_t blocks = ntiles < 512 ? ntiles : 512;
+  const size_t lds_bytes = (size_t)((wns(TI0) + wns(T1) + wns(T2) + wns(T3)) * 256) * 16;
+  auto kern = mlp_wide_fwd_f16_kernel<TI0, T1, T2, T3, T4>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, Y);
+  PSDF_LAUNCH_CHECK();
+  return PSDF_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+// Forward of the colour network's shape (dims[0] <= 112, dims[1], dims[2] <= 128, dims[3] <= 64, dims[4] <= 16, not both hidden widths
+// <= 64; GELU between the layers, the last one linear) on the fp16 matrix pipe with two pieces per fp32 operand (round 6): X
+// [dims[0], N] and Y [dims[4], N] feature-major, weights[l] / biases[l] the torch-layout parameters (for a LipshitzMLP: the NORMALISED
+// weights).  -2 for other shapes, while a stream is being captured, and after a value beyond the fp16 range was met
+// (psdf_mlp_forward evaluates every shape in fp32).  Replaces the torch.nn / LipshitzMLP forward of models.py:54-129,349-350.
+int psdf_mlp_forward_wide_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                              const float* const* biases, float* Y, void* stream) {
+  if (n_layers != 4 || !dims) return PSDF_ERR_UNSUPPORTED;
+  if (N <= 0 || !X || !weights || !biases || !Y) return PSDF_ERR_ARG;
+  for (int l = 0; l < 4; l++)
+    if (!weights[l] || !biases[l]) return PSDF_ERR_ARG;
+  const char* sp = getenv("PSDF_MLP_WIDE_SPLIT");
+  if (sp && sp[0] == 'f' && sp[1] == '3') return PSDF_ERR_UNSUPPORTED;
+  uint32_t* ov = wide_overflow_word();
+  if (ov && *(volatile uint32_t*)ov) return PSDF_ERR_UNSUPPORTED;
+  if (dims[0] <= 112 && dims[1] <= 128 && dims[2] <= 128 && dims[3] <= 64 && dims[4] <= 16 && !(dims[1] <= 64 && dims[2] <= 64))
+    return wide_forward_f16<7, 8, 8, 4, 1>(dims, N, X, weights, biases, Y, (hipStream_t)stream);
+  return PSDF_ERR_UNSUPPORTED;
+}
 
 // 1 = the last psdf_mlp_backward_wide ran the fp32-MFMA kernel, 2 = the split-fp16 kernel; 0 = none yet (debug query, host only)
 int psdf_mlp_backward_wide_form(void) { return g_wide_form; }

@@ -64,6 +64,34 @@ def mlp_forward_raw(dims, x_fm, packed, skip=None, out=None, f16=False):
     return y
 
 
+_wide_f16_fn = None
+
+
+def mlp_forward_wide_f16_raw(dims, x_fm, weights, biases, out=None):
+    """The colour network's forward (LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3, models.py:349-350) on the fp16 matrix pipe with
+    two pieces per fp32 operand (csrc/mlp_wide.hip, round 6): x_fm [dims[0], N] feature-major, `weights` / `biases` the torch
+    layout (for a LipshitzMLP the NORMALISED weights) -> y [dims[-1], N], or None when the library declines (-2: another
+    shape, stream capture, PSDF_MLP_WIDE_SPLIT=f32, a value beyond the fp16 range met earlier) -- the caller then takes
+    mlp_forward_raw (fp32 MFMAs)."""
+    global _wide_f16_fn
+    if len(dims) != 5:
+        return None
+    if _wide_f16_fn is None:
+        _wide_f16_fn = L.lib().psdf_mlp_forward_wide_f16
+        _wide_f16_fn.restype = ctypes.c_int
+    N = x_fm.shape[1]
+    y = out if out is not None else torch.empty((dims[-1], N), dtype=torch.float32, device=x_fm.device)
+    arr = lambda ts: (ctypes.c_void_p * 4)(*[t.data_ptr() for t in ts])
+    ws = [w.detach() if w.is_contiguous() else w.detach().contiguous() for w in weights]
+    bs = [b.detach() for b in biases]
+    rc = _wide_f16_fn(L.c_i(4), _dims_array(dims), L.c_l(N), L.ptr(x_fm), arr(ws), arr(bs), L.ptr(y), L.stream())
+    if rc == -2:
+        return None
+    if rc != 0:
+        L.check(rc, "psdf_mlp_forward_wide_f16")
+    return y
+
+
 def _grad_views(dims, flat=None, dev=None):
     """dW_l [d_{l+1}, d_l] and db_l [d_{l+1}] as views of ONE buffer (every slice starts on a 16-byte boundary); allocates
     it zero-filled when `flat` is None"""

@@ -26,7 +26,7 @@ import torch
 from . import _lib as L
 from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
 from .encoding import encode_backward_raw, encode_double_backward_raw, encode_forward_raw
-from .mlp import (lipshitz_normalize_all_backward_raw, lipshitz_normalize_all_raw, mlp_backward_raw, mlp_double_backward, mlp_forward_raw,
+from .mlp import (mlp_forward_wide_f16_raw, lipshitz_normalize_all_backward_raw, lipshitz_normalize_all_raw, mlp_backward_raw, mlp_double_backward, mlp_forward_raw,
                   pack_params)
 from .neus import (eikonal_loss_raw, l1_loss_raw, nerf_composite_backward_raw, nerf_composite_forward_raw, neus_composite_backward_raw,
                    neus_composite_forward_raw, sigmoid_rows_backward_raw, sigmoid_rows_raw)
@@ -321,7 +321,9 @@ class ManualTrainer(Trainer):
                 m = rgbn.mlp
                 wn = lipshitz_normalize_all_raw(m.weights_per_layer, m.lipshitz_bound_per_layer)      # all four layers, one launch
                 bsr = [b.detach() for b in m.biases_per_layer]
-                rgb_fm = mlp_forward_raw(m.dims, x_rgb, pack_params(m.dims, wn, bsr))                            # [3, N]
+                rgb_fm = mlp_forward_wide_f16_raw(m.dims, x_rgb, wn, bsr)                                        # [3, N]
+                if rgb_fm is None:      # (the library declined: fp32 MFMAs)
+                    rgb_fm = mlp_forward_raw(m.dims, x_rgb, pack_params(m.dims, wn, bsr))
                 if cc is not None:
                     rgb_raw = rgb_fm.t().contiguous()                                                            # [N, 3]
                     ridx_fg = RaySamplesPacked.compute_per_sample_ray_idx(fg.ray_start_end_idx, n_fg).long()

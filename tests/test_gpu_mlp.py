@@ -647,3 +647,29 @@ def test_null_upstream_gradient_is_the_unit_gradient_of_output_zero(dev, dims):
         assert torch.equal(p, q)
     with pytest.raises(AssertionError):
         mlp_backward_raw(dims, x, ws, bs, None, need_dx=True, need_dw=True)
+
+
+@pytest.mark.parametrize("dims,N", [([111, 128, 128, 64, 3], 49_153), ([112, 128, 128, 64, 3], 5_003), ([100, 96, 128, 48, 2], 777),
+                                    ([111, 128, 128, 64, 3], 31)])
+def test_wide_net_forward_f16_against_float64(dev, dims, N):
+    """psdf_mlp_forward_wide_f16 (csrc/mlp_wide.hip, round 6: the colour network's forward on the fp16 matrix pipe, two pieces per
+    operand): against float64, 4e-6 of the largest output (the bar of the SDF net's split-fp16 forward), beside torch's fp32;
+    ragged N, padded widths; other shapes are declined (None)."""
+    import copy
+    from permuto_sdf_amd.mlp import mlp_forward_wide_f16_raw
+    torch.manual_seed(N)
+    lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
+    net = torch.nn.Sequential(lin[0], torch.nn.GELU(), lin[1], torch.nn.GELU(), lin[2], torch.nn.GELU(), lin[3]).to(dev)
+    x = torch.randn(N, dims[0], device=dev)
+    x[:, dims[0] // 2:] *= 1e-2
+    y = mlp_forward_wide_f16_raw(dims, x.t().contiguous(), [l.weight for l in lin], [l.bias for l in lin])
+    assert y is not None
+    ref = copy.deepcopy(net).double()(x.double())
+    t32 = net(x)
+    scale = float(ref.abs().max())
+    err = float((y.t().double() - ref).abs().max()) / scale
+    err_t = float((t32.double() - ref).abs().max()) / scale
+    print("wide forward f16 %s N=%d: %.1e (torch fp32 %.1e) of the largest output" % (dims, N, err, err_t))
+    assert bool(torch.isfinite(y).all()) and err <= 4e-6, (err, err_t)
+    assert mlp_forward_wide_f16_raw([36, 64, 64, 64, 1], x.t().contiguous()[:36].contiguous(), [l.weight for l in lin],
+                                    [l.bias for l in lin]) is None
