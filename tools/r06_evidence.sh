@@ -19,7 +19,7 @@ PSDF_BENCH_NO_24BIT=1 bash tools/pmc_sq.sh "mlp_bwd_split_f16_kernel" r06_mlpbwd
 bash tools/pmc_sq.sh "march_quad_kernel" r06_marchquad -- python $R/tools/train_bench.py --manual --start-iter 20000 --repeats 1 --steps 10 --warmup 3 > $O/pmc_sq_march_quad.log 2>&1
 bash tools/pmc_sq.sh "mlp_wide_bwd_f16_kernel<7" r06_widef16 -- python $R/tools/train_bench.py --manual --start-iter 20000 --repeats 1 --steps 10 --warmup 3 > $O/pmc_sq_wide_f16.log 2>&1
 python tools/cfg2_matrix.py > $O/cfg2_matrix.jsonl 2> $O/cfg2_matrix.err
-RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 PSDF_DP_FORCE_COLLECTIVES=1 PSDF_DIST_BACKEND=nccl python tools/train_bench.py --manual --start-iter 20000 > $O/cfg4_one_rank_rccl.json 2> $O/cfg4_one_rank_rccl.err
+RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 PSDF_DP_FORCE_COLLECTIVES=1 PSDF_DIST_BACKEND=nccl python tools/train_bench.py --manual --start-iter 20000 2> $O/cfg4_one_rank_rccl.err | grep "^{" > $O/cfg4_one_rank_rccl.json
 rm -rf $R/gpurun_out/pmc_hbm_r06/FETCH_SIZE $R/gpurun_out/pmc_hbm_r06/WRITE_SIZE $R/gpurun_out/pmc_sq_r06_*/pass*
 fi
 tail -c 1500 $O/bench.json; echo; head -10 $O/bench_kernel_stats.txt | cut -c1-175; head -6 $O/bench_24bit_kernel_stats.txt | cut -c1-175
