@@ -63,7 +63,12 @@ int psdf_encode_backward_ws(int pos_dim, int nr_feat, int64_t N, int nr_levels, 
     int64_t workspace_bytes, void* stream);
 /* debug query: how the last balanced binning launch of psdf_encode_backward_ws dealt its resident round of workgroups over the
    levels (counts[0 .. nr_levels)); returns nr_levels, 0 when no balanced launch has run.  Shares follow the measured duration
-   of each level's workgroups in the previous call (PSDF_ENC_BWD_BALANCE=0: equal shares); closed levels fall to the minimum. */
+   of each level's workgroups in the previous call (PSDF_ENC_BWD_BALANCE=0: equal shares); closed levels fall to the minimum.
+   REPRODUCIBILITY: the deal -- and with it the order of the float additions of the lattice gradient -- depends on the timing of
+   the previous call; PSDF_ENC_BWD_BALANCE=0 is the switch for run-to-run comparisons (state is kept per device, lattice and
+   shape class).  NON-FINITE INPUTS: contributions of neighbouring samples to one table row are merged in registers with
+   multiply-adds (encode.hip, combine_runs16), so ONE non-finite upstream gradient makes the gradient of up to 15 other table
+   rows handled by the same 16 lanes NaN as well -- a NaN batch is a NaN batch, but more rows show it than carry it. */
 int psdf_encode_backward_level_shares(int* counts, int max_levels);
 
 

@@ -1284,6 +1284,7 @@ struct EncBalance {
   uint64_t last_use = 0;
   std::vector<int> counts;
   uint32_t* times[2] = {nullptr, nullptr};
+  int device = -1;
 };
 constexpr int BAL_MAX_WG = 8192, BAL_MIN_PER_LEVEL = 4, BAL_STATES = 16;
 std::mutex g_shares_mu;
@@ -1308,9 +1309,15 @@ bool encode_balance(int nr_levels, int64_t N, int total, int64_t super_tiles, Le
     const int64_t top = (int64_t)1 << (bucket / 4);
     bucket += (int)(((N - top) * 4) / top);
   }
+  // (the key holds the device as well: an address re-used on another GPU -- or after a free -- must not inherit a deal measured
+  //  elsewhere)
+  int device = -1;
+  (void)hipGetDevice(&device);
   EncBalance* Bp = nullptr;
   for (auto& st_ : states)
-    if (st_.times[0] && st_.ident == ident && st_.kind == kind && st_.levels == nr_levels && st_.bucket == bucket && st_.total == total) Bp = &st_;
+    if (st_.times[0] && st_.ident == ident && st_.device == device && st_.kind == kind && st_.levels == nr_levels && st_.bucket == bucket &&
+        st_.total == total)
+      Bp = &st_;
   if (!Bp) {
     for (auto& st_ : states)
       if (!Bp || st_.last_use < Bp->last_use) Bp = &st_;
@@ -1338,6 +1345,7 @@ bool encode_balance(int nr_levels, int64_t N, int total, int64_t super_tiles, Le
     B.levels = nr_levels;
     B.kind = kind;
     B.ident = ident;
+    B.device = device;
     B.bucket = bucket;
     B.total = total;
     B.counts.assign(nr_levels, total / nr_levels);
