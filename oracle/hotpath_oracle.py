@@ -48,15 +48,18 @@ def reference_step(pos, dirs, normals, dt, rgb, gt, nr_rays, per_ray, lattice, s
 
 
 def reference_forward(pos, dirs, normals, dt, rgb, gt, nr_rays, per_ray, lattice, scale_per_level, shifts, window, weights, biases,
-                      inv_s, cos_anneal_ratio, points_scaling=1e-3, dtype=torch.float64, chunk_rays=1024):
+                      inv_s, cos_anneal_ratio, points_scaling=1e-3, dtype=torch.float64, chunk_rays=1024, device="cpu"):
     """Forward only (sdf [N,1], radiance [R,3], loss) of the same chain in `dtype`, ray chunk by ray chunk, so that the FULL bench
     batch (16 384 rays x 128) fits a CPU in about a minute.  dtype = float64 is the ARBITER of the full-size parity test: both
     the HIP path and an fp32 evaluation of the reference arithmetic are measured against it.  (The simplex of a point is found
     from the same fp32 positions; the encoding is continuous across simplex boundaries, so a different rounding of the
-    elevated coordinates moves features by O(eps), never by a jump.)"""
-    lat = lattice.detach().to(dtype)
-    sh = shifts.detach().to(dtype)
-    win = torch.as_tensor(window).to(dtype)
+    elevated coordinates moves features by O(eps), never by a jump.)  device: where torch evaluates the restatement -- the same
+    elementwise torch expressions on "cuda" finish the full batch in seconds (float64 on the GPU is still the oracle's arithmetic,
+    not the product's kernels)."""
+    lat = lattice.detach().to(device=device, dtype=dtype)
+    sh = shifts.detach().to(device=device, dtype=dtype)
+    win = torch.as_tensor(window).to(device=device, dtype=dtype)
+    pos, dirs, normals, dt, rgb, gt = (t.to(device) for t in (pos, dirs, normals, dt, rgb, gt))
     mods = []
     for i, (w, b) in enumerate(zip(weights, biases)):
         lin = torch.nn.Linear(w.shape[1], w.shape[0]).to(dtype)
@@ -65,8 +68,8 @@ def reference_forward(pos, dirs, normals, dt, rgb, gt, nr_rays, per_ray, lattice
         mods.append(lin)
         if i < len(weights) - 1:
             mods.append(torch.nn.GELU())
-    mlp = torch.nn.Sequential(*mods)
-    inv_s = torch.as_tensor(inv_s).to(dtype)
+    mlp = torch.nn.Sequential(*mods).to(device)
+    inv_s = torch.as_tensor(inv_s).to(device=device, dtype=dtype)
     sdfs, preds = [], []
     with torch.no_grad():
         for r0 in range(0, nr_rays, chunk_rays):
@@ -79,5 +82,5 @@ def reference_forward(pos, dirs, normals, dt, rgb, gt, nr_rays, per_ray, lattice
             sdfs.append(sdf)
             preds.append(pred)
     sdf, pred = torch.cat(sdfs), torch.cat(preds)
-    loss = no.rgb_loss(gt.to(dtype), pred, torch.ones(nr_rays, 1, dtype=dtype))
-    return dict(sdf=sdf, pred=pred, loss=float(loss))
+    loss = no.rgb_loss(gt.to(dtype), pred, torch.ones(nr_rays, 1, dtype=dtype, device=device))
+    return dict(sdf=sdf.cpu(), pred=pred.cpu(), loss=float(loss))

@@ -61,7 +61,7 @@ def composite_equal(alpha, one_minus, rgb, nr_rays, per_ray, reference_compat=Tr
     """transmittance T_i = prod_{j<i} one_minus_j, weights alpha*T, per-ray sum of w*rgb; [R*n, .] packed ray-major.
     `reference_compat` selects the backward of the weighted sum: the reference kernel's (default) or the exact one."""
     om = one_minus.view(nr_rays, per_ray)
-    T = torch.cumprod(torch.cat([torch.ones(nr_rays, 1, dtype=om.dtype), om[:, :-1]], 1), dim=1)
+    T = torch.cumprod(torch.cat([torch.ones(nr_rays, 1, dtype=om.dtype, device=om.device), om[:, :-1]], 1), dim=1)
     w = alpha.view(nr_rays, per_ray) * T
     rgb3 = rgb.view(nr_rays, per_ray, -1)
     pred = _IntegrateCompat.apply(w, rgb3) if (reference_compat and rgb3.shape[-1] == 3) else (w[:, :, None] * rgb3).sum(1)

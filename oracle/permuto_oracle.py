@@ -286,7 +286,7 @@ def encode(points, lattice_values, scale_list, shifts, window, concat_points=Fal
     for l in range(L):
         rem0, rank, bary = simplex(points, shifts[l], sf[l])
         idx = vertex_indices(rem0, rank, T)
-        acc = torch.zeros(N, F, dtype=points.dtype)
+        acc = torch.zeros(N, F, dtype=points.dtype, device=points.device)
         for r in range(P + 1):
             fv = lattice_values[l].index_select(0, idx[:, r])
             bw = bary[:, r] * window[l]
@@ -294,7 +294,7 @@ def encode(points, lattice_values, scale_list, shifts, window, concat_points=Fal
         outs.append(acc)
     npc = nr_point_channels(P, F, concat_points, layout)
     if npc:
-        pad = torch.zeros(N, npc - P, dtype=points.dtype)
+        pad = torch.zeros(N, npc - P, dtype=points.dtype, device=points.device)
         outs.append(torch.cat([points * float(points_scaling), pad], dim=1))
     return torch.cat(outs, dim=1)
 
