@@ -341,7 +341,7 @@ int psdf_grid_check_occupancy(int count, int nr_voxels_per_dim, float extent, co
     uint8_t* grid_occupancy, const float* points, uint8_t* out, void* stream);
 
 /* which form the last psdf_march_samples launched: 1 = march_kernel (a thread per ray), 2 = march_quad_kernel (four lanes per
-   ray, unit grids with nr_rays <= 16384; PSDF_MARCH_FORM=thread|quad overrides); 0 = none yet.  Debug query (host only). */
+   ray, unit grids with nr_rays <= 6144; PSDF_MARCH_FORM=thread|quad overrides); 0 = none yet.  Debug query (host only). */
 int psdf_march_form(void);
 /* replaces: OccupancyGrid::compute_samples_in_occupied_regions (src/OccupancyGrid.cu:212-257) and RaySampler::compute_samples_fg (src/RaySampler.cu:104-152);
    scratch: nr_rays * (3 + max_nr_samples_per_ray) 4-byte words */

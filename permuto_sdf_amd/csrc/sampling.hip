@@ -408,7 +408,8 @@ __global__ void __launch_bounds__(PSDF_BLOCK)
 //     needed where a byte is read, not on the dependent chain (coordinates >= 1024 keep the reference's multiply form, tagged).
 // Used for fast grids (extent 1, power-of-two n) and nr_rays <= MARCH_QUAD_MAX_RAYS; PSDF_MARCH_FORM=thread|quad overrides.
 constexpr int QCAP = 512, QSTRIDE = QCAP + 1, QRAYS = 16;    // steps recorded per ray; row stride (bank spread); rays per wave
-constexpr int MARCH_QUAD_MAX_RAYS = 8192;
+constexpr int MARCH_QUAD_MAX_RAYS = 6144;    // one workgroup (16 rays, 100 KB of LDS) per CU and round: 4096 rays are one round; measured
+                                             // 200 against 378 us at 4096 rays, 391 against 397 at 8192, 751 against 406 at 16 384
 constexpr uint32_t KEY_OCC = 0x80000000u, KEY_MASK = 0x7fffffffu;   // a key = the voxel's coordinates, 10 bits each; bit 31 = occupied
 template <int J> __device__ __forceinline__ uint32_t qb(uint32_t v) {       // lane J of the quad, to all four
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xf, 0xf, true);
