@@ -833,6 +833,7 @@ __global__ void __launch_bounds__(BW * 64)
   float* dyb = tbuf + 16 * 17;
   float* xbuf = dyb + 16;
   float* vbuf = xbuf + 2 * SX * 64;
+  BWD_STAMP(0);
   {
     const int tid = threadIdx.x, nt = BW * 64;
     const int d0 = p.dims[0], d1 = p.dims[1], d2 = p.dims[2], d3 = p.dims[3];
@@ -862,6 +863,7 @@ __global__ void __launch_bounds__(BW * 64)
       }
   }
   __syncthreads();
+  BWD_STAMP(1);
   const int g = lane >> 4, c = lane & 15;
   const int K0 = p.dims[0], OUT = p.dims[p.n_layers], S0 = p.steps0;
   const int lf = p.n_layers - 1;
@@ -1100,10 +1102,12 @@ __global__ void __launch_bounds__(BW * 64)
     }
   }
   }
+  BWD_STAMP(2);
   __syncthreads();
   float* ACC = lds;
   for (int e = threadIdx.x; e < p.total; e += BW * 64) ACC[e] = 0.f;
   __syncthreads();
+  BWD_STAMP(3);
 #pragma unroll 1
   for (int r = 0; r < BW; r++) {      // rotating rounds of plain read-add-write, see LayerAcc::flush_chain
     const int sel = (wave + r) & (BW - 1);
@@ -1130,7 +1134,9 @@ __global__ void __launch_bounds__(BW * 64)
     }
     __syncthreads();
   }
+  BWD_STAMP(4);
   flush_image<BW * 64>(p, a, ACC);
+  BWD_STAMP(5);
 }
 
 template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
@@ -1288,6 +1294,15 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
   // not fit one wave's registers (the single-wave instantiations below spill 213-227 registers) -- the workgroup-cooperative
   // kernel of mlp_wide.hip splits the dW rows over 8 waves.  -2 (no stream-ordered scratch: capture) falls through.
   if (dW && n_layers == 4 && to >= 2 && t1 == 4 && t2 == 4 && t3 == 4) {
+    const int r = psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
+    if (r != PSDF_ERR_UNSUPPORTED) {
+      psdf::g_last_path[psdf::PATH_MLP_BWD] = 3;
+      return r;
+    }
+  }
+  // the background colour head 80 -> 64 x 2 -> 3: the split-fp16 workgroup kernel, two hidden layers (round 6; the fp32 single-wave
+  // instantiation below stays for PSDF_MLP_WIDE_SPLIT=f32, capture, and after an overflow of the fp16 range guard)
+  if (dW && dX && n_layers == 3 && ti0 == 5 && t1 == 4 && t2 == 4 && to == 1 && p.final_dot) {
     const int r = psdf_mlp_backward_wide(n_layers, dims, N, X, weights, biases, dY, dX, dW, db, stream);
     if (r != PSDF_ERR_UNSUPPORTED) {
       psdf::g_last_path[psdf::PATH_MLP_BWD] = 3;

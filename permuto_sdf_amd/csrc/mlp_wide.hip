@@ -139,8 +139,9 @@ __device__ __forceinline__ void layer_dh(const float* __restrict__ WT, int out_p
 // then db1, db2, db3, db4 (padded widths)
 template <int TI0, int T1, int T2, int T3, int T4>
 struct GImg {
+  static constexpr int TL = T3 > 0 ? T3 : T2;   // tiles of the last hidden layer (T3 == 0: a net with two hidden layers, round 6)
   static constexpr int W1 = 0, W2 = W1 + T1 * 16 * TI0 * 16, W3 = W2 + T2 * 16 * T1 * 16, W4 = W3 + T3 * 16 * T2 * 16,
-                       B1 = W4 + T4 * 16 * T3 * 16, B2 = B1 + T1 * 16, B3 = B2 + T2 * 16, B4 = B3 + T3 * 16,
+                       B1 = W4 + T4 * 16 * TL * 16, B2 = B1 + T1 * 16, B3 = B2 + T2 * 16, B4 = B3 + T3 * 16,
                        TOTAL = B4 + T4 * 16;
 };
 
@@ -291,7 +292,7 @@ __global__ void mlp_wide_reduce_kernel(const float* __restrict__ partial, int ni
   if (e < GI::W2) mat(e - GI::W1, TI0 * 16, a.dims[1], a.dims[0], dW0);
   else if (e < GI::W3) mat(e - GI::W2, T1 * 16, a.dims[2], a.dims[1], dW1);
   else if (e < GI::W4) mat(e - GI::W3, T2 * 16, a.dims[3], a.dims[2], dW2);
-  else if (e < GI::B1) mat(e - GI::W4, T3 * 16, a.dims[4], a.dims[3], dW3);
+  else if (e < GI::B1) mat(e - GI::W4, GI::TL * 16, a.dims[4], a.dims[3], dW3);
   else if (e < GI::B2) { if (e - GI::B1 < a.dims[1]) atomicAdd(&db0[e - GI::B1], s); }
   else if (e < GI::B3) { if (e - GI::B2 < a.dims[2]) atomicAdd(&db1[e - GI::B2], s); }
   else if (e < GI::B4) { if (e - GI::B3 < a.dims[3]) atomicAdd(&db2[e - GI::B3], s); }
@@ -444,7 +445,8 @@ int wide_launch(const int* dims, int64_t N, const float* X, const float* const* 
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, dY, dX, partial);
-  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3, T4>), dim3((GI::TOTAL + 255) / 256, 8), dim3(256), 0, st, partial,
+  // (the small nets' images: 32 slices of the workgroup images instead of 8 -- their summing launch waits on loads, not on bytes)
+  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3, T4>), dim3((GI::TOTAL + 255) / 256, GI::TOTAL < 20000 ? 32 : 8), dim3(256), 0, st, partial,
                      (int)blocks, a, dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
@@ -548,7 +550,7 @@ struct PackH {
 };
 __global__ void mlp_wide_f16_pack_kernel(PackH p) {
   const int l = blockIdx.y >> 1, tr = blockIdx.y & 1;
-  if (tr && !p.AT[l]) return;                                        // (forward only: no transposed records)
+  if ((tr && !p.AT[l]) || !p.W[l]) return;                           // (forward only: no transposed records; an empty layer slot)
   const int rows_t = tr ? p.in_tiles[l] : p.out_tiles[l];            // tiles of the records' rows
   const int ks = wns(tr ? p.out_tiles[l] : p.in_tiles[l]);           // k-steps
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -610,8 +612,12 @@ __global__ void __launch_bounds__(WN * 64, 1)
   // gives wave w the row tile w % T and every (8 / T)-th ... precisely: the column tiles [cb, cb + CN) with CN = ceil(cols * T / 8)
   // ... so that all eight waves carry accumulators for every layer (a layer with 4 output tiles would otherwise leave half of the
   // waves' registers unused and the other half short: the kernel lives at 256 registers per wave).
-  constexpr int S1 = WN / T1 > 0 ? WN / T1 : 1, S2 = WN / T2 > 0 ? WN / T2 : 1, S3 = WN / T3 > 0 ? WN / T3 : 1, S4 = WN / T4 > 0 ? WN / T4 : 1;
-  constexpr int C1 = (TI0 + S1 - 1) / S1, C2 = (T1 + S2 - 1) / S2, C3 = (T2 + S3 - 1) / S3, C4 = (T3 + S4 - 1) / S4;   // column tiles per wave
+  constexpr bool L3 = T3 > 0;            // three hidden layers (the colour / density nets) or two (80 -> 64 -> 64 -> 3, the background
+                                         // colour head, models.py:463-469: layer 3 does not exist, the linear layer reads h2)
+  constexpr int TL = L3 ? T3 : T2;
+  constexpr int S1 = WN / T1 > 0 ? WN / T1 : 1, S2 = WN / T2 > 0 ? WN / T2 : 1, S3 = (L3 && WN / (L3 ? T3 : 1) > 0) ? WN / (L3 ? T3 : 1) : 1,
+                S4 = WN / T4 > 0 ? WN / T4 : 1;
+  constexpr int C1 = (TI0 + S1 - 1) / S1, C2 = (T1 + S2 - 1) / S2, C3 = L3 ? (T2 + S3 - 1) / S3 : 1, C4 = (TL + S4 - 1) / S4;   // column tiles per wave
   f32x4 dW1[C1], dW2[C2], dW3[C3], dW4[C4];
 #pragma unroll
   for (int i = 0; i < C1; i++) dW1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -831,7 +837,12 @@ __global__ void __launch_bounds__(WN * 64, 1)
     WRec wq[2];
     const wu32x4* wnext = nullptr;     // the records the current prefetch belongs to (k-steps 2, 3 follow from it)
     auto prefetch = [&](const wu32x4* Aw, int ns, int tiles) {
-      wnext = Aw + ((size_t)(wave * ns) * 2) * 64 + lane;
+      // (the lane index behind an empty asm: left visible, the eight record addresses of a tile are hoisted out of the tile loop as
+      //  64-bit register pairs, parked in scratch, and their reloads wait -- vmcnt counts in order -- for the LDS-DMA prefetch of
+      //  the next tile that is in flight by then; recomputed here they are two instructions each)
+      int lane_p = lane;
+      asm volatile("" : "+v"(lane_p));
+      wnext = reinterpret_cast<const wu32x4*>(reinterpret_cast<const char*>(Aw) + (uint32_t)((wave * ns * 128 + lane_p) * 16));
 #pragma unroll
       for (int s = 0; s < 2; s++)
         if (s < ns && wave < tiles) wq[s] = wload(wnext + (size_t)s * 128);
@@ -923,7 +934,8 @@ __global__ void __launch_bounds__(WN * 64, 1)
       bias_init(a.b[1], a.dims[2], acc);
       mma(NS1, B1, acc);
     }
-    prefetch(a.A[2], NS2, T3);
+    if (L3) prefetch(a.A[2], NS2, T3);
+    else prefetch(a.AT[3], NS4, T2);
     // the next tile's inputs (their landing zone, the input records, has had its last reader before the barrier above); behind
     // this phase's weight requests: loads return in order, an earlier place would make those wait for HBM
     request(tile + gridDim.x);
@@ -931,47 +943,56 @@ __global__ void __launch_bounds__(WN * 64, 1)
     WDBG
     __syncthreads();
     WDBG
-    if (wave < T3) {
-      bias_init(a.b[2], a.dims[3], acc);
-      mma(NS2, B2, acc);
+    // (the two scratch sets alternate layer by layer, starting with set A for the linear layer's upstream gradient)
+    wu32x4* const SA = SCR;
+    wu32x4* const SB = SCR + WN * 128;
+    wu32x4* const S2set = L3 ? SA : SB;       // where dZ2 (transposed) goes; dZ1 takes the other set
+    wu32x4* const S1set = L3 ? SB : SA;
+    if constexpr (L3) {
+      if (wave < T3) {
+        bias_init(a.b[2], a.dims[3], acc);
+        mma(NS2, B2, acc);
+      }
+      prefetch(a.AT[3], NS4, T3);
+      if (wave < T3) act(acc, B3, H3T, g3, (T3 & 1) != 0, T3);
+      WDBG
+      __syncthreads();
+      WDBG
     }
-    prefetch(a.AT[3], NS4, T3);
-    if (wave < T3) act(acc, B3, H3T, g3, (T3 & 1) != 0, T3);
-    WDBG
-    __syncthreads();
-    WDBG
-    // ---- backward.  Layer 4 (linear): its upstream gradient is in B4 / the scratch of the owners of its tiles
-    if (wave < S4 * T4) dw(SCR, H3T, T4, T3, C4, dW4);
-    if (wave < T3) {
-      acc[0] = zero2[0], acc[1] = zero2[1];
-      mma(NS4, B4, acc);
+    // ---- backward.  The linear last layer: its upstream gradient is in B4 / set A of the scratch
+    if (wave < S4 * T4) dw(SA, L3 ? H3T : H2T, T4, TL, C4, dW4);
+    if constexpr (L3) {
+      if (wave < T3) {
+        acc[0] = zero2[0], acc[1] = zero2[1];
+        mma(NS4, B4, acc);
+      }
+      prefetch(a.AT[2], NS3, T2);
+      if (wave < T3) to_dz(acc, g3, db3, B3, SB, (T3 & 1) != 0, T3);
+      WDBG
+      __syncthreads();
+      WDBG
+      if (wave < S3 * T3) dw(SB, H2T, T3, T2, C3, dW3);
     }
-    prefetch(a.AT[2], NS3, T2);
-    if (wave < T3) to_dz(acc, g3, db3, B3, SCR + WN * 128, (T3 & 1) != 0, T3);
-    WDBG
-    __syncthreads();
-    WDBG
-    if (wave < S3 * T3) dw(SCR + WN * 128, H2T, T3, T2, C3, dW3);
     if (wave < T2) {
       acc[0] = zero2[0], acc[1] = zero2[1];
-      mma(NS3, B3, acc);
+      mma(L3 ? NS3 : NS4, L3 ? B3 : B4, acc);
     }
     prefetch(a.AT[1], NS2, T1);
-    if (wave < T2) to_dz(acc, g2, db2, B2, SCR, (T2 & 1) != 0, T2);
+    if (wave < T2) to_dz(acc, g2, db2, B2, S2set, (T2 & 1) != 0, T2);
     WDBG
     __syncthreads();
     WDBG
-    if (wave < S2 * T2) dw(SCR, H1T, T2, T1, C2, dW2);
+    if (wave < S2 * T2) dw(S2set, H1T, T2, T1, C2, dW2);
     if (wave < T1) {
       acc[0] = zero2[0], acc[1] = zero2[1];
       mma(NS2, B2, acc);
     }
     prefetch(a.AT[0], NS1, TI0);
-    if (wave < T1) to_dz(acc, g1, db1, B1, SCR + WN * 128, (T1 & 1) != 0, T1);
+    if (wave < T1) to_dz(acc, g1, db1, B1, S1set, (T1 & 1) != 0, T1);
     WDBG
     __syncthreads();
     WDBG
-    if (wave < S1 * T1) dw(SCR + WN * 128, X0T, T1, TI0, C1, dW1);
+    if (wave < S1 * T1) dw(S1set, X0T, T1, TI0, C1, dW1);
     if (dX && wave < TI0) {
       acc[0] = zero2[0], acc[1] = zero2[1];
       mma(NS1, B1, acc);
@@ -1009,11 +1030,11 @@ __global__ void __launch_bounds__(WN * 64, 1)
   };
   if (wave < S1 * T1) put(GI::W1, TI0 * 16, T1, TI0, C1, dW1);
   if (wave < S2 * T2) put(GI::W2, T1 * 16, T2, T1, C2, dW2);
-  if (wave < S3 * T3) put(GI::W3, T2 * 16, T3, T2, C3, dW3);
-  if (wave < S4 * T4) put(GI::W4, T3 * 16, T4, T3, C4, dW4);
+  if (L3 && wave < S3 * T3) put(GI::W3, T2 * 16, L3 ? T3 : 1, T2, C3, dW3);
+  if (wave < S4 * T4) put(GI::W4, TL * 16, T4, TL, C4, dW4);
   if (wave < T1) put_db(GI::B1, wave, db1);
   if (wave < T2) put_db(GI::B2, wave, db2);
-  if (wave < T3) put_db(GI::B3, wave, db3);
+  if (L3 && wave < T3) put_db(GI::B3, wave, db3);
   if (wave < T4) put_db(GI::B4, wave, db4);
 }
 
@@ -1167,13 +1188,18 @@ static uint32_t* wide_overflow_word() {
 }
 int g_wide_form = 0;    // 1 = fp32 MFMA kernel, 2 = split-fp16 kernel (last launch)
 
+// n_layers = 4: dims {in, h1, h2, h3, out}; n_layers = 3 (T3 == 0): dims {in, h1, h2, out} -- the linear last layer then sits in slot 3
+// of the kernel's arrays and slot 2 stays empty
 template <int TI0, int T1, int T2, int T3, int T4>
-int wide_launch_f16(const int* dims, int64_t N, const float* X, const float* const* weights, const float* const* biases,
+int wide_launch_f16(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights, const float* const* biases,
                     const float* dY, float* dX, float* const* dW, float* const* db, hipStream_t st) {
   using GI = GImg<TI0, T1, T2, T3, T4>;
-  const int tiles[5] = {TI0, T1, T2, T3, T4};
+  constexpr int TL = T3 > 0 ? T3 : T2;
+  const int in_t[4] = {TI0, T1, T2, TL}, out_t[4] = {T1, T2, T3, T4};       // tiles of every layer's input / output (slot 2: maybe none)
+  const int src[4] = {0, 1, n_layers == 4 ? 2 : -1, n_layers - 1};          // which of the caller's layers a slot holds
+  int kd[5] = {dims[0], dims[1], dims[2], n_layers == 4 ? dims[3] : dims[2], dims[n_layers]};
   size_t nrec = 0;      // 16-byte records of the weight images
-  for (int l = 0; l < 4; l++) nrec += (size_t)tiles[l + 1] * wns(tiles[l]) * 128 + (size_t)tiles[l] * wns(tiles[l + 1]) * 128;
+  for (int l = 0; l < 4; l++) nrec += (size_t)out_t[l] * wns(in_t[l]) * 128 + (size_t)in_t[l] * wns(out_t[l]) * 128;
   const int64_t ntiles = (N + TS - 1) / TS;
   int64_t blocks = ntiles < 256 ? ntiles : 256;
   char* scratch = (char*)psdf::stream_scratch(nrec * 16 + (size_t)blocks * GI::TOTAL * sizeof(float), st);  // NULL while capturing
@@ -1181,20 +1207,24 @@ int wide_launch_f16(const int* dims, int64_t N, const float* X, const float* con
   WideArgsH a;
   PackH pk;
   wu32x4* wp = reinterpret_cast<wu32x4*>(scratch);
-  int nmax = 0;
+  int nmax = 1;
   for (int l = 0; l < 4; l++) {
-    pk.out[l] = dims[l + 1], pk.in[l] = dims[l], pk.out_tiles[l] = tiles[l + 1], pk.in_tiles[l] = tiles[l];
-    pk.W[l] = weights[l];
+    const bool have = src[l] >= 0;
+    pk.out[l] = have ? (l == 3 ? kd[4] : kd[l + 1]) : 0;
+    pk.in[l] = have ? kd[l] : 0;
+    pk.out_tiles[l] = have ? out_t[l] : 0;
+    pk.in_tiles[l] = have ? in_t[l] : 0;
+    pk.W[l] = have ? weights[src[l]] : nullptr;
     pk.A[l] = wp;
-    wp += (size_t)tiles[l + 1] * wns(tiles[l]) * 128;
+    wp += (size_t)out_t[l] * wns(in_t[l]) * 128;
     pk.AT[l] = wp;
-    wp += (size_t)tiles[l] * wns(tiles[l + 1]) * 128;
-    a.A[l] = pk.A[l], a.AT[l] = pk.AT[l], a.b[l] = biases[l];
-    const int n1 = tiles[l + 1] * wns(tiles[l]) * 64, n2 = tiles[l] * wns(tiles[l + 1]) * 64;
+    wp += (size_t)in_t[l] * wns(out_t[l]) * 128;
+    a.A[l] = pk.A[l], a.AT[l] = pk.AT[l], a.b[l] = have ? biases[src[l]] : nullptr;
+    const int n1 = out_t[l] * wns(in_t[l]) * 64, n2 = in_t[l] * wns(out_t[l]) * 64;
     nmax = n1 > nmax ? n1 : nmax;
     nmax = n2 > nmax ? n2 : nmax;
   }
-  for (int i = 0; i < 5; i++) a.dims[i] = dims[i];
+  for (int i = 0; i < 5; i++) a.dims[i] = kd[i];
   a.overflow = wide_overflow_word();
   hipLaunchKernelGGL(mlp_wide_f16_pack_kernel, dim3((nmax + 255) / 256, 8), dim3(256), 0, st, pk);
   float* partial = reinterpret_cast<float*>(wp);
@@ -1205,10 +1235,17 @@ int wide_launch_f16(const int* dims, int64_t N, const float* X, const float* con
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WN * 64), lds_bytes, st, a, N, X, dY, dX, partial);
   WideArgs ar;
-  for (int i = 0; i < 5; i++) ar.dims[i] = dims[i];
+  for (int i = 0; i < 5; i++) ar.dims[i] = kd[i];
   for (int l = 0; l < 4; l++) ar.W[l] = ar.WT[l] = ar.b[l] = nullptr;
-  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3, T4>), dim3((GI::TOTAL + 255) / 256, 8), dim3(256), 0, st, partial,
-                     (int)blocks, ar, dW[0], dW[1], dW[2], dW[3], db[0], db[1], db[2], db[3]);
+  float* gw[4];
+  float* gb[4];
+  for (int l = 0; l < 4; l++) {
+    gw[l] = src[l] >= 0 ? dW[src[l]] : nullptr;
+    gb[l] = src[l] >= 0 ? db[src[l]] : nullptr;
+  }
+  // (the small nets' images: 32 slices of the workgroup images instead of 8 -- their summing launch waits on loads, not on bytes)
+  hipLaunchKernelGGL((mlp_wide_reduce_kernel<TI0, T1, T2, T3, T4>), dim3((GI::TOTAL + 255) / 256, GI::TOTAL < 20000 ? 32 : 8), dim3(256), 0, st, partial,
+                     (int)blocks, ar, gw[0], gw[1], gw[2], gw[3], gb[0], gb[1], gb[2], gb[3]);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
 }
@@ -1341,11 +1378,22 @@ int psdf_lipshitz_normalize_backward_multi(int n_layers, const int* out, const i
 int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
                            const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db,
                            void* stream) {
-  if (n_layers != 4 || !dims || !dW || !db) return PSDF_ERR_UNSUPPORTED;
+  if ((n_layers != 4 && n_layers != 3) || !dims || !dW || !db) return PSDF_ERR_UNSUPPORTED;
   if (N <= 0 || !X || !weights || !biases || !dY) return PSDF_ERR_ARG;
-  for (int l = 0; l < 4; l++)
+  for (int l = 0; l < n_layers; l++)
     if (!weights[l] || !biases[l] || !dW[l] || !db[l]) return PSDF_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (n_layers == 3) {
+    // two hidden layers: the background colour head 80 -> 64 -> 64 -> 3 (models.py:463-469), split-fp16 kernel only (round 6)
+    const char* sp3 = getenv("PSDF_MLP_WIDE_SPLIT");
+    uint32_t* ov3 = wide_overflow_word();
+    if ((sp3 && sp3[0] == 'f' && sp3[1] == '3') || (ov3 && *(volatile uint32_t*)ov3)) return PSDF_ERR_UNSUPPORTED;
+    if (dims[0] > 64 && dims[0] <= 80 && dims[1] > 32 && dims[1] <= 64 && dims[2] > 32 && dims[2] <= 64 && dims[3] <= 16) {
+      g_wide_form = 2;
+      return wide_launch_f16<5, 4, 4, 0, 1>(3, dims, N, X, weights, biases, dY, dX, dW, db, st);
+    }
+    return PSDF_ERR_UNSUPPORTED;
+  }
   // PSDF_MLP_WIDE_SPLIT = f16 (default: two fp16 pieces per operand on the fp16 matrix pipe) | f32 (fp32 MFMAs); a value that left
   // the fp16 range in an earlier launch (host-mapped flag) switches the process to the fp32 kernel
   const char* sp = getenv("PSDF_MLP_WIDE_SPLIT");
@@ -1364,7 +1412,7 @@ int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float
   // the colour network (111 -> 128 -> 128 -> 64 -> 3) and anything that fits its tile counts with one output tile
   if (dims[0] <= 112 && dims[1] <= 128 && dims[2] <= 128 && dims[3] <= 64 && dims[4] <= 16 && !(dims[1] <= 64 && dims[2] <= 64)) {
     if (f16) {
-      const int r = wide_launch_f16<7, 8, 8, 4, 1>(dims, N, X, weights, biases, dY, dX, dW, db, st);
+      const int r = wide_launch_f16<7, 8, 8, 4, 1>(4, dims, N, X, weights, biases, dY, dX, dW, db, st);
       if (r != PSDF_ERR_UNSUPPORTED) return r;
       g_wide_form = 1;
     }
@@ -1373,7 +1421,7 @@ int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float
   // the background density / feature net (52 -> 64 x 3 -> 65) and its 33-output sibling: up to 80 outputs, 64-wide hidden layers
   if (dims[0] <= 64 && dims[1] <= 64 && dims[2] <= 64 && dims[3] <= 64 && dims[4] > 16 && dims[4] <= 80) {
     if (f16) {
-      const int r = wide_launch_f16<4, 4, 4, 4, 5>(dims, N, X, weights, biases, dY, dX, dW, db, st);
+      const int r = wide_launch_f16<4, 4, 4, 4, 5>(4, dims, N, X, weights, biases, dY, dX, dW, db, st);
       if (r != PSDF_ERR_UNSUPPORTED) return r;
       g_wide_form = 1;
     }

@@ -296,9 +296,11 @@ def test_split_bf16_backward_matches_float64(dev, K0, N):
 @pytest.mark.parametrize("arith", ["f32", "f16"])
 @pytest.mark.parametrize("dy_scale", [1.0, 1e-6, "wide"])
 @pytest.mark.parametrize("dims,N", [([111, 128, 128, 64, 3], 49_152), ([112, 128, 128, 64, 3], 5_003), ([100, 96, 128, 48, 2], 777),
-                                    ([52, 64, 64, 64, 65], 23_001), ([36, 64, 64, 64, 33], 4_096)])
+                                    ([52, 64, 64, 64, 65], 23_001), ([36, 64, 64, 64, 33], 4_096),
+                                    ([80, 64, 64, 3], 22_753), ([70, 60, 50, 3], 1_001)])
 def test_wide_net_backward_matches_float64(dev, dims, N, dy_scale, arith, monkeypatch):
-    """csrc/mlp_wide.hip (the colour network's widths, models.py:349-350, and the background density net's) through
+    """csrc/mlp_wide.hip (the colour network's widths, models.py:349-350, the background density net's and -- two hidden layers,
+    split-fp16 kernel only -- the background colour head's, models.py:463-469) through
     psdf_mlp_backward, both workgroup-cooperative kernels: fp32 MFMAs (no worse than 4x torch's fp32 backward against float64) and,
     since round 6 the default, two fp16 pieces per operand on the fp16 matrix pipe (2e-5 of the largest entry, the bar of the SDF
     net's split-fp16 kernel); upstream gradients of ordinary size, tiny (1e-6: fp16 subnormals without the per-sample scaling) and
@@ -310,10 +312,14 @@ def test_wide_net_backward_matches_float64(dev, dims, N, dy_scale, arith, monkey
     assert backward_supported(dims)
     monkeypatch.setenv("PSDF_MLP_WIDE_SPLIT", arith)
     torch.manual_seed(N)
-    lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(4)]
-    net = torch.nn.Sequential(lin[0], torch.nn.GELU(), lin[1], torch.nn.GELU(), lin[2], torch.nn.GELU(), lin[3]).to(dev)
+    nl = len(dims) - 1
+    lin = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(nl)]
+    mods = []
+    for i, l in enumerate(lin):
+        mods += [l] + ([torch.nn.GELU()] if i < nl - 1 else [])
+    net = torch.nn.Sequential(*mods).to(dev)
     x = torch.randn(N, dims[0], device=dev)
-    gy = torch.randn(N, dims[4], device=dev)
+    gy = torch.randn(N, dims[-1], device=dev)
     gy = gy * (10.0 ** (-6.0 * torch.rand(N, 1, device=dev)) if dy_scale == "wide" else dy_scale)
     net64 = copy.deepcopy(net).double()
     x64 = x.double().requires_grad_(True)
@@ -327,7 +333,12 @@ def test_wide_net_backward_matches_float64(dev, dims, N, dy_scale, arith, monkey
     dx, dWs, dbs = mlp_backward_raw(dims, x.t().contiguous(), ws, bs, gy.t().contiguous(), need_dx=True)
     form = L.lib().psdf_mlp_backward_wide_form
     form.restype = ctypes.c_int
-    assert form() == (2 if arith == "f16" else 1)
+    fn = L.lib().psdf_last_path
+    fn.restype = ctypes.c_int
+    if nl == 3 and arith == "f32":
+        assert int(fn(ctypes.c_int(1))) == 1        # two hidden layers: the fp32 form is the single-wave kernel of mlp_bwd.hip
+    else:
+        assert form() == (2 if arith == "f16" else 1) and int(fn(ctypes.c_int(1))) == 3
     got = [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
     errs = []
     for i, (g, r, t) in enumerate(zip(got, ref, t32)):
