@@ -402,13 +402,19 @@ struct Img {
   static constexpr int TOTAL = WF + (FINAL_DOT ? 4 * TL * 16 : 0);
 };
 
-__device__ __forceinline__ float ld_w(const float* W, int rows, int cols, int row, int col) {
-  return (row < rows && col < cols) ? W[(int64_t)row * cols + col] : 0.f;
+// (clamped address + select, not a guarded load: a guarded load is a branch on the exec mask, and the staging loops below then
+//  run one load -> wait -> store per iteration -- 5.5 us per workgroup for the SDF net's 9.7 K image entries, more than the tiles
+//  of a training step's batch take; unconditional loads are issued together, round 6)
+__device__ __forceinline__ float ld_w(const float* __restrict__ W, int rows, int cols, int row, int col) {
+  const int rr = row < rows ? row : rows - 1, cc = col < cols ? col : cols - 1;
+  const float v = W[rr * cols + cc];
+  return (row < rows && col < cols) ? v : 0.f;
 }
 // stage one chain-layer pair of images (forward + transposed) of W [rows x cols]
 __device__ __forceinline__ void stage_chain(float* fwd, float* bwd, const float* W, int rows, int cols, int TO, int TI,
                                             int tid, int nthreads) {
   const int n = TO * TI * 256;
+#pragma unroll 4
   for (int e = tid; e < n; e += nthreads) {
     const int r = e & 3, lane = (e >> 2) & 63, pr = e >> 8, ti = pr % TI, to = pr / TI;
     const int g = lane >> 4, c = lane & 15;
@@ -476,6 +482,7 @@ __global__ void __launch_bounds__(NW * 64)
   {
     const int tid = threadIdx.x, nt = NW * 64;
     const int d0 = p.dims[0], d1 = p.dims[1], d2 = p.dims[2], d3 = p.dims[3];
+#pragma unroll 4
     for (int e = tid; e < T1 * TI0 * 256; e += nt) {  // layer 0: forward (k-steps by four) and transposed (dX)
       const int j = e & 3, ln = (e >> 2) & 63, gg = ln >> 4, cc = ln & 15;
       {
@@ -837,6 +844,7 @@ __global__ void __launch_bounds__(BW * 64)
   {
     const int tid = threadIdx.x, nt = BW * 64;
     const int d0 = p.dims[0], d1 = p.dims[1], d2 = p.dims[2], d3 = p.dims[3];
+#pragma unroll 4
     for (int e = tid; e < T1 * TI0 * 256; e += nt) {
       const int j = e & 3, ln = (e >> 2) & 63, gg = ln >> 4, cc = ln & 15;
       {
@@ -1172,15 +1180,19 @@ int launch_bwd_nw(const Plan16& p, int64_t N, const float* X, const float* dY, f
   if (blocks > 256) blocks = 256;  // one workgroup per CU; each wave walks many tiles
   using IM = Img<TI0, T1, T2, T3, FINAL_DOT ? 1 : OUT_T, FINAL_DOT>;
   const int img = IM::TOTAL > p.total ? IM::TOTAL : ((p.total + 3) & ~3);
-  if (!a.dW[0]) {  // data gradient only: no accumulators -> more waves per CU, more workgroups
+  if (!a.dW[0]) {  // data gradient only: no accumulators -> two workgroups per CU
     if (!dX) return PSDF_OK;
     const size_t shmem = ((size_t)img + BW * (16 * 17 + 16 + 2 * 4 * TI0 * 64)) * sizeof(float);
     if (shmem > 160 * 1024) return PSDF_ERR_UNSUPPORTED;
     auto kern = mlp_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, true, false, BW>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return (int)e;
+    // ONE resident round of workgroups (two per CU): staging the weight image is 5.6 us of index arithmetic per workgroup, as
+    // long as two tiles of the SDF net, so a second round costs more than a longer walk (round 6, tools/small_batch_bench.py
+    // 52-32-32-32-33 at 49 152 / 262 144 samples: 1024 workgroups 30.0 / 92.8 us, 512: 25.4 / 86.6, 256: 28.2 / 108.7; eight waves
+    // per workgroup sharing one image: 25.1 / 83.2 at 256 workgroups -- no better, not kept)
     int64_t nb = (ntiles + BW - 1) / BW;
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(BW * 64), shmem, st, p, N, X, dY, dX, a);
     PSDF_LAUNCH_CHECK();
     return PSDF_OK;
