@@ -54,6 +54,8 @@ class Pcg32:
 
 
 def _f32c(t):
+    if t.dtype is torch.float32 and t.is_contiguous():      # (the usual case, without two dispatcher round trips)
+        return t
     return t.to(torch.float32).contiguous()
 
 
@@ -63,6 +65,8 @@ def _check2d(t, cols, name):
 
 
 def _vec3(v):
+    if type(v) is list and len(v) == 3 and type(v[0]) is float:
+        return v
     v = [float(x) for x in (v.tolist() if hasattr(v, "tolist") else v)]
     if len(v) != 3:
         raise ValueError("expected a 3-vector")

@@ -37,6 +37,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self.__dict__.pop("_small_ok", None)
         for p in getattr(self, "_touched", {}):
             self._rebuild_active(p)
         # a (consolidated) checkpoint holds FULL moments; under the sharded update a rank must hold zeros outside the ranges it
@@ -90,11 +91,13 @@ class FusedAdamW(torch.optim.Optimizer):
             self._moments_loaded = False
         self.generation += 1
         blocks_pending = []
+        touched_rows = getattr(self, "_touched", {})
+        small_cache = self.__dict__.setdefault("_small_ok", {})
         for group in self.param_groups:
             b1, b2 = group["betas"]
             small = {}   # step count -> [(p, g, m, v)]
             for p in group["params"]:
-                tr = getattr(self, "_touched", {}).get(p)
+                tr = touched_rows.get(p)
                 if tr is not None:
                     st = self.state[p]
                     if not st:
@@ -115,6 +118,9 @@ class FusedAdamW(torch.optim.Optimizer):
                         if lo % be or hi % be:
                             raise L.PsdfError("owned ranges of a touched-rows parameter must be aligned to its row blocks")
                         blo, bhi = lo // be, hi // be
+                        if lo == 0 and hi == pf.numel() and group["weight_decay"] == 0.0:   # the whole tensor (no data parallel
+                            blocks_pending.append((bhi, be, pf, gf, mf, vf, tf, af, group["lr"], b1, b2, group["eps"], st["step"]))
+                            continue                                                        # sharding): no slicing, eight views less
                         if group["weight_decay"] != 0.0:       # every row moves: dense update from the same buffer
                             L.call("psdf_adamw_step", L.c_l(hi - lo), L.ptr(pf[lo:hi]), L.ptr(gf[lo:hi]), L.ptr(mf[lo:hi]),
                                    L.ptr(vf[lo:hi]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
@@ -155,8 +161,11 @@ class FusedAdamW(torch.optim.Optimizer):
                                L.ptr(vf[lo:hi]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
                                L.c_f(group["weight_decay"]), L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())
                     continue
-                aligned = all(t.data_ptr() % 16 == 0 for t in (p, g, st["exp_avg"], st["exp_avg_sq"]))
-                if p.numel() < self.SMALL and aligned:
+                small_ok = small_cache.get(p)       # (parameter and moments do not move between steps: checked once; dropped by
+                if small_ok is None:                # load_state_dict, which replaces the moments)
+                    small_ok = small_cache[p] = (p.numel() < self.SMALL
+                                                 and all(t.data_ptr() % 16 == 0 for t in (p, st["exp_avg"], st["exp_avg_sq"])))
+                if small_ok and g.data_ptr() % 16 == 0:
                     small.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
                     continue
                 L.call("psdf_adamw_step", L.c_l(p.numel()), L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),

@@ -33,33 +33,46 @@ from .neus import (eikonal_loss_raw, l1_loss_raw, nerf_composite_backward_raw, n
 from .train_step import Trainer, map_range_val
 
 
-def _enc_fwd(enc, pts, win, train=True):
-    tr = enc.touched_rows
-    return encode_forward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
-                              touched=tr.touched if train else None, block_rows_log2=tr.block_rows_log2)
+def _raw(enc):
+    """(cfg, lattice, scale factors, shifts, touched-rows record) of an encoding as the raw kernels take them.  Kept on the module:
+    a step asks 17 times, and every ask is five nn.Module attribute lookups and two detach() calls on the host -- the step is host
+    bound at iteration 0 (tools/prof_step.py).  Rebuilt when the parameter's storage has moved (.to(), load of a new tensor) or the
+    touched-rows record was replaced."""
+    lat = enc._parameters["lattice_values"]
+    r = enc.__dict__.get("_psdf_raw")
+    if r is None or r[5] != lat.data_ptr() or r[4] is not enc.__dict__.get("touched_rows"):
+        r = (enc.cfg, lat.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), enc.touched_rows, lat.data_ptr())
+        enc.__dict__["_psdf_raw"] = r
+    return r
+
+
+def _enc_fwd(enc, pts, win, train=True, out=None):
+    cfg, lat, sf, sh, tr, _ = _raw(enc)
+    return encode_forward_raw(cfg, pts, lat, sf, sh, win, out=out, touched=tr.touched if train else None,
+                              block_rows_log2=tr.block_rows_log2)
 
 
 def _enc_bwd(enc, pts, win, g_fm, want_pos=False, want_lattice=True):
     """lattice gradient into the encoding's persistent buffer; optionally the position gradient [N, P]"""
     g_pos = torch.zeros_like(pts) if want_pos else None
-    encode_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win, g_fm,
-                        enc.touched_rows.grad if want_lattice else None, g_pos)
+    cfg, lat, sf, sh, tr, _ = _raw(enc)
+    encode_backward_raw(cfg, pts, lat, sf, sh, win, g_fm, tr.grad if want_lattice else None, g_pos)
     return g_pos
 
 
 def _enc_dbl_gather(enc, pts, win, dd_pos, g_fm):
     """backward of the position gradient, first half: the gradient w.r.t. the feature gradient [C, N] (a gather)"""
     gg = torch.empty_like(g_fm)
-    encode_double_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
-                               dd_pos, g_fm, None, gg)
+    cfg, lat, sf, sh, _, _ = _raw(enc)
+    encode_double_backward_raw(cfg, pts, lat, sf, sh, win, dd_pos, g_fm, None, gg)
     return gg
 
 
 def _enc_dbl_scatter(enc, pts, win, dd_pos, g_fm, direct_fm):
     """second half, together with the plain backward of `direct_fm` (the gradient that reached the features): ONE scatter of both
     into the lattice buffer -- they land on the same rows of the same simplices"""
-    encode_double_backward_raw(enc.cfg, pts, enc.lattice_values.detach(), enc.scale_factor, enc.random_shift_per_level.detach(), win,
-                               dd_pos, g_fm, enc.touched_rows.grad, None, direct_fm)
+    cfg, lat, sf, sh, tr, _ = _raw(enc)
+    encode_double_backward_raw(cfg, pts, lat, sf, sh, win, dd_pos, g_fm, tr.grad, None, direct_fm)
 
 
 def _normalize3(x, gy=None):

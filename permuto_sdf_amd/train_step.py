@@ -464,8 +464,9 @@ class Trainer:
         pinned[:R].copy_(pool._ray_counts, non_blocking=True)
         event = torch.cuda.Event()
         event.record()
+        # (the centre as the host list: handed the CUDA tensor the bridge has to read it back -- a stream sync per step)
         bg = None if self.with_mask else RaySampler.compute_samples_bg(o, d, tx, hp.nr_samples_bg, self.sphere.m_radius,
-                                                                       self.sphere.m_center_tensor, jitter, False)
+                                                                       self.sphere.m_center, jitter, False)
         return dict(o=o, d=d, tx=tx, pool=pool, bg=bg, counts=pinned[:R], event=event, jitter=jitter)
 
     def _pinned(self, R):
