@@ -179,7 +179,9 @@ int psdf_mlp_backward_wide_form(void);
    dims[2] <= 128, dims[3] <= 64, dims[4] <= 16): the colour network LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3 of
    permuto_sdf_py/models/models.py:54-129,349-350 (weights = the already normalised ones).  Workgroup-cooperative: 8 waves
    share a 32-sample tile through LDS, each owns one output tile per layer.  -2 for other widths / no stream-ordered scratch;
-   psdf_mlp_backward falls through to it. */
+   psdf_mlp_backward falls through to it.  Also (split-fp16 kernel only): the 64-wide nets with many outputs (background density
+   net 52 -> 64 x 3 -> 65, models.py:451-459) and, with n_layers = 3, the background colour head 80 -> 64 -> 64 -> 3
+   (models.py:463-469: 64 < dims[0] <= 80, 32 < dims[1], dims[2] <= 64, dims[3] <= 16). */
 int psdf_mlp_backward_wide(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
     const float* const* biases, const float* dY, float* dX, float* const* dW, float* const* db, void* stream);
 
