@@ -161,10 +161,14 @@ class FusedAdamW(torch.optim.Optimizer):
                                L.ptr(vf[lo:hi]), L.c_f(group["lr"]), L.c_f(b1), L.c_f(b2), L.c_f(group["eps"]),
                                L.c_f(group["weight_decay"]), L.c_i(st["step"]), L.c_f(float(grad_scale)), L.stream())
                     continue
-                small_ok = small_cache.get(p)       # (parameter and moments do not move between steps: checked once; dropped by
-                if small_ok is None:                # load_state_dict, which replaces the moments)
-                    small_ok = small_cache[p] = (p.numel() < self.SMALL
-                                                 and all(t.data_ptr() % 16 == 0 for t in (p, st["exp_avg"], st["exp_avg_sq"])))
+                # (parameter and moments do not move between steps: their alignment is checked once per (moment tensors, address of
+                #  the parameter) -- p.data = ..., .to() or a reloaded state are seen)
+                c = small_cache.get(p)
+                if c is None or c[1] is not st["exp_avg"] or c[2] is not st["exp_avg_sq"] or c[3] != p.data_ptr():
+                    c = small_cache[p] = (p.numel() < self.SMALL
+                                          and all(t.data_ptr() % 16 == 0 for t in (p, st["exp_avg"], st["exp_avg_sq"])),
+                                          st["exp_avg"], st["exp_avg_sq"], p.data_ptr())
+                small_ok = c[0]
                 if small_ok and g.data_ptr() % 16 == 0:
                     small.setdefault(st["step"], []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
                     continue

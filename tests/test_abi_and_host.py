@@ -271,3 +271,24 @@ def test_binned_backward_plan_refuses_what_its_32_bit_offsets_cannot_address(lib
     assert 0 < small < bench < big
     assert bench >= (1 << 21) * 4 * 16 * 10          # room for every contribution: u16 row + two floats each
     assert ws(1 << 28) == 0                          # 2^30 contributions per level: 10 GiB of queue values per level slice
+
+
+def test_cached_raw_views_of_an_encoding_follow_the_parameter():
+    """train_manual._raw caches (cfg, detached lattice, scale factors, shifts, touched-rows record) on the module (the hand-written
+    step asks 17 times per iteration); the cache must notice a lattice whose storage moved and a replaced touched-rows record"""
+    from permuto_sdf_amd.encoding import PermutoEncoding
+    from permuto_sdf_amd.train_manual import _raw
+    enc = PermutoEncoding(3, 256, 4, 2, [1.0, 2.0, 4.0, 8.0])
+    tr0 = enc.enable_touched_rows()
+    r0 = _raw(enc)
+    assert r0 is _raw(enc)                                     # second ask: the cached tuple
+    assert r0[1].data_ptr() == enc.lattice_values.data_ptr() and not r0[1].requires_grad and r0[4] is tr0
+    with torch.no_grad():                                      # in-place writes (optimizer, load_state_dict) keep the views valid
+        enc.lattice_values.add_(1.0)
+    assert _raw(enc) is r0 and torch.equal(r0[1], enc.lattice_values.detach())
+    enc.lattice_values.data = enc.lattice_values.data.clone()  # storage moved (what .to(device) does)
+    r1 = _raw(enc)
+    assert r1 is not r0 and r1[1].data_ptr() == enc.lattice_values.data_ptr()
+    tr1 = enc.enable_touched_rows()                            # a new record (its buffers are what the backward accumulates into)
+    r2 = _raw(enc)
+    assert r2 is not r1 and r2[4] is tr1

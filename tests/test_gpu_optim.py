@@ -104,3 +104,36 @@ def test_sharded_step_after_a_resume_clears_the_moments_it_does_not_own(dev):
     q.grad = torch.randn(n, device=dev)
     opt2.step(owned={q: [(lo, hi)]})
     assert float(st["exp_avg"][:lo].abs().max()) == 0.0
+
+
+def test_alignment_cache_of_small_parameters_sees_moved_moments(dev):
+    """FusedAdamW batches small 16-byte aligned parameters into one launch with vector loads and remembers the alignment check per
+    parameter (round 6: the training step is host bound).  Replaced moment tensors must be re-examined: aligned ones keep matching
+    torch.optim.AdamW; MISALIGNED ones (a view into a flat buffer) must not reach the vector kernel -- the scalar launch refuses
+    them loudly (status -1), as it always did."""
+    import pytest
+    from permuto_sdf_amd import _lib as L
+    from permuto_sdf_amd.optim import FusedAdamW
+    torch.manual_seed(3)
+    a = torch.nn.Parameter(torch.randn(1000, device=dev))
+    b = torch.nn.Parameter(a.detach().clone())
+    ours, ref = FusedAdamW([a], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0), \
+        torch.optim.AdamW([b], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, weight_decay=0.0)
+    for it in range(5):
+        g = torch.randn(1000, device=dev)
+        a.grad, b.grad = g.clone(), g.clone()
+        if it == 2:      # new (aligned) moment tensors, as load_state_dict leaves them
+            st = ours.state[a]
+            st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+        ours.step()
+        ref.step()
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), it
+    st = ours.state[a]
+    flat = torch.zeros(1008, device=dev)
+    view = flat[1:1001]
+    assert view.data_ptr() % 16 != 0
+    view.copy_(st["exp_avg"])
+    st["exp_avg"] = view
+    a.grad = torch.randn(1000, device=dev)
+    with pytest.raises(L.PsdfError):
+        ours.step()
