@@ -67,6 +67,11 @@ def _check2d(t, cols, name):
 def _vec3(v):
     if type(v) is list and len(v) == 3 and type(v[0]) is float:
         return v
+    # a tensor this package made from a host vector (Sphere.m_center_tensor: what train_permuto_sdf.py hands to
+    # compute_samples_bg every iteration) carries that vector: no read-back -- a stream synchronisation -- while it is unmodified
+    h = getattr(v, "_psdf_host3", None)
+    if h is not None and h[1] == v._version:
+        return h[0]
     v = [float(x) for x in (v.tolist() if hasattr(v, "tolist") else v)]
     if len(v) != 3:
         raise ValueError("expected a 3-vector")
@@ -244,6 +249,7 @@ class Sphere:
         self.m_center = _vec3(center)
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.m_center_tensor = torch.tensor(self.m_center, dtype=torch.float32, device=dev)
+        self.m_center_tensor._psdf_host3 = (self.m_center, self.m_center_tensor._version)
 
     def ray_intersection(self, ray_origins, ray_dirs):
         _check2d(ray_origins, 3, "ray_origins")
