@@ -527,12 +527,14 @@ def lipshitz_normalize_all_raw(weights, bounds):
     return outs
 
 
-def lipshitz_normalize_all_backward_raw(weights, bounds, grads):
-    """-> ([dW_l], [dc_l]) for dL/dWn_l = grads[l], one launch"""
+def lipshitz_normalize_all_backward_raw(weights, bounds, grads, dc_flat=None):
+    """-> ([dW_l], [dc_l]) for dL/dWn_l = grads[l], one launch.  dc_flat: a ZERO-filled [4 * n] tensor to hold the dc_l (one fill
+    shared with other buffers of the caller's step), else one is filled here"""
     ws, cs = [w.detach().contiguous() for w in weights], [c.detach().contiguous() for c in bounds]
     gs = [g.contiguous() for g in grads]
     dws = [torch.empty_like(w) for w in ws]
-    dc_flat = torch.zeros(4 * len(cs), dtype=torch.float32, device=ws[0].device)   # one fill; every [1] slice 16-byte aligned
+    if dc_flat is None:
+        dc_flat = torch.zeros(4 * len(cs), dtype=torch.float32, device=ws[0].device)   # one fill; every [1] slice 16-byte aligned
     dcs = [dc_flat[4 * i:4 * i + 1] for i in range(len(cs))]                        # (the fused optimiser batches aligned tensors)
     n = len(ws)
     L.call("psdf_lipshitz_normalize_backward_multi", L.c_i(n), (ctypes.c_int * n)(*[w.shape[0] for w in ws]),

@@ -26,8 +26,8 @@ import torch
 from . import _lib as L
 from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
 from .encoding import encode_backward_raw, encode_double_backward_raw, encode_forward_raw
-from .mlp import (mlp_forward_wide_f16_raw, lipshitz_normalize_all_backward_raw, lipshitz_normalize_all_raw, mlp_backward_raw, mlp_double_backward, mlp_forward_raw,
-                  pack_params)
+from .mlp import (_grad_views, mlp_forward_wide_f16_raw, lipshitz_normalize_all_backward_raw, lipshitz_normalize_all_raw, mlp_backward_raw,
+                  mlp_double_backward, mlp_forward_raw, pack_params)
 from .neus import (eikonal_loss_raw, l1_loss_raw, nerf_composite_backward_raw, nerf_composite_forward_raw, neus_composite_backward_raw,
                    neus_composite_forward_raw, sigmoid_rows_backward_raw, sigmoid_rows_raw)
 from .train_step import Trainer, map_range_val
@@ -52,9 +52,10 @@ def _enc_fwd(enc, pts, win, train=True, out=None):
                               block_rows_log2=tr.block_rows_log2)
 
 
-def _enc_bwd(enc, pts, win, g_fm, want_pos=False, want_lattice=True):
-    """lattice gradient into the encoding's persistent buffer; optionally the position gradient [N, P]"""
-    g_pos = torch.zeros_like(pts) if want_pos else None
+def _enc_bwd(enc, pts, win, g_fm, want_pos=False, want_lattice=True, zeroed=None):
+    """lattice gradient into the encoding's persistent buffer; optionally the position gradient [N, P] (the kernels accumulate:
+    `zeroed` = a zero-filled [N, P] tensor to use for it, else one is filled here)"""
+    g_pos = (zeroed if zeroed is not None else torch.zeros_like(pts)) if want_pos else None
     cfg, lat, sf, sh, tr, _ = _raw(enc)
     encode_backward_raw(cfg, pts, lat, sf, sh, win, g_fm, tr.grad if want_lattice else None, g_pos)
     return g_pos
@@ -99,6 +100,7 @@ class ManualTrainer(Trainer):
         self.prefetch_sampling = os.environ.get("PSDF_TRAIN_PREFETCH", "1") != "0"
         self._prefetched = None
         self._prefetch_side = None
+        self._pos_pool = None
         self._events = [torch.cuda.Event() for _ in range(4)] if self.dev.type == "cuda" else []
 
     def _side_stream(self):
@@ -179,8 +181,35 @@ class ManualTrainer(Trainer):
         dims = self.sdf.mlp_sdf.dims
         e0 = None       # "the unit gradient of output 0": the kernels take NULL for it (no [33, N] tensor that is 1 in one row)
         dfeat, _, _ = mlp_backward_raw(dims, feat, ws, bs, e0, need_dx=True, need_dw=False)
-        n = _enc_bwd(self.sdf.encoding, pts, win, dfeat, want_pos=True, want_lattice=False)
+        n = _enc_bwd(self.sdf.encoding, pts, win, dfeat, want_pos=True, want_lattice=False, zeroed=self._zeroed_pos(pts))
         return n, dfeat, e0
+
+    def _zeroed_pos(self, pts):
+        """a zero-filled [N, 3] tensor for a position gradient: the step needs three of the same size (normals of the samples, of
+        the shifted samples, gradient of the shifted points) -- ONE fill launch for the three instead of one each"""
+        pool = self._pos_pool
+        if pool is None or pool[0].shape[1:] != pts.shape or pool[1] >= pool[0].shape[0]:
+            pool = self._pos_pool = [torch.zeros((3,) + tuple(pts.shape), dtype=torch.float32, device=pts.device), 0]
+        pool[1] += 1
+        return pool[0][pool[1] - 1]
+
+    def _grad_arena(self):
+        """zero-filled parameter-gradient views for the three nets without a persistent gradient buffer (background density net,
+        background colour head, colour network's normalised weights) and the four Lipschitz bounds: ONE fill launch per step
+        instead of four (the kernels accumulate into what they are given) -> (bg1, bg2, rgb, dc_flat), each (dWs, dbs)"""
+        lay = self.__dict__.get("_arena_layout")
+        if lay is None:
+            def need(dims):
+                return sum(((dims[l + 1] * dims[l] + 3) & ~3) + ((dims[l + 1] + 3) & ~3) for l in range(len(dims) - 1))
+            d1, d2, dc = self.bg.mlp_feat_and_density.dims, self.bg.mlp_rgb.dims, self.rgb.mlp.dims
+            offs = [0]
+            for sz in (need(d1), need(d2), need(dc), 4 * (len(dc) - 1)):
+                offs.append(offs[-1] + sz)
+            lay = self._arena_layout = (offs, d1, d2, dc)
+        offs, d1, d2, dc = lay
+        flat = torch.zeros(offs[-1], dtype=torch.float32, device=self.dev)
+        views = [_grad_views(d, flat=flat[offs[i]:offs[i + 1]])[1:] for i, d in enumerate((d1, d2, dc))]
+        return views[0], views[1], views[2], flat[offs[3]:offs[4]]
 
     def _sdf_gradient_backward(self, g_n, feat, dfeat, e0, pts, win, ws, bs, gb, want_pos=False, extra_dfeat=None):
         """backward of  n = d sdf / d p  for an upstream g_n [N,3]: lattice and parameter gradients are accumulated; returns the
@@ -191,7 +220,7 @@ class ManualTrainer(Trainer):
         if extra_dfeat is not None:
             dX2 = dX2 + extra_dfeat
         _enc_dbl_scatter(enc, pts, win, g_n, dfeat, dX2)
-        return _enc_bwd(enc, pts, win, dX2, want_pos=True, want_lattice=False) if want_pos else None
+        return _enc_bwd(enc, pts, win, dX2, want_pos=True, want_lattice=False, zeroed=self._zeroed_pos(pts)) if want_pos else None
 
     # ------------------------------------------------------------------ the background branch (NerfHash, models.py:431-526)
     def _bg_forward(self, bg, calib):
@@ -237,10 +266,10 @@ class ManualTrainer(Trainer):
             g_pre_b_fm = (g_pre_b * cw.index_select(0, B["ridx"])).t().contiguous()
         else:
             g_pre_b_fm = sigmoid_rows_backward_raw(g_rgbb, rgbb)                          # [3, M], one launch
-        dX2b, dW2b, db2b = mlp_backward_raw(B["d2"], B["x2"], B["w2b"], B["b2b"], g_pre_b_fm, need_dx=True)
+        dX2b, dW2b, db2b = mlp_backward_raw(B["d2"], B["x2"], B["w2b"], B["b2b"], g_pre_b_fm, need_dx=True, into=B.get("into2"))
         _set_grads(B["l2b"], dW2b, db2b)
         g_fd = torch.cat([g_raw.view(1, -1), torch.ops.aten.gelu_backward(dX2b[:64], B["fd"][1:65])], 0)      # [65, M]
-        dX4, dW1b, db1b = mlp_backward_raw(B["d1"], B["feat4"], B["w1b"], B["b1b"], g_fd, need_dx=True)
+        dX4, dW1b, db1b = mlp_backward_raw(B["d1"], B["feat4"], B["w1b"], B["b1b"], g_fd, need_dx=True, into=B.get("into1"))
         _set_grads(B["l1b"], dW1b, db1b)
         _enc_bwd(bgn.encoding, B["p4"], bgn._win, dX4)
         return g_cw, g_cb
@@ -312,6 +341,8 @@ class ManualTrainer(Trainer):
             inv_s = torch.exp(torch.tensor(float(forced_variance) * 10.0, dtype=torch.float32, device="cpu")).clip(1e-6, 1e6).view(1).to(dev)
             rgbn.last_inv_s = inv_s.view(())
             loss = L.zeroed_scalar(dev)     # ONE accumulator: every loss kernel of the step adds its (already weighted) term to it
+            self._pos_pool = None           # (zero-filled position gradients: a fresh pool per step)
+            arena = self._grad_arena()      # zero-filled parameter gradients of the nets without a persistent buffer: one fill
             # ================================================================= forward
             if "B" in early_bg:
                 B = early_bg["B"]
@@ -359,6 +390,7 @@ class ManualTrainer(Trainer):
             # networks' backward leaves for the side stream while this one goes on with the SDF losses
             g_raw, g_rgbb, g_bgT = nerf_composite_backward_raw(bg, hp.nr_samples_bg, g_pred, raw_den, rgbb, bgT)
             fork(self._events[2])
+            B["into1"], B["into2"] = arena[0], arena[1]
             with side_ctx():
                 g_cw_bg, g_cb_bg = self._bg_backward(B, g_raw, g_rgbb, calib, R)
             if side is None:
@@ -404,8 +436,8 @@ class ManualTrainer(Trainer):
                     g_pre_fm = (g_pre * cw.index_select(0, ridx_fg)).t().contiguous()
                 else:
                     g_pre_fm = sigmoid_rows_backward_raw(g_rgb, rgb)
-                dXr, dWn, dbr = mlp_backward_raw(m.dims, x_rgb, wn, bsr, g_pre_fm, need_dx=True)
-                dws, dcs = lipshitz_normalize_all_backward_raw(m.weights_per_layer, m.lipshitz_bound_per_layer, dWn)
+                dXr, dWn, dbr = mlp_backward_raw(m.dims, x_rgb, wn, bsr, g_pre_fm, need_dx=True, into=arena[2])
+                dws, dcs = lipshitz_normalize_all_backward_raw(m.weights_per_layer, m.lipshitz_bound_per_layer, dWn, dc_flat=arena[3])
                 for i, (w, c) in enumerate(zip(m.weights_per_layer, m.lipshitz_bound_per_layer)):
                     w.grad, c.grad, m.biases_per_layer[i].grad = dws[i], dcs[i].view_as(c), dbr[i]
                 _enc_bwd(rgbn.encoding, pts, rgbn._win, dXr[:c_enc])

@@ -69,4 +69,9 @@ def test_early_reduce_and_deferred_gather_equal_the_serialised_schedule(dev, sta
         assert scale > 0 and err <= max(3.0 * noise, 1e-5 * scale), (k, err, noise, scale)
     noise = float((loss_ref - loss_ref2).abs().max())
     print("losses", loss_ref.tolist(), loss_got.tolist(), "noise", noise)
-    assert float((loss_ref - loss_got).abs().max()) <= max(5.0 * noise, 1e-3 * float(loss_ref.abs().max()))
+    # first step: same state in every run -- the loss must agree to the last bits.  Later steps: the runs have drifted apart by
+    # then (Adam on the atomics' last-bit noise, see above; two serialised runs differ by up to ~0.5 % of the loss, and ONE draw of
+    # that difference is no bar: 1 run in 3 exceeded 5x of it) -- a parameter read before its all-gather landed is a NaN (the
+    # double's sentinel), one step's stale table moves the loss by the step-to-step change (7 - 15 % here): 1.5 % separates them
+    assert abs(float(loss_ref[0] - loss_got[0])) <= max(5.0 * abs(float(loss_ref[0] - loss_ref2[0])), 1e-5 * float(loss_ref[0].abs()))
+    assert float((loss_ref - loss_got).abs().max()) <= max(5.0 * noise, 1.5e-2 * float(loss_ref.abs().max()))
