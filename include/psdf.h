@@ -287,6 +287,14 @@ int psdf_mlp_backward(int n_layers, const int* dims, int64_t N, const float* X, 
 int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
     const float* const* biases, const float* dY, const float* V, float* dX2, float* const* dW, float* const* db,
     void* stream);
+/* the same pass with the plain backward of an upstream gradient dY2 [dims[n_layers], N] of the net's OUTPUTS folded in (round 6: the
+   training step runs both on the same samples -- g_y of (sdf, geometry features) beside g_n of the normals; one forward
+   recomputation, one backward sweep, one launch instead of psdf_mlp_backward + psdf_mlp_double_backward): dX2 = the double
+   backward's data gradient + the dX psdf_mlp_backward would return for dY2; dW[l] / db[l] accumulate both.  The reference's SDF net
+   shapes only (models.py:153-161: <= 64 inputs, 32 x 3 hidden, a matrix output layer of 5 .. 48 rows); -2 otherwise */
+int psdf_mlp_double_backward_plus(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+    const float* const* biases, const float* dY, const float* V, const float* dY2, float* dX2, float* const* dW,
+    float* const* db, void* stream);
 
 /* ---- fused.hip ---- */
 /* replaces: models.py:186-192 `point_features=self.encoding(points, window); sdf_and_feat=self.mlp_sdf(point_features)`

@@ -824,11 +824,17 @@ __device__ __forceinline__ void to_nt_all(const f32x4 (&in)[T], f32x4 (&out)[T],
   for (int t = 0; t < T; t++) to_nt(in[t], out[t], buf, g, c);
 }
 
-template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+// Y2 (round 6): the same pass also takes an upstream gradient dY2 [OUT, N] of the net's OUTPUTS -- the plain backward that the
+// training step runs right beside this one on the same samples (g_y of (sdf, geometry features) next to g_n of the normals).
+// The ordinary backward sweep is linear in what is injected into it, so dY2 enters as one more chain product and one more dW
+// block: dz3 += (W3^T dY2) * a3, dW3 += dY2 h3^T, db3 += dY2 -- one forward recomputation, one sweep, one staging and one flush
+// instead of two of each (216 + 352 -> 400 matrix instructions per tile); dX2 comes out as the SUM of both data gradients.
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool Y2 = false>
 __global__ void __launch_bounds__(BW * 64)
     mlp_dbl_bwd_kernel(Plan16 p, int64_t N, const float* __restrict__ X, const float* __restrict__ V,
-                       const float* __restrict__ dY, float* __restrict__ dX2, BwdPtrs a) {
+                       const float* __restrict__ dY, const float* __restrict__ dY2, float* __restrict__ dX2, BwdPtrs a) {
   static_assert(T3 > 0, "three hidden layers");
+  static_assert(!(Y2 && FINAL_DOT), "the fused plain backward exists for nets with a matrix output layer");
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int SX = 4 * TI0;
@@ -947,6 +953,7 @@ __global__ void __launch_bounds__(BW * 64)
     const bool live = n < N;
     // ---- forward: h, a = gelu', c = gelu''
     f32x4 h1[T1], a1[T1], c1[T1], h2[T2], a2[T2], c2[T2], a3[T3], c3[T3];
+    f32x4 h3k[Y2 ? T3 : 1];      // h3: the output layer's input, needed again for dW3 += dY2 h3^T
     {
       f32x4 z[T1];
       init_bias16<T1>(z, W + IM::BIAS1, g);
@@ -964,6 +971,10 @@ __global__ void __launch_bounds__(BW * 64)
       init_bias16<T3>(z, W + IM::BIAS3, g);
       chain_fwd4<T2, T3>(h2, z, W + IM::F2, lane);
       gelu3<T3>(z, h3, a3, c3);
+      if constexpr (Y2) {
+#pragma unroll
+        for (int t = 0; t < T3; t++) h3k[t] = h3[t];
+      }
     }
     // ---- first-order chain: q3 = W3^T gy ... u1
     f32x4 q3[T3], q2[T2], q1[T1];
@@ -1059,6 +1070,27 @@ __global__ void __launch_bounds__(BW * 64)
     // ---- ordinary backward sweep with the injected pre-activation gradients
     f32x4 dz3[T3];
     mul16<T3>(da3, c3, dz3);
+    if constexpr (Y2) {
+      f32x4 gyT[OTS];
+#pragma unroll
+      for (int to = 0; to < OTS; to++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = 16 * to + 4 * g + r;
+          gyT[to][r] = (row < OUT && live) ? dY2[(int64_t)row * N + n] : 0.f;
+        }
+      f32x4 dh3[T3];
+      zero16<T3>(dh3);
+      chain_bwd4<OTS, T3>(gyT, dh3, W + IM::BO, lane);                // W3^T dY2
+#pragma unroll
+      for (int t = 0; t < T3; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dz3[t][r] = dz3[t][r] + dh3[t][r] * a3[t][r];
+      f32x4 gy_nt[OTS], h3_nt[T3];
+      to_nt_all<OTS>(gyT, gy_nt, tbuf, g, c);
+      to_nt_all<T3>(h3k, h3_nt, tbuf, g, c);
+      acco.add(gy_nt, h3_nt);                                          // dW3 += dY2 h3^T, db3 += dY2
+    }
     {
       f32x4 dz_nt[T3], h_nt[T2];
       to_nt_all<T3>(dz3, dz_nt, tbuf, g, c);
@@ -1147,9 +1179,9 @@ __global__ void __launch_bounds__(BW * 64)
   BWD_STAMP(5);
 }
 
-template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT>
+template <int TI0, int T1, int T2, int T3, int OUT_T, bool FINAL_DOT, bool Y2 = false>
 int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, const float* dY, float* dX2,
-                   const BwdPtrs& a, hipStream_t st) {
+                   const BwdPtrs& a, hipStream_t st, const float* dY2 = nullptr) {
   using IM = Img<TI0, T1, T2, T3, FINAL_DOT ? 1 : OUT_T, FINAL_DOT>;
   const int img = IM::TOTAL > p.total ? IM::TOTAL : ((p.total + 3) & ~3);
   const size_t shmem = ((size_t)img + BW * (16 * 17 + 16 + 4 * 4 * TI0 * 64)) * sizeof(float);
@@ -1157,12 +1189,12 @@ int launch_dbl_bwd(const Plan16& p, int64_t N, const float* X, const float* V, c
   const int64_t ntiles = (N + 15) / 16;
   int64_t blocks = (ntiles + BW - 1) / BW;
   if (blocks > 256) blocks = 256;
-  auto kern = mlp_dbl_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT>;
+  auto kern = mlp_dbl_bwd_kernel<TI0, T1, T2, T3, OUT_T, FINAL_DOT, Y2>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   if (e != hipSuccess) return (int)e;
   BwdPtrs ap = a;
   ap.partial = grad_scratch_alloc((size_t)blocks * p.total, st);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, V, dY, dX2, ap);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BW * 64), shmem, st, p, N, X, V, dY, dY2, dX2, ap);
   grad_scratch_reduce(p, ap, (int)blocks, st);
   PSDF_LAUNCH_CHECK();
   return PSDF_OK;
@@ -1401,9 +1433,9 @@ int psdf_mlp_backward_data_masked(int n_layers, const int* dims, int64_t N, cons
 // Double backward (see mlp_dbl_bwd_kernel): V [dims[0], N] is the upstream gradient of the dX that psdf_mlp_backward
 // produced for the same X / parameters / dY.  dX2 [dims[0], N] receives the gradient wrt X; dW[l] / db[l] are
 // ACCUMULATED INTO.  Three hidden layers only; returns PSDF_ERR_UNSUPPORTED (-2) for widths without an instantiation.
-int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
-                             const float* const* biases, const float* dY, const float* V, float* dX2,
-                             float* const* dW, float* const* db, void* stream) {
+static int mlp_double_backward_impl(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                                    const float* const* biases, const float* dY, const float* V, const float* dY2, float* dX2,
+                                    float* const* dW, float* const* db, void* stream) {
   Plan16 p;
   int rc = make_plan16(n_layers, dims, p);
   if (rc != PSDF_OK) return rc;
@@ -1424,6 +1456,13 @@ int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const flo
 #define CASE(I, A, B, C, O, D)                                                   \
   if (ti0 == I && t1 == A && t2 == B && t3 == C && to == O && p.final_dot == D) \
     return launch_dbl_bwd<I, A, B, C, O, D>(p, N, X, V, dY, dX2, a, st);
+  if (dY2) {     // with the plain backward of an upstream gradient of the outputs folded in: the reference's SDF net only
+    if (ti0 == 4 && t1 == 2 && t2 == 2 && t3 == 2 && to == 3 && !p.final_dot)
+      return launch_dbl_bwd<4, 2, 2, 2, 3, false, true>(p, N, X, V, dY, dX2, a, st, dY2);
+    if (ti0 == 3 && t1 == 2 && t2 == 2 && t3 == 2 && to == 3 && !p.final_dot)
+      return launch_dbl_bwd<3, 2, 2, 2, 3, false, true>(p, N, X, V, dY, dX2, a, st, dY2);
+    return PSDF_ERR_UNSUPPORTED;
+  }
   CASE(4, 2, 2, 2, 3, false)  // 52 -> 32x3 -> 33   (reference SDF net, models.py:153-161)
   CASE(3, 2, 2, 2, 3, false)  // 36 -> 32x3 -> 33
   CASE(4, 2, 2, 2, 1, true)   // 49..64 -> 32x3 -> 1..4
@@ -1433,6 +1472,22 @@ int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const flo
   CASE(4, 4, 4, 4, 1, true)
 #undef CASE
   return PSDF_ERR_UNSUPPORTED;
+}
+
+int psdf_mlp_double_backward(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                             const float* const* biases, const float* dY, const float* V, float* dX2,
+                             float* const* dW, float* const* db, void* stream) {
+  return mlp_double_backward_impl(n_layers, dims, N, X, weights, biases, dY, V, nullptr, dX2, dW, db, stream);
+}
+
+// The double backward AND the plain backward of an upstream gradient dY2 [dims[n_layers], N] of the net's outputs in one pass
+// (mlp_dbl_bwd_kernel<..., Y2>): dX2 = (data gradient of the double backward) + (dX of psdf_mlp_backward for dY2), dW / db
+// accumulate both.  The reference's SDF net shapes (<= 64 inputs, 32 x 3 hidden, 5..48 outputs); -2 otherwise.
+int psdf_mlp_double_backward_plus(int n_layers, const int* dims, int64_t N, const float* X, const float* const* weights,
+                                  const float* const* biases, const float* dY, const float* V, const float* dY2, float* dX2,
+                                  float* const* dW, float* const* db, void* stream) {
+  if (!dY2) return PSDF_ERR_ARG;
+  return mlp_double_backward_impl(n_layers, dims, N, X, weights, biases, dY, V, dY2, dX2, dW, db, stream);
 }
 
 }  // extern "C"

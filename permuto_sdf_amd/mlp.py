@@ -392,9 +392,19 @@ def double_backward_supported(dims):
                    (2, 2, 2, 2, 1, True), (3, 4, 4, 4, 1, True), (4, 4, 4, 4, 1, True)}
 
 
-def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None, module=None):
+def double_backward_plus_supported(dims):
+    """psdf_mlp_double_backward_plus: the reference's SDF net shapes (<= 64 inputs, 32 x 3 hidden, matrix output layer <= 48 rows)"""
+    return (len(dims) == 5 and 32 < dims[0] <= 64 and 16 < dims[1] <= 32 and 16 < dims[2] <= 32 and 16 < dims[3] <= 32
+            and 32 < dims[4] <= 48)
+
+
+def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None, module=None, gy2_fm=None):
     """-> (dX [C,N], [dW_l], [db_l]) of <dx(x, params; gy), v>; fused kernel where one is built, torch (GPU) otherwise;
-    into = (dWs, dbs): accumulate the parameter gradients there; gy_fm = None: the unit gradient of output 0"""
+    into = (dWs, dbs): accumulate the parameter gradients there; gy_fm = None: the unit gradient of output 0.
+    gy2_fm [dims[-1], N] (only where double_backward_plus_supported(dims)): the plain backward of this upstream gradient of the
+    outputs rides in the same launch -- dX is then the sum of both data gradients, the parameter gradients hold both"""
+    if gy2_fm is not None:
+        assert double_backward_plus_supported(dims), dims
     if gy_fm is None and not double_backward_supported(dims):      # the torch route needs the tensor: unit gradient of output 0
         gy_fm = torch.zeros((dims[-1], x_fm.shape[1]), dtype=torch.float32, device=x_fm.device)
         gy_fm[0].fill_(1.0)
@@ -417,8 +427,12 @@ def mlp_double_backward(dims, x_fm, weights, biases, gy_fm, v_fm, into=None, mod
     Bp = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in bs])
     W = (ctypes.c_void_p * n_layers)(*[w.data_ptr() for w in dWs])
     B = (ctypes.c_void_p * n_layers)(*[b.data_ptr() for b in dbs])
-    L.call("psdf_mlp_double_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), Wp, Bp, L.ptr(gy_fm),
-           L.ptr(v_fm), L.ptr(dx2), W, B, L.stream())
+    if gy2_fm is not None:
+        L.call("psdf_mlp_double_backward_plus", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), Wp, Bp, L.ptr(gy_fm),
+               L.ptr(v_fm), L.ptr(gy2_fm), L.ptr(dx2), W, B, L.stream())
+    else:
+        L.call("psdf_mlp_double_backward", L.c_i(n_layers), _dims_array(dims), L.c_l(N), L.ptr(x_fm), Wp, Bp, L.ptr(gy_fm),
+               L.ptr(v_fm), L.ptr(dx2), W, B, L.stream())
     return dx2, dWs, dbs
 
 

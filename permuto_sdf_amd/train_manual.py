@@ -26,7 +26,7 @@ import torch
 from . import _lib as L
 from .bridge import PermutoSDF, RaySamplesPacked, VolumeRendering as VR
 from .encoding import encode_backward_raw, encode_double_backward_raw, encode_forward_raw
-from .mlp import (_grad_views, mlp_forward_wide_f16_raw, lipshitz_normalize_all_backward_raw, lipshitz_normalize_all_raw, mlp_backward_raw,
+from .mlp import (_grad_views, double_backward_plus_supported, mlp_forward_wide_f16_raw, lipshitz_normalize_all_backward_raw, lipshitz_normalize_all_raw, mlp_backward_raw,
                   mlp_double_backward, mlp_forward_raw, pack_params)
 from .neus import (eikonal_loss_raw, l1_loss_raw, nerf_composite_backward_raw, nerf_composite_forward_raw, neus_composite_backward_raw,
                    neus_composite_forward_raw, sigmoid_rows_backward_raw, sigmoid_rows_raw)
@@ -101,6 +101,8 @@ class ManualTrainer(Trainer):
         self._prefetched = None
         self._prefetch_side = None
         self._pos_pool = None
+        # the SDF net's plain backward (g_y) inside the double backward's launch (g_n); PSDF_TRAIN_FUSE_SDF_BWD=0: two launches
+        self.fuse_sdf_backward = os.environ.get("PSDF_TRAIN_FUSE_SDF_BWD", "1") != "0"
         self._events = [torch.cuda.Event() for _ in range(4)] if self.dev.type == "cuda" else []
 
     def _side_stream(self):
@@ -211,12 +213,14 @@ class ManualTrainer(Trainer):
         views = [_grad_views(d, flat=flat[offs[i]:offs[i + 1]])[1:] for i, d in enumerate((d1, d2, dc))]
         return views[0], views[1], views[2], flat[offs[3]:offs[4]]
 
-    def _sdf_gradient_backward(self, g_n, feat, dfeat, e0, pts, win, ws, bs, gb, want_pos=False, extra_dfeat=None):
+    def _sdf_gradient_backward(self, g_n, feat, dfeat, e0, pts, win, ws, bs, gb, want_pos=False, extra_dfeat=None, extra_gy=None):
         """backward of  n = d sdf / d p  for an upstream g_n [N,3]: lattice and parameter gradients are accumulated; returns the
-        position gradient when asked (the shifted points of the curvature term depend on n)"""
+        position gradient when asked (the shifted points of the curvature term depend on n).  extra_gy [33, N]: an upstream
+        gradient of the net's outputs on the same samples -- its plain backward rides in the double backward's launch (round 6:
+        one forward recomputation and one sweep for both); extra_dfeat: a data gradient to add instead (the two-launch form)"""
         enc, dims = self.sdf.encoding, self.sdf.mlp_sdf.dims
         gg = _enc_dbl_gather(enc, pts, win, g_n, dfeat)
-        dX2, _, _ = mlp_double_backward(dims, feat, ws, bs, e0, gg, into=(gb.dWs, gb.dbs), module=self.sdf.mlp_sdf)
+        dX2, _, _ = mlp_double_backward(dims, feat, ws, bs, e0, gg, into=(gb.dWs, gb.dbs), module=self.sdf.mlp_sdf, gy2_fm=extra_gy)
         if extra_dfeat is not None:
             dX2 = dX2 + extra_dfeat
         _enc_dbl_scatter(enc, pts, win, g_n, dfeat, dX2)
@@ -453,8 +457,11 @@ class ManualTrainer(Trainer):
                            L.ptr(g_from_shift), L.stream())
                     g_n = g_n + g_from_shift
                 # first evaluation: from (sdf, geom) directly and from n through the double backward; ONE lattice scatter
-                dX1, _, _ = mlp_backward_raw(dims_s, feat, ws, bs, g_y, need_dx=True, into=(gb.dWs, gb.dbs))
-                self._sdf_gradient_backward(g_n, feat, dfeat, e0, pts, win, ws, bs, gb, extra_dfeat=dX1)
+                if self.fuse_sdf_backward and double_backward_plus_supported(dims_s):
+                    self._sdf_gradient_backward(g_n, feat, dfeat, e0, pts, win, ws, bs, gb, extra_gy=g_y)
+                else:
+                    dX1, _, _ = mlp_backward_raw(dims_s, feat, ws, bs, g_y, need_dx=True, into=(gb.dWs, gb.dbs))
+                    self._sdf_gradient_backward(g_n, feat, dfeat, e0, pts, win, ws, bs, gb, extra_dfeat=dX1)
             else:
                 self._dp_lattice_final(1)      # (no foreground samples on this rank: the same collective at the same point)
             # ---- off-surface points

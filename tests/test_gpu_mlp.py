@@ -207,6 +207,41 @@ def test_double_backward_through_input_gradient(dev, dims):
         assert (a.bias.grad.cpu().double() - b.bias.grad).abs().max() <= 2e-4 * sc(b.bias.grad)
 
 
+@pytest.mark.parametrize("dims,N", [([52, 32, 32, 32, 33], 48_864), ([36, 32, 32, 32, 33], 1_003), ([51, 30, 32, 28, 40], 517)])
+def test_double_backward_with_the_plain_backward_folded_in(dev, dims, N):
+    """psdf_mlp_double_backward_plus (round 6): the double backward for an upstream gradient V of d y0 / d x AND the plain backward of
+    an upstream gradient gy2 of the outputs, one launch.  Against float64 autograd of  <d y0/d x, V> + <y, gy2>  (every gradient
+    within 2e-5 of its largest entry) and against the two separate launches it replaces (fp32 rounding of a different summation
+    order: 1e-5)"""
+    import copy
+    from permuto_sdf_amd.mlp import double_backward_plus_supported, mlp_backward_raw, mlp_double_backward
+    assert double_backward_plus_supported(dims) and not double_backward_plus_supported([52, 64, 64, 64, 33])
+    torch.manual_seed(N)
+    ref = _ref_net(dims).to(dev)
+    x = torch.randn(N, dims[0], device=dev)
+    v = torch.randn(N, dims[0], device=dev)
+    gy2 = torch.randn(N, dims[-1], device=dev) * 0.3
+    net64 = copy.deepcopy(ref).double()
+    x64 = x.double().requires_grad_(True)
+    y64 = net64(x64)
+    (g64,) = torch.autograd.grad(y64[:, 0:1], x64, torch.ones_like(y64[:, 0:1]), create_graph=True)
+    ((g64 * v.double()).sum() + (y64 * gy2.double()).sum()).backward()
+    want = [x64.grad] + [p.grad for p in net64.parameters()]
+    lin = [m for m in ref if isinstance(m, torch.nn.Linear)]
+    ws, bs = [l.weight for l in lin], [l.bias for l in lin]
+    x_fm, v_fm, gy2_fm = x.t().contiguous(), v.t().contiguous(), gy2.t().contiguous()
+    dx, dWs, dbs = mlp_double_backward(dims, x_fm, ws, bs, None, v_fm, gy2_fm=gy2_fm)
+    got = [dx.t()] + [t for pair in zip(dWs, dbs) for t in pair]
+    dx_a, dWa, dba = mlp_double_backward(dims, x_fm, ws, bs, None, v_fm)
+    dx_b, dWb, dbb = mlp_backward_raw(dims, x_fm, ws, bs, gy2_fm, need_dx=True)
+    two = [(dx_a + dx_b).t()] + [t for l in range(len(dWa)) for t in (dWa[l] + dWb[l], dba[l] + dbb[l])]
+    for i, (g, w, t) in enumerate(zip(got, want, two)):
+        scale = float(w.abs().max())
+        assert bool(torch.isfinite(g).all()), i
+        e64, e2 = float((g.double() - w).abs().max()) / scale, float((g - t).abs().max()) / scale
+        assert e64 <= 2e-5 and e2 <= 1e-5, (i, e64, e2)
+
+
 @pytest.mark.parametrize("dims", [[52, 32, 32, 32, 1], [36, 64, 64, 64, 1], [52, 32, 32, 32, 33]])
 def test_data_gradient_only_variant(dev, dims):
     """psdf_mlp_backward with dW = db = NULL (analytic normals at inference): same dX as the full backward"""
