@@ -30,7 +30,12 @@ def _python_set(func_name):
 def test_backward_and_double_backward_tables_match():
     src = open(os.path.join(ROOT, "permuto_sdf_amd", "csrc", "mlp_bwd.hip")).read()
     assert _cases(src, "psdf_mlp_backward") == _python_set("backward_supported")
-    assert _cases(src, "psdf_mlp_double_backward") == _python_set("double_backward_supported")
+    # (the table lives in the function both psdf_mlp_double_backward and psdf_mlp_double_backward_plus call)
+    assert _cases(src, "mlp_double_backward_impl") == _python_set("double_backward_supported")
+    # the fused form (double backward + plain backward of an output gradient): exactly the two SDF-net instantiations, and the host
+    # predicate admits exactly their tile signatures
+    plus = set(re.findall(r"launch_dbl_bwd<(\d), (\d), (\d), (\d), (\d), false, true>", src))
+    assert plus == {("4", "2", "2", "2", "3"), ("3", "2", "2", "2", "3")}
 
 
 def test_predicates_on_the_nets_of_the_reference():
@@ -38,6 +43,9 @@ def test_predicates_on_the_nets_of_the_reference():
     assert backward_supported([52, 32, 32, 32, 33]) and double_backward_supported([52, 32, 32, 32, 33])   # SDF net
     assert backward_supported([36, 64, 64, 64, 1]) and double_backward_supported([36, 64, 64, 64, 1])     # BASELINE net
     assert backward_supported([52, 64, 64, 64, 65]) and backward_supported([80, 64, 64, 3])               # background nets
+    from permuto_sdf_amd.mlp import double_backward_plus_supported
+    assert double_backward_plus_supported([52, 32, 32, 32, 33]) and double_backward_plus_supported([36, 32, 32, 32, 33])
+    assert not double_backward_plus_supported([36, 64, 64, 64, 1]) and not double_backward_plus_supported([52, 32, 32, 32, 1])
     assert backward_supported([112, 128, 128, 64, 3]) and backward_supported([111, 128, 128, 64, 3])     # colour net: mlp_wide.hip
     assert not backward_supported([200, 256, 256, 64, 3]) and not double_backward_supported([112, 128, 128, 64, 3])
     assert not double_backward_supported([80, 64, 64, 3])
