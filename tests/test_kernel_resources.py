@@ -140,7 +140,7 @@ SPILLING = {
     r"mlp_bwd_kernelILi4ELi2ELi2ELi2ELi3ELb0ELb1ELb1ELi8E": 24, r"mlp_bwd_kernelILi4ELi2ELi2ELi2ELi3ELb0ELb0ELb1ELi8E": 8,
     # double backward of the BASELINE net (psdf_mlp_double_backward; the reference's own net is 32 wide and does not spill):
     # fp32-MFMA form, one wave per SIMD -- DESIGN.md "Next": the workgroup-cooperative split form
-    r"mlp_dbl_bwd_kernelILi3ELi4ELi4ELi4ELi1ELb1EE": 256, r"mlp_dbl_bwd_kernelILi4ELi4ELi4ELi4ELi1ELb1EE": 320,
+    r"mlp_dbl_bwd_kernelILi3ELi4ELi4ELi4ELi1ELb1ELb0EE": 256, r"mlp_dbl_bwd_kernelILi4ELi4ELi4ELi4ELi1ELb1ELb0EE": 320,
     # background colour head 80 -> 64x2 -> 3 with parameter gradients (models.py:463-469): every training step, one register
     r"mlp_bwd_kernelILi5ELi4ELi4ELi0ELi1ELb1ELb1ELb1ELi4E": 8,
     # fused encode -> MLP forward of a 32-wide net with 33 outputs (psdf_encode_mlp_forward: the sphere tracer's colour pass)
