@@ -1307,6 +1307,10 @@ int psdf_mlp_forward_wide_f16(int n_layers, const int* dims, int64_t N, const fl
   if (ov && *(volatile uint32_t*)ov) return PSDF_ERR_UNSUPPORTED;
   if (dims[0] <= 112 && dims[1] <= 128 && dims[2] <= 128 && dims[3] <= 64 && dims[4] <= 16 && !(dims[1] <= 64 && dims[2] <= 64))
     return wide_forward_f16<7, 8, 8, 4, 1>(dims, N, X, weights, biases, Y, (hipStream_t)stream);
+  // the background density / feature net 52 -> 64 x 3 -> 65 (models.py:451-459)
+  if (dims[0] <= 64 && dims[1] > 32 && dims[1] <= 64 && dims[2] > 32 && dims[2] <= 64 && dims[3] > 32 && dims[3] <= 64 &&
+      dims[4] > 16 && dims[4] <= 80)
+    return wide_forward_f16<4, 4, 4, 4, 5>(dims, N, X, weights, biases, Y, (hipStream_t)stream);
   return PSDF_ERR_UNSUPPORTED;
 }
 

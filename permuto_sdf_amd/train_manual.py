@@ -238,7 +238,9 @@ class ManualTrainer(Trainer):
         l1b = list(bgn.mlp_feat_and_density.layers)
         w1b, b1b = [l.weight for l in l1b], [l.bias for l in l1b]
         d1 = bgn.mlp_feat_and_density.dims
-        fd = mlp_forward_raw(d1, feat4, pack_params(d1, w1b, b1b))                        # [65, M]
+        fd = mlp_forward_wide_f16_raw(d1, feat4, w1b, b1b)                                # [65, M] on the fp16 matrix pipe (round 6)
+        if fd is None:      # (the library declined: fp32 MFMAs)
+            fd = mlp_forward_raw(d1, feat4, pack_params(d1, w1b, b1b))
         gel = torch.nn.functional.gelu(fd[1:65])
         sh4 = PermutoSDF.spherical_harmonics(dirs_b, 4)
         x2 = torch.cat([gel, sh4.t()], 0)                                                 # [80, M]

@@ -696,7 +696,7 @@ def test_null_upstream_gradient_is_the_unit_gradient_of_output_zero(dev, dims):
 
 
 @pytest.mark.parametrize("dims,N", [([111, 128, 128, 64, 3], 49_153), ([112, 128, 128, 64, 3], 5_003), ([100, 96, 128, 48, 2], 777),
-                                    ([111, 128, 128, 64, 3], 31)])
+                                    ([111, 128, 128, 64, 3], 31), ([52, 64, 64, 64, 65], 21_920), ([36, 48, 64, 40, 33], 1_001)])
 def test_wide_net_forward_f16_against_float64(dev, dims, N):
     """psdf_mlp_forward_wide_f16 (csrc/mlp_wide.hip, round 6: the colour network's forward on the fp16 matrix pipe, two pieces per
     operand): against float64, 4e-6 of the largest output (the bar of the SDF net's split-fp16 forward), beside torch's fp32;

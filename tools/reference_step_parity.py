@@ -346,6 +346,16 @@ def main():
                         g4, l4, _, _ = run_reference(mode, it, git, seed, permute_seed=ps, forced_fg=fg_ref)
                         draws.append((g4, l4))
                     gref4, loss_ref4 = draws[0]
+                # the ENSEMBLE of the reference's own evaluations on these samples (the run itself + the six re-numberings), dense
+                # tensors only (the MLP parameters: small): a cloud of equally valid fp32 roundings of the same gradients.  Its
+                # diameter per tensor (largest distance between two members) and, below, OUR distance to the nearest member are
+                # what `tests/test_gpu_reference_step.py` holds the same-samples gradients to where 1e-4 of the single run is not
+                # met: ONE run is one draw of that cloud, and so is the maximum of six distances from it (the late state's last
+                # SDF bias: 2e-5 .. 1e-4 from run to run, float atomics upstream) -- a bar made of one draw fails ~1 run in 8.
+                ensemble = None
+                if draws:
+                    dense_keys = [k for k in gref if "lattice" not in k]
+                    ensemble = [{k: gd[k].detach().double().clone() for k in dense_keys if k in gd} for gd in [gref] + [d_[0] for d_ in draws]]
                 repeats = []                                                         # the same run again, three times
                 for _ in range(3):
                     g3, l3, _, _ = run_reference(mode, it, git, seed)
@@ -368,6 +378,15 @@ def main():
                 worst["by_tensor_max"] = {k: max(c_["grads"][k]["max_rel"] for c_ in cmps if k in c_["grads"] and "max_rel" in c_["grads"][k])
                                           for k in cmps[0]["grads"] if "max_rel" in cmps[0]["grads"][k]}
                 worst["draws_worst_dense"] = [c_["worst_dense"] for c_ in cmps]
+                diam = {}
+                for k in ensemble[0]:
+                    sc_ = float(ensemble[0][k].abs().max())
+                    if sc_ == 0.0:
+                        continue
+                    diam[k] = max(float((ensemble[i_][k] - ensemble[j_][k]).abs().max()) / sc_
+                                  for i_ in range(len(ensemble)) for j_ in range(i_ + 1, len(ensemble)) if k in ensemble[i_] and k in ensemble[j_])
+                worst["ensemble_members"] = len(ensemble)
+                worst["ensemble_diameter_by_tensor"] = diam
                 case["reference_self_noise_same_samples"] = worst
             # the float64 arbiter of the SDF net's last bias (see run_reference): the reference's own fp32 gradient against it ...
             ARB = "sdf.mlp_sdf.layers.%d.bias" % (len([k for k in gref if k.startswith("sdf.mlp_sdf.layers.") and k.endswith(".bias")]) - 1)
@@ -398,6 +417,15 @@ def main():
                                                        nr_fg_samples=last.get("nr_fg_samples"))
                         if variant[1] is not None:     # ... and ours on the SAME samples against the same float64 sum
                             case["arbiter_last_sdf_bias"][name + "_same_samples_vs_f64"] = to_f64(g)
+                            if ensemble is not None:   # distance to the NEAREST member of the reference's ensemble, per dense tensor
+                                near = {}
+                                for k in ensemble[0]:
+                                    sc_ = float(ensemble[0][k].abs().max())
+                                    if sc_ == 0.0 or k not in g:
+                                        continue
+                                    gk = g[k].detach().double()
+                                    near[k] = min(float((gk - m_[k]).abs().max()) / sc_ for m_ in ensemble if k in m_)
+                                case[name + variant[0]]["nearest_reference_member_by_tensor"] = near
                         if variant[1] is None and fg_ref is not None and fg_own is not None:
                             # how far this trainer's OWN foreground samples are from the reference's (same rays, same jitter
                             # streams; the importance samples follow each side's own SDF evaluations)
