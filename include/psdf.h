@@ -164,7 +164,9 @@ int psdf_mlp_backward_split_f16_form(void);
 unsigned psdf_mlp_f16_range_events(void);
 
 /* ---- mlp_wide.hip ---- */
-/* Forward of the reference's colour network shape (LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3, models.py:54-129,349-350: dims[0] <= 112,
+/* (also, round 6: the background density / feature net 52 -> 64 x 3 -> 65, models.py:451-459: dims[0] <= 64, 32 < dims[1..3] <= 64,
+   16 < dims[4] <= 80)
+   Forward of the reference's colour network shape (LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3, models.py:54-129,349-350: dims[0] <= 112,
    dims[1], dims[2] <= 128, dims[3] <= 64, dims[4] <= 16) on the fp16 matrix pipe with two pieces per fp32 operand: X [dims[0], N],
    Y [dims[4], N] feature-major; weights[l] [dims[l+1], dims[l]] (for a LipshitzMLP the NORMALISED weights), biases[l]; GELU between
    the layers, the last one linear.  -2: another shape, stream capture, PSDF_MLP_WIDE_SPLIT=f32, or a value beyond the fp16 range met
