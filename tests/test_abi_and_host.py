@@ -47,6 +47,17 @@ def test_argument_errors_and_empty_inputs_without_gpu(lib):
     assert lib.psdf_mlp_packed_size(4, (ctypes.c_int * 5)(36, 64, 64, 64, 1)) > 0
     assert lib.psdf_adamw_step(ctypes.c_int64(8), None, None, None, None, ctypes.c_float(1e-3), ctypes.c_float(.9),
                                ctypes.c_float(.99), ctypes.c_float(1e-15), ctypes.c_float(0), 1, ctypes.c_float(1), None) == -1
+    # psdf_mlp_double_backward_plus: the folded-in output gradient is not optional (-1), and other nets than the reference's SDF
+    # shapes are declined (-2) before anything is launched
+    d5 = lambda *v: (ctypes.c_int * 5)(*v)
+    p4 = (ctypes.c_void_p * 4)(4096, 4096, 4096, 4096)
+    dummy_ = ctypes.c_void_p(4096)
+    assert lib.psdf_mlp_double_backward_plus(4, d5(52, 32, 32, 32, 33), ctypes.c_int64(16), dummy_, p4, p4, None, dummy_, None,
+                                             dummy_, p4, p4, None) == -1
+    assert lib.psdf_mlp_double_backward_plus(4, d5(36, 64, 64, 64, 1), ctypes.c_int64(16), dummy_, p4, p4, None, dummy_, dummy_,
+                                             dummy_, p4, p4, None) == -2
+    assert lib.psdf_mlp_double_backward_plus(4, d5(52, 32, 32, 32, 33), n0, dummy_, p4, p4, None, dummy_, dummy_, dummy_, p4, p4,
+                                             None) == 0
     # a level of the table above 4 GiB: the forward's 32-bit gather offsets cannot address it -> "unsupported", before any launch
     # (the pointers only have to be non-null for the argument check that precedes it)
     dummy = ctypes.c_void_p(4096)
