@@ -207,7 +207,8 @@ def test_double_backward_through_input_gradient(dev, dims):
         assert (a.bias.grad.cpu().double() - b.bias.grad).abs().max() <= 2e-4 * sc(b.bias.grad)
 
 
-@pytest.mark.parametrize("dims,N", [([52, 32, 32, 32, 33], 48_864), ([36, 32, 32, 32, 33], 1_003), ([51, 30, 32, 28, 40], 517)])
+@pytest.mark.parametrize("dims,N", [([52, 32, 32, 32, 33], 48_864), ([36, 32, 32, 32, 33], 1_003), ([51, 30, 32, 28, 40], 517),
+                                    ([52, 32, 32, 32, 33], 17), ([52, 32, 32, 32, 33], 1)])
 def test_double_backward_with_the_plain_backward_folded_in(dev, dims, N):
     """psdf_mlp_double_backward_plus (round 6): the double backward for an upstream gradient V of d y0 / d x AND the plain backward of
     an upstream gradient gy2 of the outputs, one launch.  Against float64 autograd of  <d y0/d x, V> + <y, gy2>  (every gradient
@@ -332,7 +333,7 @@ def test_split_bf16_backward_matches_float64(dev, K0, N):
 @pytest.mark.parametrize("dy_scale", [1.0, 1e-6, "wide"])
 @pytest.mark.parametrize("dims,N", [([111, 128, 128, 64, 3], 49_152), ([112, 128, 128, 64, 3], 5_003), ([100, 96, 128, 48, 2], 777),
                                     ([52, 64, 64, 64, 65], 23_001), ([36, 64, 64, 64, 33], 4_096),
-                                    ([80, 64, 64, 3], 22_753), ([70, 60, 50, 3], 1_001)])
+                                    ([80, 64, 64, 3], 22_753), ([70, 60, 50, 3], 1_001), ([80, 64, 64, 3], 17), ([111, 128, 128, 64, 3], 1)])
 def test_wide_net_backward_matches_float64(dev, dims, N, dy_scale, arith, monkeypatch):
     """csrc/mlp_wide.hip (the colour network's widths, models.py:349-350, the background density net's and -- two hidden layers,
     split-fp16 kernel only -- the background colour head's, models.py:463-469) through
