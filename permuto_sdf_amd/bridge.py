@@ -88,30 +88,33 @@ class RaySamplesPacked:
 
     def __init__(self, nr_rays, nr_samples_maximum, device=None, _alloc=True):
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.m_nr_rays = int(nr_rays)
-        self.max_nr_samples = int(nr_samples_maximum)
-        self.rays_have_equal_nr_of_samples = False
-        self.fixed_nr_of_samples_per_ray = 0
-        self.has_sdf = False
-        self._exact = False  # set by producers whose output is already hole-free and ray ordered
-        self._dense = False  # set by compaction: every slot of the sample tensors belongs to a ray (outputs need no zero fill)
+        # (straight into __dict__: a training step builds nine of these, and every attribute through __setattr__ below is host
+        #  time of a host-bound step; the values are exactly what the assignments would store)
+        d = self.__dict__
+        d["m_nr_rays"] = int(nr_rays)
+        d["max_nr_samples"] = int(nr_samples_maximum)
+        d["rays_have_equal_nr_of_samples"] = False
+        d["fixed_nr_of_samples_per_ray"] = 0
+        d["has_sdf"] = False
+        d["_exact"] = False  # set by producers whose output is already hole-free and ray ordered
+        d["_dense"] = False  # set by compaction: every slot of the sample tensors belongs to a ray (outputs need no zero fill)
         # host-side knowledge that spares later compactions their sync (round 4): the per-ray counts of a march (device tensor),
         # the number of non-empty rays once those counts have been on the host, the exact total of a merge derived from them
-        self._ray_counts = None
-        self._host_nonempty = None
-        self._known_total = None
+        d["_ray_counts"] = None
+        d["_host_nonempty"] = None
+        d["_known_total"] = None
         if _alloc:
-            M, R = self.max_nr_samples, self.m_nr_rays
-            f = dict(dtype=torch.float32, device=dev)
-            self.cur_nr_samples = L.zeroed_int(dev)      # a [1] int32 slice of a pooled, pre-zeroed buffer
-            self.samples_pos = torch.empty((M, 3), **f)
-            self.samples_pos_4d = torch.empty((M, 4), **f)
-            self.samples_dirs = torch.empty((M, 3), **f)
-            self.samples_z = torch.empty((M, 1), **f)
-            self.samples_dt = torch.empty((M, 1), **f)
-            self.samples_sdf = torch.empty((M, 1), **f)
-            self.ray_fixed_dt = torch.empty((R, 1), **f)
-            self.ray_start_end_idx = torch.empty((R, 2), dtype=torch.int32, device=dev)
+            M, R = d["max_nr_samples"], d["m_nr_rays"]
+            f32 = torch.float32
+            d["cur_nr_samples"] = L.zeroed_int(dev)      # a [1] int32 slice of a pooled, pre-zeroed buffer
+            d["samples_pos"] = torch.empty((M, 3), dtype=f32, device=dev)
+            d["samples_pos_4d"] = torch.empty((M, 4), dtype=f32, device=dev)
+            d["samples_dirs"] = torch.empty((M, 3), dtype=f32, device=dev)
+            d["samples_z"] = torch.empty((M, 1), dtype=f32, device=dev)
+            d["samples_dt"] = torch.empty((M, 1), dtype=f32, device=dev)
+            d["samples_sdf"] = torch.empty((M, 1), dtype=f32, device=dev)
+            d["ray_fixed_dt"] = torch.empty((R, 1), dtype=f32, device=dev)
+            d["ray_start_end_idx"] = torch.empty((R, 2), dtype=torch.int32, device=dev)
 
     def __setattr__(self, name, value):
         """Python may overwrite any attribute (the reference does: sdf_utils.py:216 assigns samples_pos).  A container whose
