@@ -67,6 +67,17 @@ def mlp_forward_raw(dims, x_fm, packed, skip=None, out=None, f16=False):
 _wide_f16_fn = None
 
 
+def wide_f16_forward_candidate(dims):
+    """the shapes psdf_mlp_forward_wide_f16 is instantiated for (csrc/mlp_wide.hip): the colour network 111-128-128-64-3 and the
+    background density net 52-64-64-64-65; asked before the call so that other nets do not pay an ABI round trip for a -2"""
+    if len(dims) != 5:
+        return False
+    d = dims
+    colour = d[0] <= 112 and d[1] <= 128 and d[2] <= 128 and d[3] <= 64 and d[4] <= 16 and not (d[1] <= 64 and d[2] <= 64)
+    density = d[0] <= 64 and 32 < d[1] <= 64 and 32 < d[2] <= 64 and 32 < d[3] <= 64 and 16 < d[4] <= 80
+    return colour or density
+
+
 def mlp_forward_wide_f16_raw(dims, x_fm, weights, biases, out=None):
     """The colour network's forward (LipshitzMLP 111 -> 128 -> 128 -> 64 -> 3, models.py:349-350) on the fp16 matrix pipe with
     two pieces per fp32 operand (csrc/mlp_wide.hip, round 6): x_fm [dims[0], N] feature-major, `weights` / `biases` the torch
@@ -290,8 +301,12 @@ class _FusedMLPFunc(torch.autograd.Function):
         x_fm = x.t()
         if not x_fm.is_contiguous():
             x_fm = x_fm.contiguous()
-        packed = pack_params(module.dims, weights, biases)
-        y = mlp_forward_raw(module.dims, x_fm, packed)
+        y = None
+        if wide_f16_forward_candidate(module.dims):      # colour network / background density net: the fp16 matrix pipe (round 6)
+            y = mlp_forward_wide_f16_raw(module.dims, x_fm, weights, biases)
+        if y is None:
+            packed = pack_params(module.dims, weights, biases)
+            y = mlp_forward_raw(module.dims, x_fm, packed)
         ctx.module = module
         ctx.n_layers = n_layers
         ctx.save_for_backward(x, *weights, *biases)   # the INPUTS themselves: they keep their place in the graph
